@@ -1,0 +1,177 @@
+"""Deterministic synthetic inputs for the line-by-line hot path.
+
+No real spectroscopic data ships with the reference (download-test-data needs
+network), so benchmarks and parity tests run on seeded synthetic columns, line
+lists in the HITRAN 160-column layout, and smooth cross-section tables.  The
+shapes and magnitudes follow the reference's formats (Appendix B of SURVEY.md):
+HITRAN .par records (gas-optics/src/parse_HITRAN_file.c:77-100) and two-column
+CSV tables with one header line (utilities/src/parse_csv.c:55-166).
+"""
+import os
+
+import numpy as np
+
+# HITRAN molecule ids (gas-optics/src/molecules.h:32-88)
+H2O, CO2, O3, N2O, CO, CH4, O2, N2 = 1, 2, 3, 4, 5, 6, 7, 22
+
+#: fraction of the band's lines given to each absorber (200k/300k/250k/200k/30k/15k/5k of 1.0M)
+LINE_SHARE = {H2O: 0.20, CO2: 0.30, O3: 0.25, CH4: 0.20, N2O: 0.03, O2: 0.015, CO: 0.005}
+
+
+def profile(col=0, num_levels=61):
+    """One synthetic column: pressures [mb] TOA->surface, temperatures [K], VMRs [ppmv]."""
+    V = num_levels
+    k = np.arange(V, dtype=np.float64) / (V - 1)
+    p = 0.01 + (1013.25 - 0.01) * k ** 2.5
+    rng = np.random.default_rng(1000 + col)
+    t = 200.0 + 90.0 * k + rng.uniform(-2.0, 2.0, V)
+    t_layer = 0.5 * (t[:-1] + t[1:])
+    ppmv = {
+        H2O: 4.0 * (1.5e4 / 4.0) ** k,                       # 4 ppmv -> 1.5e4 ppmv log-linear
+        O3: 0.02 + 8.0 * np.exp(-0.5 * (np.log(p / 10.0) / 0.9) ** 2),
+        CO2: np.full(V, 400.0), CH4: np.full(V, 1.8), N2O: np.full(V, 0.33),
+        CO: np.full(V, 0.1), O2: np.full(V, 0.209e6), N2: np.full(V, 0.781e6),
+    }
+    return dict(p=p, t=t, t_layer=t_layer, t_surf=float(t[-1] + 1.0), ppmv=ppmv,
+                emissivity=0.98, albedo=0.2, mu0=0.6, mu_dif=0.5, tsi=1360.0,
+                cfc_ppmv={0: np.full(V, 2.3e-4), 1: np.full(V, 5.2e-4)})
+
+
+def line_list(mol_id, n, w0, wn, seed=20261003):
+    """Synthetic line parameters for one molecule, sorted by centre.
+
+    yair/yself/en/n/delta carry f32-representable values because the reference
+    reads those columns through a float (parse_HITRAN_file.c:197-212)."""
+    rng = np.random.default_rng(seed + 7919 * mol_id)
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)
+    v0 = np.sort(np.round(rng.uniform(w0, wn, n), 6))
+    return dict(
+        v0=v0,
+        s0=10.0 ** rng.uniform(-27.0, -20.0, n),
+        yair=f32(np.round(rng.uniform(0.02, 0.10, n), 4)),
+        yself=f32(np.round(rng.uniform(0.1, 0.5, n), 3)),
+        en=f32(np.round(rng.uniform(0.0, 4000.0, n), 4)),
+        nexp=f32(np.round(rng.uniform(0.4, 0.8, n), 2)),
+        delta=f32(np.round(rng.uniform(-0.02, 0.02, n), 6)),
+        iso=np.ones(n, dtype=np.int32),
+    )
+
+
+def band_line_lists(total_lines, w0, wn, seed=20261003):
+    """Per-molecule line lists for one band with the LINE_SHARE split."""
+    return {m: line_list(m, max(int(round(total_lines * s)), 1), w0, wn, seed)
+            for m, s in LINE_SHARE.items()}
+
+
+def _fw(v, width, prec):
+    """Fortran-style fixed-width float: drop the leading zero when it does not fit (F5.4 -> '.0834')."""
+    s = "%.*f" % (prec, v)
+    if len(s) > width:
+        s = s.replace("0.", ".", 1)
+    assert len(s) <= width, (s, width)
+    return s.rjust(width)
+
+
+def write_hitran_par(path, lists):
+    """Write {mol_id: lines} as fixed-width HITRAN-2012 160-char records, sorted by centre.
+
+    S is stored as the raw (un-rescaled) 296 K strength, as in a real .par file."""
+    recs = []
+    for mol, ln in lists.items():
+        for j in range(ln["v0"].size):
+            recs.append((ln["v0"][j], mol, ln, j))
+    recs.sort(key=lambda r: r[0])
+    with open(path, "w") as f:
+        for v, mol, ln, j in recs:
+            iso = int(ln["iso"][j])
+            iso_c = "0" if iso == 10 else (chr(ord("A") + iso - 11) if iso > 10 else str(iso))
+            s = "%2d%1s%12.6f%10.3E%10.3E" % (mol, iso_c, v, ln["s0"][j], 0.0)
+            s += _fw(ln["yair"][j], 5, 4) + _fw(ln["yself"][j], 5, 3) + "%10.4f" % ln["en"][j]
+            s += _fw(ln["nexp"][j], 4, 2) + _fw(ln["delta"][j], 8, 6)
+            assert len(s) == 67, (len(s), s)
+            f.write(s + " " * 93 + "\n")
+
+
+def read_back_par_values(lists):
+    """Round line parameters to what survives the .par text format (so that arrays
+    fed directly to a checker equal what a loader parses from write_hitran_par)."""
+    out = {}
+    for mol, ln in lists.items():
+        o = dict(ln)
+        o["s0"] = np.array([float("%10.3E" % s) for s in ln["s0"]])
+        f32 = lambda a: a.astype(np.float32).astype(np.float64)
+        o["yair"] = f32(np.array([float(_fw(v, 5, 4)) for v in ln["yair"]]))
+        o["yself"] = f32(np.array([float(_fw(v, 5, 3)) for v in ln["yself"]]))
+        o["en"] = f32(np.array([float("%10.4f" % v) for v in ln["en"]]))
+        o["nexp"] = f32(np.array([float(_fw(v, 4, 2)) for v in ln["nexp"]]))
+        o["delta"] = f32(np.array([float(_fw(v, 8, 6)) for v in ln["delta"]]))
+        o["v0"] = np.array([float("%12.6f" % v) for v in ln["v0"]])
+        out[mol] = o
+    return out
+
+
+# ---- smooth analytic cross-section tables (CSV: header + "wavenumber,value") ---- #
+def _table(w_lo, w_hi, step, fn):
+    w = np.arange(w_lo, w_hi + 0.5 * step, step)
+    return w, fn(w)
+
+
+def tables(sw=False):
+    """Analytic stand-ins for the data bundle's CSV files (same roles, smooth shapes)."""
+    hi = 50000.0 if sw else 3500.0
+    step = 50.0 if sw else 5.0
+    t = {}
+    t["h2o_self_296"] = _table(0.0, hi, step, lambda w: 2.0e-22 * np.exp(-w / 600.0) + 1.0e-27)
+    t["h2o_foreign_296"] = _table(0.0, hi, step, lambda w: 4.0e-24 * np.exp(-w / 450.0) + 1.0e-29)
+    t["h2o_self_t"] = _table(0.0, hi, step, lambda w: 0.02 + 0.01 * np.exp(-w / 2000.0))
+    t["h2o_foreign_t"] = _table(0.0, hi, step, lambda w: 0.002 + 0.001 * np.exp(-w / 2000.0))
+    t["o3_ctm"] = _table(10.0, hi, step, lambda w: 1.0e-21 * np.exp(-0.5 * ((w - (30000.0 if sw else 1040.0)) / (4000.0 if sw else 60.0)) ** 2))
+    t["cfc11"] = _table(700.0, 1300.0, 1.0, lambda w: 2.0e-18 * np.exp(-0.5 * ((w - 850.0) / 15.0) ** 2))
+    t["cfc12"] = _table(700.0, 1300.0, 1.0, lambda w: 3.0e-18 * np.exp(-0.5 * ((w - 920.0) / 12.0) ** 2))
+    t["cia_n2n2"] = _table(1.0, 400.0 if not sw else 5000.0, 2.0, lambda w: 1.0e-46 * np.exp(-0.5 * ((w - 100.0) / 60.0) ** 2))
+    t["cia_o2n2"] = _table(1200.0, 1900.0 if not sw else 9000.0, 2.0, lambda w: 2.0e-46 * np.exp(-0.5 * ((w - 1560.0) / 80.0) ** 2))
+    t["cia_o2o2"] = _table(1200.0, 1900.0 if not sw else 30000.0, 2.0, lambda w: 3.0e-46 * np.exp(-0.5 * ((w - 1560.0) / 80.0) ** 2))
+    # Planck-like 5772 K solar shape [arbitrary units]; normalised by create_solar_flux
+    t["solar"] = _table(0.5, 50010.0, 10.0, lambda w: w ** 3 / np.expm1(1.4387773538277202 * w / 5772.0))
+    return t
+
+
+def write_csv(path, w, y, header="wavenumber,value", extra_cols=0):
+    with open(path, "w") as f:
+        f.write(header + ",x" * extra_cols + "\n")
+        for a, b in zip(w, y):
+            f.write("%.6f,%.9e" % (a, b) + ",0" * extra_cols + "\n")
+
+
+def write_data_bundle(root, lw_lines, sw_lines, seed=20261003,
+                      lw_band=(1.0, 3250.0), sw_band=(1.0, 50000.0)):
+    """Lay out a synthetic 'grtcode-data'-style directory; returns dict of paths + the line lists."""
+    os.makedirs(os.path.join(root, "water_vapor_continuum"), exist_ok=True)
+    out = {"root": root}
+    lists = {}
+    for band, nlines, rng_ in (("lw", lw_lines, lw_band), ("sw", sw_lines, sw_band)):
+        if nlines <= 0:
+            continue
+        ll = band_line_lists(nlines, rng_[0], rng_[1], seed + (0 if band == "lw" else 1))
+        path = os.path.join(root, f"hitran_{band}.par")
+        write_hitran_par(path, ll)
+        out[f"hitran_{band}"] = path
+        lists[band] = read_back_par_values(ll)
+    for band in ("lw", "sw"):
+        t = tables(sw=(band == "sw"))
+        d = os.path.join(root, f"water_vapor_continuum_{band}")
+        os.makedirs(d, exist_ok=True)
+        write_csv(os.path.join(d, "296MTCKD25_F.csv"), *t["h2o_foreign_296"])
+        write_csv(os.path.join(d, "296MTCKD25_S.csv"), *t["h2o_self_296"])
+        write_csv(os.path.join(d, "CKDF.csv"), *t["h2o_foreign_t"], extra_cols=2)
+        write_csv(os.path.join(d, "CKDS.csv"), *t["h2o_self_t"], extra_cols=2)
+        out[f"h2o_ctm_{band}"] = d
+        for name in ("o3_ctm", "cfc11", "cfc12", "cia_n2n2", "cia_o2n2", "cia_o2o2"):
+            p = os.path.join(root, f"{name}_{band}.csv")
+            write_csv(p, *t[name])
+            out[f"{name}_{band}"] = p
+    p = os.path.join(root, "solar_flux.csv")
+    write_csv(p, *tables(sw=True)["solar"])
+    out["solar"] = p
+    out["lines"] = lists
+    return out
