@@ -1,0 +1,86 @@
+"""Build the C-ABI library: C99 host layer (gcc) + hand-written gfx950 kernels (hipcc).
+
+    python -m grtcode_amd.build            # -> grtcode_amd/lib/libgrtcode_hip.so + the four .a
+    python -m grtcode_amd.build --force
+
+Cross-compiles without a GPU (hipcc --offload-arch=gfx950).  Outputs stay in-tree
+(git-ignored) so that they travel with gpurun snapshots.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "lib", "obj")
+LIB = os.path.join(HERE, "lib")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+SO = os.path.join(LIB, "libgrtcode_hip.so")
+
+HOST_SRC = ["grt_error.c", "grt_util.c", "grt_grid.c", "grt_device.c", "grt_optics.c", "grt_tips.c",
+            "grt_gas_optics.c", "grt_solvers.c", "grt_pipeline.c"]
+HIP_SRC = ["k_gas_optics.hip", "k_optics.hip", "k_longwave.hip", "k_shortwave.hip"]
+
+# the reference's archive names (*/src/Makefile.am): which objects go where
+ARCHIVES = {
+    "libgrtcode_utilities.a": ["grt_error", "grt_util", "grt_grid", "grt_device", "grt_optics", "k_optics"],
+    "libgas_optics.a": ["grt_tips", "grt_gas_optics", "k_gas_optics"],
+    "liblongwave.a": ["k_longwave"],
+    "libshortwave.a": ["k_shortwave"],
+    # solvers' host entry points and the batched pipeline reference both bands
+    "libgrtcode_hip_ext.a": ["grt_solvers", "grt_pipeline"],
+}
+
+CFLAGS = ["-std=gnu99", "-O2", "-ffp-contract=off", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter",
+          "-D__HIP_PLATFORM_AMD__", f"-I{ROOT}/include", f"-I{ROCM}/include", f"-I{CSRC}/host"]
+HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-munsafe-fp-atomics",
+            f"-I{ROOT}/include"]
+
+
+def _newer(src, dst, extra=()):
+    if not os.path.exists(dst):
+        return True
+    t = os.path.getmtime(dst)
+    return any(os.path.getmtime(p) > t for p in (src,) + tuple(extra))
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(" ".join(cmd) + "\n" + r.stdout)
+        raise RuntimeError(f"build step failed: {cmd[0]} {cmd[-1]}")
+    return r.stdout
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(ROOT, "include", h) for h in ("grtcode_hip_api.h", "grt_ext.h")]
+    headers += [os.path.join(CSRC, "grt_kernels.h"), os.path.join(CSRC, "host", "grt_internal.h"),
+                os.path.join(CSRC, "host", "grt_molecule_table.h")]
+    objs = []
+    for f in HOST_SRC:
+        src, obj = os.path.join(CSRC, "host", f), os.path.join(OBJ, f[:-2] + ".o")
+        if force or _newer(src, obj, headers):
+            out = _run(["gcc"] + CFLAGS + ["-c", src, "-o", obj])
+            if verbose and out:
+                print(out)
+        objs.append(obj)
+    for f in HIP_SRC:
+        src, obj = os.path.join(CSRC, "hip", f), os.path.join(OBJ, f[:-4] + ".o")
+        if force or _newer(src, obj, headers):
+            _run(["hipcc"] + HIPFLAGS + ["-c", src, "-o", obj])
+        objs.append(obj)
+    if force or any(_newer(o, SO) for o in objs):
+        _run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs +
+             [f"-L{ROCM}/lib", "-lamdhip64", "-lm", f"-Wl,-rpath,{ROCM}/lib"])
+        for name, members in ARCHIVES.items():
+            path = os.path.join(LIB, name)
+            if os.path.exists(path):
+                os.remove(path)
+            _run(["ar", "rcs", path] + [os.path.join(OBJ, m + ".o") for m in members])
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,149 @@
+/* grt_kernels.h -- C-callable launch wrappers of the hand-written gfx950 kernels.
+ *
+ * Shared between the C99 host layer (csrc/host) and the HIP translation units
+ * (csrc/hip).  Every wrapper enqueues on the given stream and returns a
+ * hipError_t cast to int (0 == success); none of them allocates or synchronises.
+ * All pointers are device pointers unless a name ends in _h.
+ */
+#ifndef GRT_KERNELS_H_
+#define GRT_KERNELS_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRT_MAX_ISO 18      /* largest isotopologue count in the molecule table (O3) */
+#define GRT_MAX_SLOTS 53    /* NUM_MOLS */
+#define GRT_MAX_TABLES 32   /* 4 H2O + 1 O3 + 21 CFC + 3 CIA + spare */
+
+/* Merged line store: all active molecules, sorted by unshifted centre.  The five
+   f32 arrays hold values the reference itself reads through a float
+   (parse_HITRAN_file.c:197-212), so nothing is lost by the narrower storage. */
+typedef struct GrtLineStore
+{
+    uint64_t n;
+    double const *v0;       /* centre [cm-1] */
+    double const *s0;       /* strength rescaled at load (parse_HITRAN_file.c:372-384) */
+    float const *yair;
+    float const *yself;
+    float const *en;
+    float const *nexp;
+    float const *delta;
+    uint8_t const *iso;     /* 1-based isotopologue id */
+    uint8_t const *slot;    /* molecule slot (order of add_molecule) */
+    double dmax;            /* max |delta| over the store: bound on the pressure shift */
+} GrtLineStore;
+
+/* Per-column layer state prepared on the host in the reference's arithmetic
+   (curtis_godson.c:25-106, kernels.c:52-66,117-127) and uploaded once per column.
+   Layout of one column block (doubles):
+     lay  [L][4]            : pavg, tavg, 1/tavg, log(296/tavg)
+     ms   [nslot][L][4]     : ps, pavg-ps, ns, doppler factor sqrt(2 kb T/(m c c))
+     q    [nslot][L][GRT_MAX_ISO] : 1/Q(T, iso)
+     cont [L][GRT_MAX_TABLES] : per-layer multiplier of each continuum-type table
+     h2o  [L][4]            : N_s(296/T), Ps, P-Ps, 296-T  (kernels.c:484-487)
+*/
+typedef struct GrtColumnLayout
+{
+    int num_layers;
+    int num_slots;
+    int num_tables;      /* linear tables: tau += cont[layer][k]*table[k][f] */
+    int has_h2o_ctm;     /* tables 0..3 of the h2o block are F296,S296,CKDF,CKDS */
+    uint64_t stride;     /* doubles per column */
+    uint64_t off_lay, off_ms, off_q, off_cont, off_h2o;
+} GrtColumnLayout;
+
+typedef struct GrtGasOpticsArgs
+{
+    GrtLineStore lines;
+    GrtColumnLayout lay;
+    double const *colstate;   /* [ncol][lay.stride] */
+    double const *tables;     /* [num_tables][nw] linear tables (O3, CFC, CIA) */
+    double const *h2o_tables; /* [4][nw] or NULL */
+    double w0, wres;          /* bins.w0 / bins.wres (spectral_bin.c:39-40) */
+    uint64_t nw;
+    int ncol;
+    double *tau;              /* [ncol][L][nw] */
+    uint64_t tau_col_stride;  /* doubles between columns */
+    int tile;                 /* wavenumbers per workgroup (multiple of 64) */
+    int nslice;               /* line slices per tile (>=1); >1 uses global atomics */
+    int fast;                 /* 0: reference operation order; 1: fused-multiply-add form */
+} GrtGasOpticsArgs;
+
+int grt_launch_gas_optics(void *stream, GrtGasOpticsArgs const *a);
+
+/* Debug/parity hook: per-(layer,line) preparation only (kernels.c:34-131) and the
+   integer window [s,e] of kernels.c:431-437 (s=1,e=0 when the line is skipped). */
+int grt_launch_line_prep(void *stream, GrtGasOpticsArgs const *a, int col,
+                         double *vnn, double *snn, double *gamma, double *alpha,
+                         int64_t *win_s, int64_t *win_e);
+
+/* rayleigh.c:29-68: n_layer [L] on device. */
+int grt_launch_rayleigh(void *stream, int num_layers, double w0, double dw, uint64_t nw,
+                        double const *n_layer, double *tau, double *omega, double *g);
+
+/* optics.c:128-148: K objects, each [n]; pointers passed by value (K <= 8). */
+typedef struct GrtOpticsPtrs { double const *tau[8]; double const *omega[8]; double const *g[8]; } GrtOpticsPtrs;
+int grt_launch_add_optics(void *stream, uint64_t n, int num_optics, GrtOpticsPtrs const *in,
+                          double *tau, double *omega, double *g);
+
+/* optics.c:306-321 */
+int grt_launch_sample_optics(void *stream, uint64_t n, uint64_t factor, double *tau,
+                             double *omega, double *g, double const *tau_in,
+                             double const *omega_in, double const *g_in);
+
+/* longwave.c:226-264.  Batched: column c uses tau/omega + c*optics_stride, temps at
+   t_layers + c*L, t_levels + c*V, t_surf[c]; emis shared unless emis_stride != 0. */
+typedef struct GrtLwArgs
+{
+    int num_levels, ncol;
+    double w0, dw;
+    uint64_t nw;
+    double const *tau, *omega;      /* [ncol][L][nw]; omega may be NULL (treated as 0) */
+    uint64_t optics_stride;
+    double const *t_layers, *t_levels, *t_surf;
+    double const *emis; uint64_t emis_stride;
+    double *flux_up, *flux_down;    /* [ncol][V][nw] or NULL when only integrating */
+    uint64_t flux_stride;
+    double *integrated;             /* optional [ncol][6]: up TOA, up SFC, up USER, dn TOA, dn SFC, dn USER */
+    int user_level;                 /* -1: none */
+} GrtLwArgs;
+int grt_launch_lw(void *stream, GrtLwArgs const *a);
+
+/* shortwave.c:410-453 */
+typedef struct GrtSwArgs
+{
+    int num_levels, ncol;
+    uint64_t nw;
+    double dw;
+    double const *tau, *omega, *g;  /* [ncol][L][nw] */
+    uint64_t optics_stride;
+    double const *mu_dir;           /* [ncol] */
+    double mu_dif;
+    double const *alb_dir, *alb_dif; uint64_t alb_stride;
+    double const *tsi;              /* [ncol] */
+    double const *solar;            /* [nw] */
+    double *flux_up, *flux_down; uint64_t flux_stride;
+    double *integrated; int user_level;
+} GrtSwArgs;
+int grt_launch_sw(void *stream, GrtSwArgs const *a);
+
+/* Fused Rayleigh + combine for the clear-sky driver sequence (rayleigh.c:39 +
+   optics.c:138-145 with K=2, gas omega=g=0, Rayleigh omega=1,g=0):
+   tau_tot = tau_gas + tau_R, omega = tau_R/tau_tot, g = 0/ tau_R.  n_layer [ncol][L]. */
+int grt_launch_clear_sky_optics(void *stream, int num_layers, int ncol, double w0, double dw,
+                                uint64_t nw, double const *n_layer, double const *tau_gas,
+                                double *tau, double *omega, double *g);
+
+/* driver.c:302-326 on device rows: sum 0.5*(row[i]+row[i+1])*dw of row r goes to
+   out[(r/group)*out_stride + out_offset + r%group]. */
+int grt_launch_integrate_rows(void *stream, double const *const *rows_dev, int nrows,
+                              uint64_t nw, double dw, double *out, int group, int out_stride,
+                              int out_offset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,139 @@
+// k_longwave.hip -- four-stream no-scattering longwave solver for gfx950.
+//
+// Reference: longwave/src/longwave.c:68-264 (planck_law, effective_planck, lw_flux,
+// lw_fluxes_kernel).  One thread per (wavenumber, column); tau/omega are read and the
+// fluxes written as (layer|level, wavenumber) rows, so every access is coalesced across
+// the wavefront.  The reference walks stream -> layer and keeps three 200-element
+// per-thread arrays; we walk layer -> stream with the four stream intensities in
+// registers, which needs no per-thread array and produces each flux element by the
+// same left-to-right sum (0 + c2[0] I0) + c2[1] I1 + c2[2] I2 + c2[3] I3 as the
+// reference's `+=` over its stream loop (longwave.c:184,194-205), i.e. identical values.
+// The Planck terms do not depend on the stream and are evaluated once per layer and
+// direction instead of once per stream (same inputs, same results).
+//
+// HBM-bound by design (1 944 B per wavenumber at 60 layers: SURVEY.md §8a19); the fp64
+// exp's make it VALU-visible at small grids, which is why column batches share a launch.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include "../grt_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int kBlock = 128;
+constexpr double kMaxExpArg = 700.;   // grtcode_config.h:41
+
+// longwave.c:68-94
+__device__ __forceinline__ double planck(double T, double w)
+{
+    double const c1 = 1.1910429526245744e-8;
+    double const c2 = 1.4387773538277202;
+    double e = c2*w/T;
+    if (e > kMaxExpArg)
+    {
+        e = kMaxExpArg;
+    }
+    e = exp(e);
+    return (c1*w*w*w)/(e - 1.);
+}
+
+// longwave.c:100-118 with the two Planck values supplied by the caller
+__device__ __forceinline__ double effective_planck(double bc, double be, double tau)
+{
+    double const a = 0.193;
+    double const b = 0.013;
+    return (bc + (a*tau + b*tau*tau)*be)/(1. + a*tau + b*tau*tau);
+}
+
+__device__ __forceinline__ double extinction(double c1, double tau)
+{
+    double e = c1*tau;                     // longwave.c:177-183
+    if (e > kMaxExpArg)
+    {
+        e = kMaxExpArg;
+    }
+    return exp(e);
+}
+
+__global__ __launch_bounds__(kBlock) void lw_kernel(GrtLwArgs a)
+{
+    double const c1[4] = {-14.402613260847248, -3.0302159969901132,
+                          -1.4925584280108841, -1.0746123148178333};   // longwave.c:160-163
+    double const c2[4] = {0.07587638482015649, 0.676114979733751,
+                          1.3726594476601073, 1.0169418413757783};     // longwave.c:165-168
+    uint64_t const i = (uint64_t)blockIdx.x*kBlock + threadIdx.x;
+    int const col = blockIdx.y;
+    if (i >= a.nw)
+    {
+        return;
+    }
+    int const V = a.num_levels;
+    int const L = V - 1;
+    double const w = a.w0 + i*a.dw;                                      // longwave.c:246
+    double const *tau = a.tau + (uint64_t)col*a.optics_stride + i;
+    double const *omega = a.omega ? a.omega + (uint64_t)col*a.optics_stride + i : nullptr;
+    double const *tl = a.t_layers + (uint64_t)col*L;
+    double const *tv = a.t_levels + (uint64_t)col*V;
+    double const emis = a.emis[(uint64_t)col*a.emis_stride + i];
+    double *fu = a.flux_up + (uint64_t)col*a.flux_stride + i;
+    double *fd = a.flux_down + (uint64_t)col*a.flux_stride + i;
+
+    double I[4] = {0., 0., 0., 0.};
+    fd[0] = 0.;                                                          // longwave.c:171
+    for (int j = 0; j < L; ++j)
+    {
+        uint64_t const o = (uint64_t)j*a.nw;
+        double const t = omega ? tau[o]*(1. - omega[o]) : tau[o]*(1. - 0.);   // longwave.c:252
+        double const val = effective_planck(planck(tl[j], w), planck(tv[j + 1], w), t);
+        double f = 0.;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+        {
+            double const ext = extinction(c1[s], t);
+            double const p = (1. - ext)*val;                             // longwave.c:193
+            I[s] = p + I[s]*ext;
+            f += c2[s]*I[s];                                             // longwave.c:195
+        }
+        fd[(uint64_t)(j + 1)*a.nw] = f;
+    }
+    double const bs = planck(a.t_surf[col], w);
+    double f = 0.;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+    {
+        I[s] = emis*bs + (1 - emis)*I[s];                                // longwave.c:202
+        f += c2[s]*I[s];
+    }
+    fu[(uint64_t)L*a.nw] = f;
+    for (int j = L - 1; j >= 0; --j)
+    {
+        uint64_t const o = (uint64_t)j*a.nw;
+        double const t = omega ? tau[o]*(1. - omega[o]) : tau[o]*(1. - 0.);
+        double const val = effective_planck(planck(tl[j], w), planck(tv[j], w), t);
+        double g = 0.;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+        {
+            double const ext = extinction(c1[s], t);
+            double const p = (1. - ext)*val;                             // longwave.c:211
+            I[s] = p + I[s]*ext;
+            g += c2[s]*I[s];
+        }
+        fu[o] = g;
+    }
+}
+
+} // namespace
+
+extern "C" int grt_launch_lw(void *stream, GrtLwArgs const *a)
+{
+    if (a->flux_up == nullptr || a->flux_down == nullptr || a->ncol < 1)
+    {
+        return (int)hipErrorInvalidValue;
+    }
+    dim3 const grid((unsigned)((a->nw + kBlock - 1)/kBlock), a->ncol, 1);
+    hipLaunchKernelGGL(lw_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, *a);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,195 @@
+// k_optics.hip -- streaming (HBM-bound) optics kernels for gfx950: Rayleigh, optics
+// combination, sub-sampling, the fused clear-sky combine and the spectral trapezoid.
+// One thread per wavenumber (or per element), coalesced fp64 reads/writes, grid-stride
+// so one launch covers any grid size with <= 2048 workgroups.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../grt_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int kBlock = 256;
+
+inline unsigned grid_for(uint64_t n)
+{
+    uint64_t const b = (n + kBlock - 1)/kBlock;
+    return (unsigned)(b < 2048 ? (b ? b : 1) : 2048);
+}
+
+// shortwave/src/rayleigh.c:38-39
+__device__ __forceinline__ double rayleigh_tau(double w, double n)
+{
+    double const W = w*1.e-4;
+    return (n*1.e-20*W*W*W*W)/(0.268675*1.e5*(9.38076E2 - 10.8426*W*W));
+}
+
+__global__ __launch_bounds__(kBlock) void rayleigh_kernel(int L, double w0, double dw, uint64_t nw,
+                                                          double const *n_layer, double *tau,
+                                                          double *omega, double *g)
+{
+    uint64_t const total = (uint64_t)L*nw;
+    for (uint64_t o = (uint64_t)blockIdx.x*kBlock + threadIdx.x; o < total; o += (uint64_t)gridDim.x*kBlock)
+    {
+        uint64_t const i = o/nw;
+        uint64_t const j = o - i*nw;
+        double const w = w0 + j*dw;                      // rayleigh.c:63
+        omega[o] = 1.;
+        g[o] = 0.;
+        tau[o] = rayleigh_tau(w, n_layer[i]);
+    }
+}
+
+// utilities/src/optics.c:128-148 (result object starts zero-filled: optics.c:194-199)
+__global__ __launch_bounds__(kBlock) void add_optics_kernel(uint64_t n, int K, GrtOpticsPtrs in,
+                                                            double *tau, double *omega, double *g)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x*kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x*kBlock)
+    {
+        double gs = 0., os = 0., ts = 0.;
+        for (int j = 0; j < K; ++j)
+        {
+            double const t = in.tau[j][i], o = in.omega[j][i], gg = in.g[j][i];
+            gs += gg*o*t;
+            os += o*t;
+            ts += t;
+        }
+        gs /= os;
+        os /= ts;
+        g[i] = gs;
+        omega[i] = os;
+        tau[i] = ts;
+    }
+}
+
+// utilities/src/optics.c:306-321
+__global__ __launch_bounds__(kBlock) void sample_optics_kernel(uint64_t n, uint64_t factor, double *tau,
+                                                               double *omega, double *g,
+                                                               double const *tau_in,
+                                                               double const *omega_in,
+                                                               double const *g_in)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x*kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x*kBlock)
+    {
+        uint64_t const o = i*factor;
+        tau[i] = tau_in[o];
+        omega[i] = omega_in[o];
+        g[i] = g_in[o];
+    }
+}
+
+// Rayleigh + add_optics({gas, rayleigh}) in one pass (driver.c:247-270,381-383):
+// with gas omega = g = 0 and Rayleigh omega = 1, g = 0 the sums of optics.c:138-145 are
+//   g_sum = 0*0*tg + 0*1*tr, o_sum = 0*tg + 1*tr, t_sum = tg + tr.
+__global__ __launch_bounds__(kBlock) void clear_sky_kernel(int L, int ncol, double w0, double dw,
+                                                           uint64_t nw, double const *n_layer,
+                                                           double const *tau_gas, double *tau,
+                                                           double *omega, double *g)
+{
+    uint64_t const per_col = (uint64_t)L*nw;
+    uint64_t const total = per_col*ncol;
+    for (uint64_t o = (uint64_t)blockIdx.x*kBlock + threadIdx.x; o < total; o += (uint64_t)gridDim.x*kBlock)
+    {
+        uint64_t const c = o/per_col;
+        uint64_t const r = o - c*per_col;
+        uint64_t const i = r/nw;
+        uint64_t const j = r - i*nw;
+        double const tr = rayleigh_tau(w0 + j*dw, n_layer[c*L + i]);
+        double const tg = tau_gas[o];
+        double gs = 0., os = 0., ts = 0.;
+        gs += 0.*0.*tg;  os += 0.*tg;  ts += tg;
+        gs += 0.*1.*tr;  os += 1.*tr;  ts += tr;
+        gs /= os;
+        os /= ts;
+        g[o] = gs;
+        omega[o] = os;
+        tau[o] = ts;
+    }
+}
+
+// framework/src/driver.c:302-326: one workgroup per row; wavefront shuffle reduction,
+// then LDS across the 4 waves.  (Summation order differs from the serial loop.)
+__global__ __launch_bounds__(kBlock) void integrate_rows_kernel(double const *const *rows, uint64_t nw,
+                                                                double dw, double *out, int group,
+                                                                int out_stride, int out_offset)
+{
+    __shared__ double part[kBlock/64];
+    double const *row = rows[blockIdx.x];
+    double s = 0.;
+    for (uint64_t i = threadIdx.x; i + 1 < nw; i += kBlock)
+    {
+        s += 0.5*(row[i] + row[i + 1])*dw;
+    }
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        s += __shfl_down(s, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0)
+    {
+        part[threadIdx.x >> 6] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        int const r = blockIdx.x;
+        out[(r/group)*out_stride + out_offset + (r % group)] = ((part[0] + part[1]) + part[2]) + part[3];
+    }
+}
+
+} // namespace
+
+extern "C" int grt_launch_rayleigh(void *stream, int num_layers, double w0, double dw, uint64_t nw,
+                                   double const *n_layer, double *tau, double *omega, double *g)
+{
+    hipLaunchKernelGGL(rayleigh_kernel, dim3(grid_for((uint64_t)num_layers*nw)), dim3(kBlock), 0,
+                       (hipStream_t)stream, num_layers, w0, dw, nw, n_layer, tau, omega, g);
+    return (int)hipGetLastError();
+}
+
+extern "C" int grt_launch_add_optics(void *stream, uint64_t n, int num_optics, GrtOpticsPtrs const *in,
+                                     double *tau, double *omega, double *g)
+{
+    if (num_optics < 1 || num_optics > 8)
+    {
+        return (int)hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(add_optics_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream,
+                       n, num_optics, *in, tau, omega, g);
+    return (int)hipGetLastError();
+}
+
+extern "C" int grt_launch_sample_optics(void *stream, uint64_t n, uint64_t factor, double *tau,
+                                        double *omega, double *g, double const *tau_in,
+                                        double const *omega_in, double const *g_in)
+{
+    hipLaunchKernelGGL(sample_optics_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream,
+                       n, factor, tau, omega, g, tau_in, omega_in, g_in);
+    return (int)hipGetLastError();
+}
+
+extern "C" int grt_launch_clear_sky_optics(void *stream, int num_layers, int ncol, double w0, double dw,
+                                           uint64_t nw, double const *n_layer, double const *tau_gas,
+                                           double *tau, double *omega, double *g)
+{
+    hipLaunchKernelGGL(clear_sky_kernel, dim3(grid_for((uint64_t)num_layers*nw*ncol)), dim3(kBlock), 0,
+                       (hipStream_t)stream, num_layers, ncol, w0, dw, nw, n_layer, tau_gas, tau, omega, g);
+    return (int)hipGetLastError();
+}
+
+extern "C" int grt_launch_integrate_rows(void *stream, double const *const *rows_dev, int nrows,
+                                         uint64_t nw, double dw, double *out, int group,
+                                         int out_stride, int out_offset)
+{
+    if (nrows < 1)
+    {
+        return 0;
+    }
+    if (group < 1)
+    {
+        return (int)hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(integrate_rows_kernel, dim3(nrows), dim3(kBlock), 0, (hipStream_t)stream,
+                       rows_dev, nw, dw, out, group, out_stride, out_offset);
+    return (int)hipGetLastError();
+}

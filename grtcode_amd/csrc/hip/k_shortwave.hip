@@ -1,0 +1,220 @@
+// k_shortwave.hip -- two-stream delta-Eddington + adding shortwave solver for gfx950.
+//
+// Reference: shortwave/src/shortwave.c:68-453 (delta_eddington_scaling_jww1976,
+// meador_weaver_1980, eddington_mw1980, sw_adding, sw_flux, sw_fluxes_kernel).
+// One thread per (wavenumber, column), coalesced (layer|level, wavenumber) rows.
+//
+// The reference keeps five 200-element layer arrays plus three level arrays per thread
+// (scratch spills on a GPU).  We run the adding method as two sweeps with O(1) state:
+//   sweep 1 (surface -> TOA): layer R/T from the Eddington solution, the downward-beam
+//     reflectances of shortwave.c:280-294 are parked in the output rows themselves
+//     (flux_up[i] <- R_dir_downward[i], flux_down[i] <- R_dif_downward[i]);
+//   sweep 2 (TOA -> surface): layer R/T are recomputed (same inputs, same values), the
+//     upward-beam reflectance of :299-306 is carried in registers, and each parked
+//     pair is consumed and overwritten by the final fluxes of :308-329,401-405,447-451.
+// Every expression keeps the reference's evaluation order, so results are identical.
+// The in-kernel range checks of the reference are no-ops on device builds
+// (debug.h:105-116) and are not restated.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include "../grt_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int kBlock = 128;
+constexpr double kMaxExpArg = 700.;   // grtcode_config.h:41
+
+struct LayerRT { double R, T, Tpure; };
+
+// shortwave.c:97-207 (+ gamma definitions :226-230).  WITH_PURE mirrors T_pure != NULL.
+template <bool WITH_PURE>
+__device__ __forceinline__ LayerRT eddington(double omega, double tau, double mu, double g)
+{
+    LayerRT r;
+    double const gamma1 = 0.25*(7. - omega*(4. + 3.*g));
+    double const gamma2 = -0.25*(1. - omega*(4. - 3.*g));
+    double const gamma3 = 0.25*(2. - 3.*g*mu);
+    r.Tpure = 0.;
+    if (omega <= 0.0)
+    {
+        r.R = 0.;
+        r.T = exp(-tau/mu);
+        r.Tpure = r.T;
+    }
+    else
+    {
+        double const gamma4 = 1. - gamma3;
+        double const alpha1 = gamma1*gamma4 + gamma2*gamma3;
+        double const alpha2 = gamma1*gamma3 + gamma2*gamma4;
+        double const k = sqrt(gamma1*gamma1 - gamma2*gamma2);
+        double t = tau;
+        if (1./mu > k && tau/mu > kMaxExpArg)
+        {
+            t = kMaxExpArg*mu;
+        }
+        else if (tau*k > kMaxExpArg)
+        {
+            t = kMaxExpArg/k;
+        }
+        double const tp = exp(t/mu);
+        if (tp <= 1.0)
+        {
+            r.R = 0.;
+            r.T = 1.;
+            r.Tpure = 1.;
+        }
+        else
+        {
+            double const tm = exp(-t/mu);
+            double const tkm = exp(-t*k);
+            double const tkp = exp(t*k);
+            r.Tpure = tm;
+            if (omega >= 1.)
+            {
+                r.R = (1./(1. + gamma1*t))*(gamma1*t + (gamma3 - gamma1*mu)*(1. - tm));
+                r.T = 1. - r.R;
+            }
+            else
+            {
+                r.R = (omega/((1. - k*k*mu*mu)*((k + gamma1)*tkp + (k - gamma1)*tkm)))*
+                      ((1. - k*mu)*(alpha2 + k*gamma3)*tkp - (1. + k*mu)*(alpha2 - k*gamma3)*tkm -
+                      2.*k*(gamma3 - alpha2*mu)*tm);
+                r.T = tm*(1. - (omega/((1. - k*k*mu*mu)*((k + gamma1)*tkp +
+                      (k - gamma1)*tkm)))*((1. + k*mu)*(alpha1 + k*gamma4)*tkp -
+                      (1. - k*mu)*(alpha1 - k*gamma4)*tkm - 2.*k*(gamma4 + alpha1*mu)*tp));
+            }
+        }
+    }
+    if (WITH_PURE)
+    {
+        if (r.Tpure > r.T)
+        {
+            r.T = r.Tpure;
+        }
+    }
+    return r;
+}
+
+struct LayerProps { double Rdir, Tdir, Tpure, Rdif, Tdif; };
+
+__device__ __forceinline__ LayerProps layer_props(double omega, double g, double tau,
+                                                  double mu_dir, double mu_dif)
+{
+    // shortwave.c:86-89
+    double const gs = g/(g + 1.);
+    double const f = g*g;
+    double const os = (1. - f)*omega/(1. - omega*f);
+    double const ts = tau*(1. - omega*f);
+    LayerRT const d = eddington<true>(os, ts, mu_dir, gs);
+    LayerRT const s = eddington<false>(os, ts, mu_dif, gs);
+    LayerProps p;
+    p.Rdir = d.R; p.Tdir = d.T; p.Tpure = d.Tpure; p.Rdif = s.R; p.Tdif = s.T;
+    return p;
+}
+
+__global__ __launch_bounds__(kBlock) void sw_kernel(GrtSwArgs a)
+{
+    uint64_t const i = (uint64_t)blockIdx.x*kBlock + threadIdx.x;
+    int const col = blockIdx.y;
+    if (i >= a.nw)
+    {
+        return;
+    }
+    int const V = a.num_levels;
+    int const L = V - 1;
+    uint64_t const nw = a.nw;
+    double const *tau = a.tau + (uint64_t)col*a.optics_stride + i;
+    double const *omega = a.omega + (uint64_t)col*a.optics_stride + i;
+    double const *g = a.g + (uint64_t)col*a.optics_stride + i;
+    double const mu_dir = a.mu_dir[col];
+    double const mu_dif = a.mu_dif;
+    double *fu = a.flux_up + (uint64_t)col*a.flux_stride + i;
+    double *fd = a.flux_down + (uint64_t)col*a.flux_stride + i;
+
+    // sweep 1: shortwave.c:280-294
+    double Rdir_dn = a.alb_dir[(uint64_t)col*a.alb_stride + i];
+    double Rdif_dn = a.alb_dif[(uint64_t)col*a.alb_stride + i];
+    fu[(uint64_t)L*nw] = Rdir_dn;
+    fd[(uint64_t)L*nw] = Rdif_dn;
+    for (int j = L - 1; j >= 0; --j)
+    {
+        uint64_t const o = (uint64_t)j*nw;
+        LayerProps const p = layer_props(omega[o], g[o], tau[o], mu_dir, mu_dif);
+        double const A = p.Tpure;
+        double const B = 1./(1. - p.Rdif*Rdif_dn);
+        double const ndir = p.Rdir + (A*Rdir_dn + (p.Tdir - A)*Rdif_dn)*p.Tdif*B;
+        double const ndif = p.Rdif + p.Tdif*p.Tdif*Rdif_dn*B;
+        Rdir_dn = ndir;
+        Rdif_dn = ndif;
+        fu[o] = Rdir_dn;
+        fd[o] = Rdif_dn;
+    }
+
+    // sweep 2: shortwave.c:299-329 fused, then the scalings of :401-405 and :447-451
+    double const scale = a.solar[i]*mu_dir;
+    double const tsi = a.tsi[col];
+    double dir_beam = 1.;
+    double dif_beam = 0.;
+    {
+        double up = dir_beam*fu[0];       // R[0] = dir_beam*R_dir_downward[0]
+        double dn = dir_beam;             // T[0]
+        up *= scale;
+        dn *= scale;
+        fu[0] = tsi*up;
+        fd[0] = tsi*dn;
+    }
+    double Rup_prev2 = 0.;    // R_dif_upward[lev-2]
+    double Rup_prev = 0.;     // R_dif_upward[lev-1]
+    for (int lev = 1; lev < V; ++lev)
+    {
+        uint64_t const o = (uint64_t)(lev - 1)*nw;
+        LayerProps const p = layer_props(omega[o], g[o], tau[o], mu_dir, mu_dif);   // layer lev-1
+        // R_dif_upward[lev-1]  (:299-306)
+        Rup_prev2 = Rup_prev;
+        if (lev == 1)
+        {
+            Rup_prev = p.Rdif;
+        }
+        else
+        {
+            double const Bu = 1./(1. - p.Rdif*Rup_prev2);
+            Rup_prev = p.Rdif + p.Tdif*p.Tdif*Rup_prev2*Bu;
+        }
+        if (lev > 1)
+        {
+            double const C = 1./(1. - p.Rdif*Rup_prev2);
+            dif_beam = (dir_beam*p.Rdir*Rup_prev2 + dif_beam)*p.Tdif*C + dir_beam*(p.Tdir - p.Tpure);
+        }
+        else
+        {
+            dif_beam = dir_beam*(p.Tdir - p.Tpure);
+        }
+        dir_beam *= p.Tpure;
+        uint64_t const ol = (uint64_t)lev*nw;
+        double const rdir = fu[ol];       // R_dir_downward[lev] parked by sweep 1
+        double const rdif = fd[ol];       // R_dif_downward[lev]
+        double const B = 1./(1. - rdif*Rup_prev);
+        double up = (dir_beam*rdir + dif_beam*rdif)*B;
+        double dn = dir_beam*(1. + rdir*Rup_prev*B) + dif_beam*B;
+        up *= scale;
+        dn *= scale;
+        fu[ol] = tsi*up;
+        fd[ol] = tsi*dn;
+    }
+}
+
+} // namespace
+
+extern "C" int grt_launch_sw(void *stream, GrtSwArgs const *a)
+{
+    if (a->flux_up == nullptr || a->flux_down == nullptr || a->ncol < 1)
+    {
+        return (int)hipErrorInvalidValue;
+    }
+    dim3 const grid((unsigned)((a->nw + kBlock - 1)/kBlock), a->ncol, 1);
+    hipLaunchKernelGGL(sw_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, *a);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,221 @@
+/* grt_device.c -- HIP device selection and memory helpers, called from C99.
+ * Contract: utilities/src/device.h:26-48 (device.c:26-75); the reference's
+ * gmalloc/gmemcpy/gmemset/gfree macros (debug.h:307-348) become the grt_dev_* calls.
+ * This library has no CPU execution path: HOST_ONLY objects are refused. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <hip/hip_runtime_api.h>
+#include "grt_internal.h"
+
+#define GRT_MAX_DEVICES 64
+static hipStream_t g_streams[GRT_MAX_DEVICES];
+
+int grt_dev_check(int hip_error, char const *what)
+{
+    if (hip_error != (int)hipSuccess)
+    {
+        GRT_FAIL(GRTCODE_GPU_ERR, "hip: %s (%s)", hipGetErrorString((hipError_t)hip_error), what);
+    }
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN int get_num_gpus(int * num_devices, int const verbose)
+{
+    GRT_REQUIRE_PTR(num_devices);
+    int n = 0;
+    hipError_t const e = hipGetDeviceCount(&n);
+    if (e == hipErrorNoDevice || e == hipErrorInsufficientDriver)
+    {
+        n = 0;   /* a host without a GPU reports zero devices rather than an error */
+    }
+    else
+    {
+        GRT_TRY(grt_dev_check((int)e, "hipGetDeviceCount"));
+    }
+    *num_devices = n;
+    if (verbose)
+    {
+        GRT_MESG("Found %d GPU devices:", n);
+        for (int i = 0; i < n; ++i)
+        {
+            hipDeviceProp_t prop;
+            GRT_TRY(grt_dev_check((int)hipGetDeviceProperties(&prop, i), "hipGetDeviceProperties"));
+            GRT_MESG("\tDevice #%d: %s (%s)", i, prop.name, prop.gcnArchName);
+        }
+    }
+    return GRTCODE_SUCCESS;
+}
+
+/* device.c:53-75, minus the host fallback: id == NULL picks GPU 0 and fails loudly when
+   there is none; id == HOST_ONLY is refused. */
+EXTERN int create_device(Device_t * const device, int const * const id)
+{
+    GRT_REQUIRE_PTR(device);
+    int n = 0;
+    GRT_TRY(get_num_gpus(&n, grtcode_verbosity() >= GRTCODE_INFO));
+    if (id != NULL && *id == HOST_ONLY)
+    {
+        GRT_FAIL(GRTCODE_VALUE_ERR, "HOST_ONLY requested, but this build of the library runs"
+                 " on HIP devices only (no CPU path).%s", "");
+    }
+    if (n < 1)
+    {
+        GRT_FAIL(GRTCODE_GPU_ERR, "no HIP device is visible (hipGetDeviceCount = %d).", n);
+    }
+    if (id != NULL)
+    {
+        GRT_REQUIRE_RANGE(*id, 0, n - 1);
+        *device = *id;
+    }
+    else
+    {
+        *device = DEFAULT_GPU;
+    }
+    return GRTCODE_SUCCESS;
+}
+
+int grt_dev_require(Device_t device)
+{
+    if (device == HOST_ONLY)
+    {
+        GRT_FAIL(GRTCODE_VALUE_ERR, "object requested on HOST_ONLY: this library has no CPU"
+                 " execution path (device ids >= 0 only).%s", "");
+    }
+    GRT_REQUIRE_RANGE(device, 0, GRT_MAX_DEVICES - 1);
+    GRT_TRY(grt_dev_check((int)hipSetDevice(device), "hipSetDevice"));
+    return GRTCODE_SUCCESS;
+}
+
+void *grt_dev_stream(Device_t device)
+{
+    if (device < 0 || device >= GRT_MAX_DEVICES)
+    {
+        return NULL;
+    }
+    if (g_streams[device] == NULL)
+    {
+        if (hipSetDevice(device) != hipSuccess ||
+            hipStreamCreateWithFlags(&g_streams[device], hipStreamNonBlocking) != hipSuccess)
+        {
+            g_streams[device] = NULL;
+        }
+    }
+    return (void *)g_streams[device];
+}
+
+int grt_dev_alloc(Device_t device, void **p, size_t bytes)
+{
+    GRT_REQUIRE_PTR(p);
+    GRT_TRY(grt_dev_require(device));
+    *p = NULL;
+    GRT_TRY(grt_dev_check((int)hipMalloc(p, bytes ? bytes : 8), "hipMalloc"));
+    return GRTCODE_SUCCESS;
+}
+
+int grt_dev_free(Device_t device, void *p)
+{
+    if (p == NULL)
+    {
+        return GRTCODE_SUCCESS;
+    }
+    GRT_TRY(grt_dev_require(device));
+    GRT_TRY(grt_dev_check((int)hipFree(p), "hipFree"));
+    return GRTCODE_SUCCESS;
+}
+
+int grt_dev_zero(Device_t device, void *p, size_t bytes, void *stream)
+{
+    GRT_TRY(grt_dev_require(device));
+    GRT_TRY(grt_dev_check((int)hipMemsetAsync(p, 0, bytes, (hipStream_t)stream), "hipMemsetAsync"));
+    return GRTCODE_SUCCESS;
+}
+
+int grt_dev_upload(Device_t device, void *dst, void const *src, size_t bytes, void *stream)
+{
+    GRT_TRY(grt_dev_require(device));
+    GRT_TRY(grt_dev_check((int)hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice,
+                                              (hipStream_t)stream), "hipMemcpyAsync H2D"));
+    return GRTCODE_SUCCESS;
+}
+
+int grt_dev_download(Device_t device, void *dst, void const *src, size_t bytes, void *stream)
+{
+    GRT_TRY(grt_dev_require(device));
+    GRT_TRY(grt_dev_check((int)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost,
+                                              (hipStream_t)stream), "hipMemcpyAsync D2H"));
+    return GRTCODE_SUCCESS;
+}
+
+int grt_dev_copy(Device_t device, void *dst, void const *src, size_t bytes, void *stream)
+{
+    GRT_TRY(grt_dev_require(device));
+    GRT_TRY(grt_dev_check((int)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice,
+                                              (hipStream_t)stream), "hipMemcpyAsync D2D"));
+    return GRTCODE_SUCCESS;
+}
+
+int grt_dev_sync(Device_t device, void *stream)
+{
+    GRT_TRY(grt_dev_require(device));
+    GRT_TRY(grt_dev_check((int)hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize"));
+    return GRTCODE_SUCCESS;
+}
+
+int grt_host_alloc_pinned(void **p, size_t bytes)
+{
+    GRT_REQUIRE_PTR(p);
+    GRT_TRY(grt_dev_check((int)hipHostMalloc(p, bytes ? bytes : 8, hipHostMallocDefault), "hipHostMalloc"));
+    return GRTCODE_SUCCESS;
+}
+
+int grt_host_free_pinned(void *p)
+{
+    if (p != NULL)
+    {
+        GRT_TRY(grt_dev_check((int)hipHostFree(p), "hipHostFree"));
+    }
+    return GRTCODE_SUCCESS;
+}
+
+/* ---- FFI helpers (grt_ext.h) ---- */
+EXTERN int grt_device_malloc(Device_t device, void **ptr, size_t bytes)
+{
+    GRT_TRY(grt_dev_alloc(device, ptr, bytes));
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN int grt_device_free(Device_t device, void *ptr)
+{
+    GRT_TRY(grt_dev_free(device, ptr));
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN int grt_device_to_host(Device_t device, void *dst_host, void const *src_dev, size_t bytes)
+{
+    void *s = grt_dev_stream(device);
+    GRT_TRY(grt_dev_download(device, dst_host, src_dev, bytes, s));
+    GRT_TRY(grt_dev_sync(device, s));
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN int grt_host_to_device(Device_t device, void *dst_dev, void const *src_host, size_t bytes)
+{
+    void *s = grt_dev_stream(device);
+    GRT_TRY(grt_dev_upload(device, dst_dev, src_host, bytes, s));
+    GRT_TRY(grt_dev_sync(device, s));
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN size_t grt_sizeof(int kind)
+{
+    switch (kind)
+    {
+        case GRT_SPECTRAL_GRID: return sizeof(SpectralGrid_t);
+        case GRT_OPTICS: return sizeof(Optics_t);
+        case GRT_GAS_OPTICS: return sizeof(GasOptics_t);
+        case GRT_SOLAR_FLUX: return sizeof(SolarFlux_t);
+        case GRT_LONGWAVE: return sizeof(Longwave_t);
+        case GRT_SHORTWAVE: return sizeof(Shortwave_t);
+        default: return 0;
+    }
+}

@@ -1,0 +1,1094 @@
+/* grt_gas_optics.c -- GasOptics_t: line lists, spectral tables, per-column prologue and
+ * the launch of the line-by-line kernel.
+ *
+ * Contract: gas-optics/src/gas_optics.h:99-180 (gas_optics.c:51-464), the column
+ * sequencing of launch.c:40-226, the HITRAN reader parse_HITRAN_file.c:224-413 and the
+ * table loaders water_vapor_continuum.c:32-122, ozone_continuum.c:31-88, cfcs.c:30-158,
+ * collision_induced_absorption.c:29-108.
+ *
+ * Layout decisions (ours):
+ *   - every molecule's lines are parsed ONCE into host staging and merged into one
+ *     centre-sorted structure-of-arrays in HBM (v0,S as f64; the five parameters the
+ *     reference itself reads through a float as f32; iso and molecule slot as u8):
+ *     37 B/line instead of the reference's 60 B, and no (layer,line) scratch arrays;
+ *   - per column, the 60-layer prologue (layer means, partial pressures, 1/Q, Doppler
+ *     factors, continuum multipliers) is evaluated on the host in the reference's exact
+ *     arithmetic and shipped as one small block (a few kB) per column;
+ *   - one kernel launch per band and column batch produces tau (lines + continua).
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "grt_internal.h"
+#include "grt_molecule_table.h"
+
+static double const MIN_CUTOFF = 1.;      /* gas_optics.c:44-47 */
+static double const MAX_CUTOFF = 50.;
+static double const DEFAULT_CUTOFF = 25.;
+
+static char const *const cfc_names[NUM_CFCS] = {   /* cfcs.c:44-106 */
+    "CFC-11", "CFC-12", "CFC-113", "CFC-114", "CFC-115", "HCFC-22", "HCFC-141b", "HCFC-142b",
+    "HFC-23", "HFC-125", "HFC-134a", "HFC-143a", "HFC-152a", "HFC-227ea", "HFC-245fa", "CCl4",
+    "C2F6", "CF4", "CH2Cl2", "NF3", "SF6"};
+
+static GrtGasOpticsImpl *impl_of(GasOptics_t const *go)
+{
+    return (GrtGasOpticsImpl *)go->impl;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Loaders                                                                               */
+/* ------------------------------------------------------------------------------------ */
+void grt_free_host_lines(GrtHostLines *l)
+{
+    free(l->v0); free(l->s0); free(l->yair); free(l->yself); free(l->en); free(l->nexp);
+    free(l->delta); free(l->iso);
+    memset(l, 0, sizeof(*l));
+}
+
+static int host_lines_reserve(GrtHostLines *l, uint64_t cap)
+{
+    l->v0 = realloc(l->v0, sizeof(double)*cap);
+    l->s0 = realloc(l->s0, sizeof(double)*cap);
+    l->yair = realloc(l->yair, sizeof(float)*cap);
+    l->yself = realloc(l->yself, sizeof(float)*cap);
+    l->en = realloc(l->en, sizeof(float)*cap);
+    l->nexp = realloc(l->nexp, sizeof(float)*cap);
+    l->delta = realloc(l->delta, sizeof(float)*cap);
+    l->iso = realloc(l->iso, sizeof(uint8_t)*cap);
+    if (!l->v0 || !l->s0 || !l->yair || !l->yself || !l->en || !l->nexp || !l->delta || !l->iso)
+    {
+        GRT_FAIL(GRTCODE_NULL_ERR, "out of host memory reserving %llu lines.", (unsigned long long)cap);
+    }
+    return GRTCODE_SUCCESS;
+}
+
+/* parse_HITRAN_file.c:372-384: S <- S * Q(296)/(e^{c2 E/296} (1 - e^{c2 nu/296})) */
+static void rescale_strengths(int mol_id, GrtHostLines *l)
+{
+    fp_t const tref = 296.f;
+    fp_t const c2 = -1.4387686f;
+    for (uint64_t i = 0; i < l->n; ++i)
+    {
+        fp_t const en = l->en[i];
+        l->s0[i] *= Q(mol_id, tref, l->iso[i])/(exp(c2*en/tref)*(1.f - exp(c2*l->v0[i]/tref)));
+    }
+}
+
+static int fixed_field(char const *rec, int off, int len, char *buf)
+{
+    memcpy(buf, rec + off, (size_t)len);
+    buf[len] = '\0';
+    return off + len;
+}
+
+/* HITRAN-2012 160-character records (parse_HITRAN_file.c:77-100): mol(2) iso(1) nu(12)
+   S(10) A(10) g_air(5) g_self(5) E"(10) n(4) delta(8) + 93 unused.  A record is kept
+   when the molecule matches and w0 <= nu <= wn (:340).  Isotopologue codes: '0' -> 10,
+   'A'.. -> 11.. (:177-194). */
+int grt_parse_hitran(char const *path, int mol_id, double w0, double wn, GrtHostLines *out)
+{
+    GRT_REQUIRE_PTR(path);
+    GRT_REQUIRE_PTR(out);
+    memset(out, 0, sizeof(*out));
+    FILE *fp = NULL;
+    GRT_TRY(open_file(&fp, path, "r"));
+    GRT_INFO("Reading HITRAN line parameters for molecule %d from %s.", mol_id, path);
+    uint64_t cap = 0;
+    char *line = NULL;
+    size_t linecap = 0;
+    ssize_t len;
+    size_t lineno = 0;
+    int rc = GRTCODE_SUCCESS;
+    while ((len = getline(&line, &linecap, fp)) != -1)
+    {
+        ++lineno;
+        if (len > 162 || len < 160)
+        {
+            grt_err_begin(GRTCODE_VALUE_ERR, __FILE__, __LINE__, "Found bad record at line %zu"
+                          " (%zd characters, expected 160-162) in file %s.", lineno, len, path);
+            rc = GRTCODE_VALUE_ERR;
+            break;
+        }
+        char buf[16];
+        int off = fixed_field(line, 0, 2, buf);
+        int mol = 0;
+        if ((rc = to_int(buf, &mol)) != GRTCODE_SUCCESS) break;
+        if (mol != mol_id)
+        {
+            continue;
+        }
+        if (out->n == cap)
+        {
+            cap = cap ? 2*cap : 65536;
+            if ((rc = host_lines_reserve(out, cap)) != GRTCODE_SUCCESS) break;
+        }
+        uint64_t const k = out->n;
+        off = fixed_field(line, off, 1, buf);
+        int iso = 0;
+        if (buf[0] == '0') iso = 10;
+        else if (buf[0] >= 'A' && buf[0] <= 'Z') iso = buf[0] - 'A' + 11;
+        else if ((rc = to_int(buf, &iso)) != GRTCODE_SUCCESS) break;
+        if (iso < 1 || iso > GRT_MAX_ISO)
+        {
+            grt_err_begin(GRTCODE_VALUE_ERR, __FILE__, __LINE__, "isotopologue %d on line %zu of %s"
+                          " is outside 1-%d.", iso, lineno, path, GRT_MAX_ISO);
+            rc = GRTCODE_VALUE_ERR;
+            break;
+        }
+        out->iso[k] = (uint8_t)iso;
+        double d;
+        off = fixed_field(line, off, 12, buf);
+        if ((rc = to_double(buf, &d)) != GRTCODE_SUCCESS) break;
+        out->v0[k] = d;
+        off = fixed_field(line, off, 10, buf);
+        if ((rc = to_double(buf, &d)) != GRTCODE_SUCCESS) break;
+        out->s0[k] = d;
+        off += 10;                                     /* Einstein A: unused */
+        float *f32dst[5] = {&out->yair[k], &out->yself[k], &out->en[k], &out->nexp[k], &out->delta[k]};
+        int const width[5] = {5, 5, 10, 4, 8};
+        for (int c = 0; c < 5 && rc == GRTCODE_SUCCESS; ++c)
+        {
+            off = fixed_field(line, off, width[c], buf);
+            if ((rc = to_double(buf, &d)) == GRTCODE_SUCCESS)
+            {
+                *f32dst[c] = (float)d;                 /* parse_HITRAN_file.c:197-212 */
+            }
+        }
+        if (rc != GRTCODE_SUCCESS) break;
+        if ((w0 < 0 && wn < 0) || (out->v0[k] >= w0 && out->v0[k] <= wn))
+        {
+            out->n++;
+        }
+    }
+    free(line);
+    if (fclose(fp) != 0 && rc == GRTCODE_SUCCESS)
+    {
+        grt_err_begin(GRTCODE_IO_ERR, __FILE__, __LINE__, "error closing file %s.", path);
+        rc = GRTCODE_IO_ERR;
+    }
+    if (rc != GRTCODE_SUCCESS)
+    {
+        grt_free_host_lines(out);
+        grt_err_frame(__FILE__, __LINE__);
+        return rc;
+    }
+    rescale_strengths(mol_id, out);
+    return GRTCODE_SUCCESS;
+}
+
+/* Two-column (or 1+k column) CSV -> values on the spectral grid: column 0 = wavenumber,
+   column 1 = value, linear interpolation, zero outside the tabulated range
+   (ozone_continuum.c:45-75 and the identical blocks in the other three loaders). */
+int grt_load_table_on_grid(char const *path, int expect_cols, SpectralGrid_t const *grid, fp_t *out)
+{
+    int rows = 0, cols = 0;
+    char **tok = NULL;
+    GRT_TRY(parse_csv(path, &rows, &cols, 1, &tok));
+    int rc = GRTCODE_SUCCESS;
+    fp_t *vals = malloc(sizeof(fp_t)*(size_t)rows*(size_t)cols);
+    for (int i = 0; i < rows*cols; ++i)
+    {
+        double d = 0.;
+        if (rc == GRTCODE_SUCCESS)
+        {
+            rc = to_double(tok[i], &d);
+        }
+        vals[i] = d;
+        free(tok[i]);
+    }
+    free(tok);
+    if (rc == GRTCODE_SUCCESS && cols != expect_cols)
+    {
+        grt_err_begin(GRTCODE_VALUE_ERR, __FILE__, __LINE__, "The number of columns (%d) in file %s"
+                      " does not match the expected number (%d).", cols, path, expect_cols);
+        rc = GRTCODE_VALUE_ERR;
+    }
+    if (rc == GRTCODE_SUCCESS)
+    {
+        memset(out, 0, sizeof(fp_t)*grid->n);
+        rc = interpolate_to_grid(*grid, &vals[0], &vals[rows], (size_t)rows, out, linear_sample, NULL);
+    }
+    free(vals);
+    GRT_TRY(rc);
+    return GRTCODE_SUCCESS;
+}
+
+static int upload_table(GasOptics_t *go, fp_t const *host, double *dev_row)
+{
+    void *s = grt_dev_stream(go->device);
+    GRT_TRY(grt_dev_upload(go->device, dev_row, host, sizeof(fp_t)*go->grid.n, s));
+    GRT_TRY(grt_dev_sync(go->device, s));
+    return GRTCODE_SUCCESS;
+}
+
+static int add_linear_table(GasOptics_t *go, char const *path, int kind, int ref, double **row_out)
+{
+    GrtGasOpticsImpl *im = impl_of(go);
+    if (im->num_lin >= GRT_MAX_TABLES)
+    {
+        GRT_FAIL(GRTCODE_RANGE_ERR, "too many cross-section tables (%d).", GRT_MAX_TABLES);
+    }
+    fp_t *host = malloc(sizeof(fp_t)*go->grid.n);
+    int rc = grt_load_table_on_grid(path, 2, &go->grid, host);
+    double *row = im->lin_tables + (size_t)im->num_lin*go->grid.n;
+    if (rc == GRTCODE_SUCCESS)
+    {
+        rc = upload_table(go, host, row);
+    }
+    free(host);
+    GRT_TRY(rc);
+    im->lin_kind[im->num_lin] = kind;
+    im->lin_ref[im->num_lin] = ref;
+    im->num_lin++;
+    if (row_out != NULL)
+    {
+        *row_out = row;
+    }
+    return GRTCODE_SUCCESS;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Object lifecycle                                                                      */
+/* ------------------------------------------------------------------------------------ */
+EXTERN int create_gas_optics(GasOptics_t * const gas_optics, int const num_levels,
+                             SpectralGrid_t const * const grid, Device_t const * const device,
+                             char const * const hitran_path, char const * const h2o_ctm_dir,
+                             char const * const o3_ctm_file, double const * const wcutoff,
+                             int const * const optical_depth_method)
+{
+    GRT_REQUIRE_PTR(gas_optics);
+    GRT_REQUIRE_RANGE(num_levels, MIN_NUM_LEVELS, MAX_NUM_LEVELS);
+    GRT_REQUIRE_PTR(grid);
+    GRT_REQUIRE_PTR(device);
+    GRT_REQUIRE_PTR(hitran_path);
+    memset(gas_optics, 0, sizeof(*gas_optics));
+    GRT_TRY(grt_dev_require(*device));
+    GasOptics_t *go = gas_optics;
+    go->num_levels = num_levels;
+    go->num_layers = num_levels - 1;
+    go->grid = *grid;
+    go->device = *device;
+
+    /* spectral_bin.c:37-58: scalar fields only.  w0/wres/num_wpoints drive the window
+       arithmetic of the line kernel; the bin arrays belong to the sweep methods. */
+    double const bin_width = 1.;
+    go->bins.num_layers = go->num_layers;
+    go->bins.w0 = grid->w0;
+    go->bins.wres = grid->dw;
+    go->bins.num_wpoints = grid->n;
+    go->bins.width = bin_width;
+    go->bins.ppb = (int)(floor(bin_width/grid->dw) + 1);
+    go->bins.do_interp = go->bins.ppb > 3 ? 1 : 0;
+    go->bins.last_ppb = (int)(grid->n % (uint64_t)go->bins.ppb);
+    go->bins.last_ppb = go->bins.last_ppb == 0 ? go->bins.ppb : go->bins.last_ppb;
+    go->bins.do_last_interp = go->bins.last_ppb > 3 ? 1 : 0;
+    go->bins.n = grid->n/(uint64_t)go->bins.ppb + (go->bins.ppb != go->bins.last_ppb ? 1 : 0);
+    go->bins.isize = 3*go->bins.n;
+    go->bins.device = *device;
+
+    snprintf(go->hitran_path, DIR_PATH_LEN, "%s", hitran_path);
+    if (wcutoff != NULL)
+    {
+        GRT_REQUIRE_RANGE(*wcutoff, MIN_CUTOFF, MAX_CUTOFF);
+        go->wcutoff = *wcutoff;     /* stored, never used: the window is 25 cm-1 (kernels.c:417) */
+    }
+    else
+    {
+        go->wcutoff = DEFAULT_CUTOFF;
+    }
+    if (optical_depth_method != NULL)
+    {
+        GRT_REQUIRE_RANGE(*optical_depth_method, wavenumber_sweep, line_sample);
+        go->optical_depth_method = *optical_depth_method;
+    }
+    else
+    {
+        go->optical_depth_method = wavenumber_sweep;   /* gas_optics.c:110-113 */
+    }
+    if (go->optical_depth_method != line_sample)
+    {
+        GRT_FAIL(GRTCODE_COMPILER_ERR, "optical_depth_method %d: only line_sample (the method the"
+                 " drivers use, driver.c:618-624) is built in this library.", go->optical_depth_method);
+    }
+    if (h2o_ctm_dir != NULL && strcmp(h2o_ctm_dir, "none") != 0)
+    {
+        go->use_h2o_ctm = 1;
+        GRT_TRY(copy_str(go->h2o_ctm_dir, h2o_ctm_dir, DIR_PATH_LEN));
+    }
+    if (o3_ctm_file != NULL && strcmp(o3_ctm_file, "none") != 0)
+    {
+        go->use_o3_ctm = 1;
+        GRT_TRY(copy_str(go->o3_ctm_file, o3_ctm_file, DIR_PATH_LEN));
+    }
+
+    GrtGasOpticsImpl *im = calloc(1, sizeof(*im));
+    if (im == NULL)
+    {
+        GRT_FAIL(GRTCODE_NULL_ERR, "out of host memory for the gas-optics state.%s", "");
+    }
+    go->impl = im;
+    size_t const V = (size_t)num_levels;
+    go->x = calloc(NUM_MOLS*V, sizeof(fp_t));
+    go->x_cfc = calloc(NUM_CFCS*V, sizeof(fp_t));
+    go->x_cia = calloc(NUM_CIAS*V, sizeof(fp_t));
+    GRT_TRY(grt_dev_alloc(go->device, (void **)&im->lin_tables, sizeof(double)*GRT_MAX_TABLES*grid->n));
+    im->store_dirty = 1;
+    GRT_TRY(inittips_d());
+    GRT_INFO("Gas optics on device %d: %d levels, %zu grid points.", go->device, num_levels, (size_t)grid->n);
+    return GRTCODE_SUCCESS;
+}
+
+static int free_store(GasOptics_t *go)
+{
+    GrtGasOpticsImpl *im = impl_of(go);
+    GRT_TRY(grt_dev_free(go->device, im->store_block));
+    im->store_block = NULL;
+    memset(&im->store, 0, sizeof(im->store));
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN int destroy_gas_optics(GasOptics_t * const gas_optics)
+{
+    GRT_REQUIRE_PTR(gas_optics);
+    GrtGasOpticsImpl *im = impl_of(gas_optics);
+    if (im != NULL)
+    {
+        for (int i = 0; i < NUM_MOLS; ++i)
+        {
+            grt_free_host_lines(&im->host[i]);
+        }
+        GRT_TRY(free_store(gas_optics));
+        GRT_TRY(grt_dev_free(gas_optics->device, im->h2o_tables));
+        GRT_TRY(grt_dev_free(gas_optics->device, im->lin_tables));
+        GRT_TRY(grt_dev_free(gas_optics->device, im->colstate_d));
+        GRT_TRY(grt_host_free_pinned(im->colstate_h));
+        free(im);
+    }
+    free(gas_optics->h2o_cc.coefs);
+    free(gas_optics->x);
+    free(gas_optics->x_cfc);
+    free(gas_optics->x_cia);
+    gas_optics->impl = NULL;
+    gas_optics->x = gas_optics->x_cfc = gas_optics->x_cia = NULL;
+    gas_optics->h2o_cc.coefs = NULL;
+    return GRTCODE_SUCCESS;
+}
+
+/* Shared tail of add_molecule / grt_add_molecule_lines: bookkeeping + continua. */
+static int register_molecule(GasOptics_t *go, int molecule_id, GrtHostLines *lines, double w0, double wn)
+{
+    GrtGasOpticsImpl *im = impl_of(go);
+    int const index = go->num_molecules;
+    Molecule_t *mol = &go->mols[index];
+    memset(mol, 0, sizeof(*mol));
+    mol->id = molecule_id;
+    mol->device = go->device;
+    snprintf(mol->name, MOL_NAME_LEN, "%s", grt_molecule_table[molecule_id - 1].name);
+    mol->mass = grt_molecule_table[molecule_id - 1].molar_mass;    /* float literal -> fp_t */
+    mol->mass /= 6.023e23;                                         /* molecules.c:307 */
+    mol->num_isotopologues = grt_molecule_table[molecule_id - 1].num_iso;
+    mol->line_params.num_lines = lines->n;
+    mol->line_params.device = go->device;
+    im->host[index] = *lines;
+    memset(lines, 0, sizeof(*lines));
+    go->num_molecules++;
+    GRT_TRY(activate(&go->molecule_bit_field, molecule_id - 1));
+    im->store_dirty = 1;
+    GRT_MESG("Using %s (%zu lines in range %e - %e [1/cm]).", mol->name,
+             (size_t)mol->line_params.num_lines, w0, wn);
+
+    if (molecule_id == H2O && go->use_h2o_ctm)
+    {
+        /* water_vapor_continuum.c:49-64 file names, :57-64 column counts */
+        static char const *const names[4] = {"296MTCKD25_F.csv", "296MTCKD25_S.csv", "CKDF.csv", "CKDS.csv"};
+        static int const cols[4] = {2, 2, 4, 4};
+        GRT_MESG("Using the %s continuum.", mol->name);
+        GRT_TRY(grt_dev_alloc(go->device, (void **)&im->h2o_tables, sizeof(double)*4*go->grid.n));
+        fp_t *host = malloc(sizeof(fp_t)*go->grid.n);
+        char path[DIR_PATH_LEN + 64];
+        int rc = GRTCODE_SUCCESS;
+        go->h2o_cc.coefs = calloc(4, sizeof(fp_t *));
+        for (int k = 0; k < 4 && rc == GRTCODE_SUCCESS; ++k)
+        {
+            snprintf(path, sizeof(path), "%s/%s", go->h2o_ctm_dir, names[k]);
+            rc = grt_load_table_on_grid(path, cols[k], &go->grid, host);
+            if (rc == GRTCODE_SUCCESS)
+            {
+                rc = upload_table(go, host, im->h2o_tables + (size_t)k*go->grid.n);
+                go->h2o_cc.coefs[k] = im->h2o_tables + (size_t)k*go->grid.n;
+            }
+        }
+        free(host);
+        GRT_TRY(rc);
+        go->h2o_cc.num_wpoints = go->grid.n;
+        go->h2o_cc.device = go->device;
+    }
+    if (molecule_id == O3 && go->use_o3_ctm)
+    {
+        GRT_MESG("Using the %s continuum.", mol->name);
+        GRT_TRY(add_linear_table(go, go->o3_ctm_file, 0, index, &go->o3_cc.cross_section));
+        go->o3_cc.num_wpoints = go->grid.n;
+        go->o3_cc.device = go->device;
+    }
+    return GRTCODE_SUCCESS;
+}
+
+static int molecule_slot_checks(GasOptics_t *go, int molecule_id, double const *min_line_center,
+                                double const *max_line_center, double *w0, double *wn)
+{
+    if (molecule_id < H2O || molecule_id > NUM_MOLS)
+    {
+        GRT_FAIL(GRTCODE_VALUE_ERR, "unrecognized molecule id %d.", molecule_id);
+    }
+    if (is_active(go->molecule_bit_field, molecule_id - 1))
+    {
+        GRT_FAIL(GRTCODE_VALUE_ERR, "molecule %d has already been added.", molecule_id);
+    }
+    GRT_REQUIRE_RANGE(go->num_molecules + 1, 1, NUM_MOLS);
+    *w0 = go->grid.w0;
+    *wn = go->grid.wn;
+    if (min_line_center != NULL)
+    {
+        GRT_REQUIRE_RANGE(*min_line_center, MIN_WAVENUMBER, MAX_WAVENUMBER);
+        *w0 = *min_line_center;
+    }
+    if (max_line_center != NULL)
+    {
+        GRT_REQUIRE_RANGE(*max_line_center, MIN_WAVENUMBER, MAX_WAVENUMBER);
+        *wn = *max_line_center;
+    }
+    if (*wn < *w0)
+    {
+        GRT_FAIL(GRTCODE_RANGE_ERR, "value (%e) less than minimum allowed (%e).", *wn, *w0);
+    }
+    return GRTCODE_SUCCESS;
+}
+
+/* gas_optics.c:228-290 */
+EXTERN int add_molecule(GasOptics_t * const gas_optics, int const molecule_id,
+                        double const * const min_line_center,
+                        double const * const max_line_center)
+{
+    GRT_REQUIRE_PTR(gas_optics);
+    GRT_REQUIRE_PTR(gas_optics->impl);
+    double w0, wn;
+    GRT_TRY(molecule_slot_checks(gas_optics, molecule_id, min_line_center, max_line_center, &w0, &wn));
+    GrtHostLines lines;
+    GRT_TRY(grt_parse_hitran(gas_optics->hitran_path, molecule_id, w0, wn, &lines));
+    int const rc = register_molecule(gas_optics, molecule_id, &lines, w0, wn);
+    grt_free_host_lines(&lines);
+    GRT_TRY(rc);
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN int grt_add_molecule_lines(GasOptics_t *gas_optics, int molecule_id, uint64_t num_lines,
+                                  int const *iso, double const *v0, double const *s_raw,
+                                  double const *yair, double const *yself, double const *en,
+                                  double const *nexp, double const *delta)
+{
+    GRT_REQUIRE_PTR(gas_optics);
+    GRT_REQUIRE_PTR(gas_optics->impl);
+    double w0, wn;
+    GRT_TRY(molecule_slot_checks(gas_optics, molecule_id, NULL, NULL, &w0, &wn));
+    GrtHostLines lines;
+    memset(&lines, 0, sizeof(lines));
+    if (num_lines > 0)
+    {
+        GRT_REQUIRE_PTR(iso); GRT_REQUIRE_PTR(v0); GRT_REQUIRE_PTR(s_raw); GRT_REQUIRE_PTR(yair);
+        GRT_REQUIRE_PTR(yself); GRT_REQUIRE_PTR(en); GRT_REQUIRE_PTR(nexp); GRT_REQUIRE_PTR(delta);
+        GRT_TRY(host_lines_reserve(&lines, num_lines));
+    }
+    for (uint64_t j = 0; j < num_lines; ++j)
+    {
+        if (!(v0[j] >= w0 && v0[j] <= wn))
+        {
+            continue;
+        }
+        if (iso[j] < 1 || iso[j] > GRT_MAX_ISO)
+        {
+            grt_free_host_lines(&lines);
+            GRT_FAIL(GRTCODE_VALUE_ERR, "isotopologue %d of line %llu is outside 1-%d.", iso[j],
+                     (unsigned long long)j, GRT_MAX_ISO);
+        }
+        uint64_t const k = lines.n++;
+        lines.iso[k] = (uint8_t)iso[j];
+        lines.v0[k] = v0[j];
+        lines.s0[k] = s_raw[j];
+        lines.yair[k] = (float)yair[j];
+        lines.yself[k] = (float)yself[j];
+        lines.en[k] = (float)en[j];
+        lines.nexp[k] = (float)nexp[j];
+        lines.delta[k] = (float)delta[j];
+    }
+    rescale_strengths(molecule_id, &lines);
+    int const rc = register_molecule(gas_optics, molecule_id, &lines, w0, wn);
+    grt_free_host_lines(&lines);
+    GRT_TRY(rc);
+    return GRTCODE_SUCCESS;
+}
+
+/* gas_optics.c:294-317, 346-368, 408-429: ppmv -> mole fraction, host mirror.  A species
+   that was never added is reported with a warning and SUCCESS, as in the reference. */
+static int store_ppmv(fp_t *dst, fp_t const *ppmv, int num_levels)
+{
+    for (int i = 0; i < num_levels; ++i)
+    {
+        dst[i] = ppmv[i]*1.e-6;
+    }
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN int set_molecule_ppmv(GasOptics_t * const gas_optics, int const molecule_id,
+                             fp_t const * const ppmv)
+{
+    GRT_REQUIRE_PTR(gas_optics);
+    GRT_REQUIRE_PTR(ppmv);
+    if (molecule_id < H2O || molecule_id > NUM_MOLS)
+    {
+        GRT_FAIL(GRTCODE_VALUE_ERR, "unrecognized molecule id %d.", molecule_id);
+    }
+    if (!is_active(gas_optics->molecule_bit_field, molecule_id - 1))
+    {
+        GRT_WARN("molecule %d is not being used.", molecule_id);
+        return GRTCODE_SUCCESS;
+    }
+    return store_ppmv(gas_optics->x + (size_t)(molecule_id - 1)*gas_optics->num_levels, ppmv,
+                      gas_optics->num_levels);
+}
+
+/* gas_optics.c:321-342 */
+EXTERN int add_cfc(GasOptics_t * const gas_optics, int const cfc_id, char const * const filepath)
+{
+    GRT_REQUIRE_PTR(gas_optics);
+    GRT_REQUIRE_PTR(gas_optics->impl);
+    GRT_REQUIRE_PTR(filepath);
+    GRT_REQUIRE_RANGE(cfc_id, 0, NUM_CFCS - 1);
+    if (is_active(gas_optics->cfc_bit_field, cfc_id))
+    {
+        GRT_FAIL(GRTCODE_VALUE_ERR, "cfc %d has already been added.", cfc_id);
+    }
+    int const index = gas_optics->num_cfcs;
+    GRT_REQUIRE_RANGE(index + 1, 1, NUM_CFCS);
+    CfcCrossSection_t *c = &gas_optics->cfcs[index];
+    memset(c, 0, sizeof(*c));
+    GRT_TRY(add_linear_table(gas_optics, filepath, 1, index, &c->cross_section));
+    c->id = cfc_id;
+    snprintf(c->name, CFC_NAME_LEN, "%s", cfc_names[cfc_id]);
+    c->num_wpoints = gas_optics->grid.n;
+    c->device = gas_optics->device;
+    gas_optics->num_cfcs++;
+    GRT_TRY(activate(&gas_optics->cfc_bit_field, cfc_id));
+    GRT_MESG("Using CFC %s.", c->name);
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN int set_cfc_ppmv(GasOptics_t * const gas_optics, int const cfc_id, fp_t const * const ppmv)
+{
+    GRT_REQUIRE_PTR(gas_optics);
+    GRT_REQUIRE_PTR(ppmv);
+    GRT_REQUIRE_RANGE(cfc_id, 0, NUM_CFCS - 1);
+    if (!is_active(gas_optics->cfc_bit_field, cfc_id))
+    {
+        GRT_WARN("CFC %d is not being used.", cfc_id);
+        return GRTCODE_SUCCESS;
+    }
+    return store_ppmv(gas_optics->x_cfc + (size_t)cfc_id*gas_optics->num_levels, ppmv,
+                      gas_optics->num_levels);
+}
+
+/* gas_optics.c:372-404 */
+EXTERN int add_cia(GasOptics_t * const gas_optics, int const species1, int const species2,
+                   char const * const filepath)
+{
+    GRT_REQUIRE_PTR(gas_optics);
+    GRT_REQUIRE_PTR(gas_optics->impl);
+    GRT_REQUIRE_PTR(filepath);
+    GRT_REQUIRE_RANGE(species1, 0, NUM_CIAS - 1);
+    GRT_REQUIRE_RANGE(species2, 0, NUM_CIAS - 1);
+    for (int i = 0; i < gas_optics->num_cias; ++i)
+    {
+        CollisionInducedAbsorption_t const *m = &gas_optics->cia[i];
+        if (m->id[0] + m->id[1] == species1 + species2)   /* the reference's pair test (:384) */
+        {
+            GRT_FAIL(GRTCODE_VALUE_ERR, "CIA with %s and %s is already active.", m->name[0], m->name[1]);
+        }
+    }
+    int const index = gas_optics->num_cias;
+    GRT_REQUIRE_RANGE(index + 1, 1, MAX_NUM_CIAS);
+    CollisionInducedAbsorption_t *c = &gas_optics->cia[index];
+    memset(c, 0, sizeof(*c));
+    GRT_TRY(add_linear_table(gas_optics, filepath, 2, index, &c->cross_section));
+    int const ids[2] = {species1, species2};
+    for (int k = 0; k < 2; ++k)
+    {
+        c->id[k] = ids[k];
+        snprintf(&c->name_buf[k*CIA_NAME_LEN], CIA_NAME_LEN, "%s", ids[k] == CIA_N2 ? "N2" : "O2");
+        c->name[k] = &c->name_buf[k*CIA_NAME_LEN];
+        GRT_TRY(activate(&gas_optics->cia_bit_field, ids[k]));
+    }
+    c->num_wpoints = gas_optics->grid.n;
+    c->device = gas_optics->device;
+    gas_optics->num_cias++;
+    GRT_INFO("Using collision-induced absorption between %s and %s.", c->name[0], c->name[1]);
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN int set_cia_ppmv(GasOptics_t * const gas_optics, int const cia_id, fp_t const * const ppmv)
+{
+    GRT_REQUIRE_PTR(gas_optics);
+    GRT_REQUIRE_PTR(ppmv);
+    GRT_REQUIRE_RANGE(cia_id, 0, NUM_CIAS - 1);
+    if (!is_active(gas_optics->cia_bit_field, cia_id))
+    {
+        GRT_WARN("CIA %d is not being used.", cia_id);
+        return GRTCODE_SUCCESS;
+    }
+    return store_ppmv(gas_optics->x_cia + (size_t)cia_id*gas_optics->num_levels, ppmv,
+                      gas_optics->num_levels);
+}
+
+EXTERN int get_num_molecules(GasOptics_t const * const gas_optics, int * const n)
+{
+    GRT_REQUIRE_PTR(gas_optics);
+    GRT_REQUIRE_PTR(n);
+    *n = gas_optics->num_molecules;
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN int grt_gas_optics_tune(GasOptics_t *gas_optics, int tile, int nslice, int fast)
+{
+    GRT_REQUIRE_PTR(gas_optics);
+    GRT_REQUIRE_PTR(gas_optics->impl);
+    GrtGasOpticsImpl *im = impl_of(gas_optics);
+    if (tile != 0)
+    {
+        if (tile < 64 || tile > 8192 || (tile % 64) != 0)
+        {
+            GRT_FAIL(GRTCODE_RANGE_ERR, "tile %d must be a multiple of 64 in [64, 8192].", tile);
+        }
+        im->tile = tile;
+    }
+    if (nslice != 0)
+    {
+        GRT_REQUIRE_RANGE(nslice, 1, 64);
+        im->nslice = nslice;
+    }
+    im->fast = fast ? 1 : 0;
+    return GRTCODE_SUCCESS;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Merged line store                                                                     */
+/* ------------------------------------------------------------------------------------ */
+typedef struct SortKey { double v0; uint32_t idx; uint8_t slot; } SortKey;
+
+static int sort_key_cmp(void const *a, void const *b)
+{
+    SortKey const *x = a, *y = b;
+    if (x->v0 < y->v0) return -1;
+    if (x->v0 > y->v0) return 1;
+    if (x->slot != y->slot) return x->slot < y->slot ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+
+static size_t align256(size_t x)
+{
+    return (x + 255) & ~(size_t)255;
+}
+
+static int build_store(GasOptics_t *go)
+{
+    GrtGasOpticsImpl *im = impl_of(go);
+    GRT_TRY(free_store(go));
+    uint64_t total = 0;
+    for (int s = 0; s < go->num_molecules; ++s)
+    {
+        total += im->host[s].n;
+    }
+    im->store.n = total;
+    im->store.dmax = 0.;
+    if (total == 0)
+    {
+        im->store_dirty = 0;
+        return GRTCODE_SUCCESS;
+    }
+    SortKey *keys = malloc(sizeof(SortKey)*total);
+    uint64_t k = 0;
+    for (int s = 0; s < go->num_molecules; ++s)
+    {
+        for (uint64_t j = 0; j < im->host[s].n; ++j, ++k)
+        {
+            keys[k].v0 = im->host[s].v0[j];
+            keys[k].idx = (uint32_t)j;
+            keys[k].slot = (uint8_t)s;
+        }
+    }
+    qsort(keys, total, sizeof(SortKey), sort_key_cmp);
+    size_t off[10];
+    size_t bytes = 0;
+    size_t const sizes[9] = {8, 8, 4, 4, 4, 4, 4, 1, 1};
+    for (int a = 0; a < 9; ++a)
+    {
+        off[a] = bytes;
+        bytes = align256(bytes + sizes[a]*total);
+    }
+    off[9] = bytes;
+    unsigned char *host = malloc(bytes);
+    double *v0 = (double *)(host + off[0]), *s0 = (double *)(host + off[1]);
+    float *yair = (float *)(host + off[2]), *yself = (float *)(host + off[3]);
+    float *en = (float *)(host + off[4]), *nexp = (float *)(host + off[5]), *delta = (float *)(host + off[6]);
+    uint8_t *iso = host + off[7], *slot = host + off[8];
+    for (k = 0; k < total; ++k)
+    {
+        GrtHostLines const *h = &im->host[keys[k].slot];
+        uint32_t const j = keys[k].idx;
+        v0[k] = h->v0[j]; s0[k] = h->s0[j];
+        yair[k] = h->yair[j]; yself[k] = h->yself[j]; en[k] = h->en[j]; nexp[k] = h->nexp[j];
+        delta[k] = h->delta[j];
+        iso[k] = h->iso[j]; slot[k] = keys[k].slot;
+        double const ad = fabs((double)h->delta[j]);
+        if (ad > im->store.dmax) im->store.dmax = ad;
+    }
+    free(keys);
+    int rc = grt_dev_alloc(go->device, &im->store_block, bytes);
+    void *s = grt_dev_stream(go->device);
+    if (rc == GRTCODE_SUCCESS) rc = grt_dev_upload(go->device, im->store_block, host, bytes, s);
+    if (rc == GRTCODE_SUCCESS) rc = grt_dev_sync(go->device, s);
+    free(host);
+    GRT_TRY(rc);
+    unsigned char *d = im->store_block;
+    im->store.v0 = (double const *)(d + off[0]);
+    im->store.s0 = (double const *)(d + off[1]);
+    im->store.yair = (float const *)(d + off[2]);
+    im->store.yself = (float const *)(d + off[3]);
+    im->store.en = (float const *)(d + off[4]);
+    im->store.nexp = (float const *)(d + off[5]);
+    im->store.delta = (float const *)(d + off[6]);
+    im->store.iso = d + off[7];
+    im->store.slot = d + off[8];
+    /* expose the device arrays through the public struct of the FIRST molecule only as
+       documentation of where they live; per-molecule views do not exist in a merged store */
+    im->store_dirty = 0;
+    GRT_INFO("Line store: %zu lines, %zu bytes on device %d.", (size_t)total, bytes, go->device);
+    return GRTCODE_SUCCESS;
+}
+
+int grt_gas_optics_prepare(GasOptics_t *go, int ncol)
+{
+    GRT_REQUIRE_PTR(go);
+    GRT_REQUIRE_PTR(go->impl);
+    GrtGasOpticsImpl *im = impl_of(go);
+    if (im->store_dirty)
+    {
+        GRT_TRY(build_store(go));
+    }
+    int const L = go->num_layers;
+    int const S = go->num_molecules > 0 ? go->num_molecules : 1;
+    GrtColumnLayout *lay = &im->layout;
+    lay->num_layers = L;
+    lay->num_slots = go->num_molecules;
+    lay->num_tables = im->num_lin;
+    lay->has_h2o_ctm = im->h2o_tables != NULL;
+    lay->off_lay = 0;
+    lay->off_ms = lay->off_lay + (uint64_t)L*4;
+    lay->off_q = lay->off_ms + (uint64_t)S*L*4;
+    lay->off_cont = lay->off_q + (uint64_t)S*L*GRT_MAX_ISO;
+    lay->off_h2o = lay->off_cont + (uint64_t)L*GRT_MAX_TABLES;
+    uint64_t const stride = lay->off_h2o + (uint64_t)L*4;
+    if (stride != lay->stride || ncol > im->layout_cols)
+    {
+        GRT_TRY(grt_dev_free(go->device, im->colstate_d));
+        GRT_TRY(grt_host_free_pinned(im->colstate_h));
+        im->colstate_d = im->colstate_h = NULL;
+        lay->stride = stride;
+        im->layout_cols = ncol;
+        GRT_TRY(grt_dev_alloc(go->device, (void **)&im->colstate_d, sizeof(double)*stride*ncol));
+        GRT_TRY(grt_host_alloc_pinned((void **)&im->colstate_h, sizeof(double)*stride*ncol));
+    }
+    return GRTCODE_SUCCESS;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Per-column prologue (host, reference arithmetic)                                      */
+/* ------------------------------------------------------------------------------------ */
+int grt_column_state(GasOptics_t const *go, fp_t const *p_mb, fp_t const *t, fp_t const *x_mol,
+                     fp_t const *x_cfc, fp_t const *x_cia, double *dst)
+{
+    GrtGasOpticsImpl const *im = impl_of(go);
+    GrtColumnLayout const *lo = &im->layout;
+    int const V = go->num_levels, L = go->num_layers;
+    fp_t const mbtoatm = 0.000986923f;                 /* gas_optics.c:445 */
+    fp_t const tref = 296.f;
+    fp_t p[MAX_NUM_LEVELS], n[MAX_NUM_LAYERS], pavg[MAX_NUM_LAYERS], tavg[MAX_NUM_LAYERS];
+    for (int i = 0; i < V; ++i)
+    {
+        GRT_REQUIRE_RANGE(t[i], MIN_TEMPERATURE, MAX_TEMPERATURE);
+        if (!(p_mb[i] >= 0.))
+        {
+            GRT_FAIL(GRTCODE_RANGE_ERR, "pressure (%e) at level %d is negative or NaN.", p_mb[i], i);
+        }
+        p[i] = p_mb[i]*mbtoatm;
+    }
+    memset(dst, 0, sizeof(double)*lo->stride);
+    fp_t const c_air = 2.147822334314468e+25;          /* curtis_godson.c:27 */
+    for (int i = 0; i < L; ++i)
+    {
+        fp_t dp = p[i] - p[i + 1];                     /* curtis_godson.c:32-34 */
+        dp = dp >= 0.f ? dp : -1.f*dp;
+        n[i] = c_air*dp;
+        pavg[i] = 0.5f*(p[i] + p[i + 1]);              /* curtis_godson.c:67-68 */
+        tavg[i] = 0.5f*(t[i] + t[i + 1]);
+        double *lay = dst + lo->off_lay + (size_t)i*4;
+        lay[0] = pavg[i];
+        lay[1] = tavg[i];
+        lay[2] = 1./tavg[i];
+        lay[3] = log(tref/tavg[i]);
+    }
+    fp_t const third = 1.f/3.f, sixth = 1.f/6.f;      /* curtis_godson.c:96-97 */
+    fp_t const kb = 1.380658E-16, c = 2.99792458E10;   /* kernels.c:118-119 */
+    for (int s = 0; s < go->num_molecules; ++s)
+    {
+        Molecule_t const *mol = &go->mols[s];
+        fp_t const *x = x_mol + (size_t)(mol->id - 1)*V;
+        fp_t const m = mol->mass;
+        for (int i = 0; i < L; ++i)
+        {
+            fp_t const ps = third*(x[i]*p[i] + x[i + 1]*p[i + 1]) + sixth*(x[i]*p[i + 1] + x[i + 1]*p[i]);
+            fp_t const ns = n[i]*0.5f*(x[i] + x[i + 1]);          /* curtis_godson.c:101-102 */
+            double *ms = dst + lo->off_ms + ((size_t)s*L + i)*4;
+            ms[0] = ps;
+            ms[1] = pavg[i] - ps;                                  /* kernels.c:105 (p - ps) */
+            ms[2] = ns;
+            ms[3] = sqrt((2.f*kb*tavg[i])/(m*c*c));                /* kernels.c:127 */
+            double *q = dst + lo->off_q + ((size_t)s*L + i)*GRT_MAX_ISO;
+            for (int k = 0; k < mol->num_isotopologues && k < GRT_MAX_ISO; ++k)
+            {
+                q[k] = 1.f/Q(mol->id, tavg[i], k + 1);             /* kernels.c:62 */
+            }
+            if (mol->id == H2O && lo->has_h2o_ctm)
+            {
+                double *h = dst + lo->off_h2o + (size_t)i*4;       /* kernels.c:484-487 */
+                h[0] = ns*(tref/tavg[i]);
+                h[1] = ps;
+                h[2] = pavg[i] - ps;
+                h[3] = tref - tavg[i];
+            }
+        }
+    }
+    for (int k = 0; k < im->num_lin; ++k)
+    {
+        for (int i = 0; i < L; ++i)
+        {
+            double *cont = dst + lo->off_cont + (size_t)i*GRT_MAX_TABLES;
+            if (im->lin_kind[k] == 0)
+            {
+                /* ozone continuum: tau += N_s(O3)*xs (kernels.c:506) */
+                cont[k] = dst[lo->off_ms + ((size_t)im->lin_ref[k]*L + i)*4 + 2];
+            }
+            else if (im->lin_kind[k] == 1)
+            {
+                /* kernels.c:597: half*n*(x_i + x_{i+1}) */
+                fp_t const *x = x_cfc + (size_t)go->cfcs[im->lin_ref[k]].id*V;
+                fp_t const half = 0.5;
+                cont[k] = half*n[i]*(x[i] + x[i + 1]);
+            }
+            else
+            {
+                /* kernels.c:610-625 with LEVEL pressures [atm] and LAYER temperatures (launch.c:206-208) */
+                CollisionInducedAbsorption_t const *ci = &go->cia[im->lin_ref[k]];
+                fp_t const *x1 = x_cia + (size_t)ci->id[0]*V, *x2 = x_cia + (size_t)ci->id[1]*V;
+                fp_t const quarter = 0.25;
+                fp_t const mm = 28.97/6.02214076e23, g = 980., kk = 1.38064852e-16, atmtobarye = 1.013e6;
+                fp_t const cc = (atmtobarye*atmtobarye)/(kk*mm*g*2.);
+                fp_t v = cc*((p[i]*p[i] - p[i + 1]*p[i + 1])/tavg[i])*quarter*(x1[i] + x1[i + 1])*
+                         (x2[i] + x2[i + 1]);
+                v = (v >= 0) ? v : v*-1.f;
+                cont[k] = v;
+            }
+        }
+    }
+    return GRTCODE_SUCCESS;
+}
+
+static void auto_tune(GasOptics_t const *go, int ncol, int *tile, int *nslice)
+{
+    GrtGasOpticsImpl const *im = impl_of(go);
+    uint64_t const nw = go->grid.n;
+    int t = im->tile;
+    if (t == 0)
+    {
+        t = nw >= 1024 ? 1024 : (int)(((nw + 63)/64)*64);
+    }
+    int ns = im->nslice;
+    if (ns == 0)
+    {
+        /* enough workgroups to cover 256 CUs several times over */
+        uint64_t const blocks = ((nw + t - 1)/t)*(uint64_t)go->num_layers*(uint64_t)ncol;
+        ns = 1;
+        while (blocks*ns < 4096 && ns < 16)
+        {
+            ns *= 2;
+        }
+    }
+    *tile = t;
+    *nslice = ns;
+}
+
+int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_stride, GrtGasOpticsArgs *a)
+{
+    GrtGasOpticsImpl *im = impl_of(go);
+    memset(a, 0, sizeof(*a));
+    a->lines = im->store;
+    a->lay = im->layout;
+    a->colstate = im->colstate_d;
+    a->tables = im->lin_tables;
+    a->h2o_tables = im->h2o_tables;
+    a->w0 = go->bins.w0;
+    a->wres = go->bins.wres;
+    a->nw = go->bins.num_wpoints;
+    a->ncol = ncol;
+    a->tau = tau;
+    a->tau_col_stride = tau_col_stride;
+    auto_tune(go, ncol, &a->tile, &a->nslice);
+    a->fast = im->fast;
+    return GRTCODE_SUCCESS;
+}
+
+static int launch_columns(GasOptics_t *go, int ncol, double *tau_dev, uint64_t tau_col_stride)
+{
+    GrtGasOpticsImpl *im = impl_of(go);
+    void *s = grt_dev_stream(go->device);
+    GrtGasOpticsArgs args;
+    GRT_TRY(grt_fill_gas_args(go, ncol, tau_dev, tau_col_stride, &args));
+    GRT_TRY(grt_dev_upload(go->device, im->colstate_d, im->colstate_h,
+                           sizeof(double)*im->layout.stride*ncol, s));
+    if (args.nslice > 1)
+    {
+        /* slices accumulate with atomics (launch.c:61 zeroes tau in every case) */
+        GRT_TRY(grt_dev_zero(go->device, tau_dev, sizeof(double)*tau_col_stride*ncol, s));
+    }
+    GRT_TRY(grt_dev_check(grt_launch_gas_optics(s, &args), "gas optics kernel"));
+    return GRTCODE_SUCCESS;
+}
+
+/* gas_optics.c:433-454 + launch.c:40-226 for one column; optics->tau is device memory and
+   is written in place (omega and g stay as they were: zero after create_optics). */
+EXTERN int calculate_optical_depth(GasOptics_t * const gas_optics, fp_t * const pressure,
+                                   fp_t * const temperature, Optics_t * const optics)
+{
+    GRT_REQUIRE_PTR(gas_optics);
+    GRT_REQUIRE_PTR(gas_optics->impl);
+    GRT_REQUIRE_PTR(pressure);
+    GRT_REQUIRE_PTR(temperature);
+    GRT_REQUIRE_PTR(optics);
+    GRT_REQUIRE_EQ(gas_optics->device, optics->device);
+    GRT_REQUIRE_EQ(gas_optics->num_layers, optics->num_layers);
+    int same = 0;
+    GRT_TRY(compare_spectral_grids(&gas_optics->grid, &optics->grid, &same));
+    GRT_REQUIRE_EQ(same, 1);
+    GRT_TRY(grt_gas_optics_prepare(gas_optics, 1));
+    GrtGasOpticsImpl *im = impl_of(gas_optics);
+    GRT_TRY(grt_column_state(gas_optics, pressure, temperature, gas_optics->x, gas_optics->x_cfc,
+                             gas_optics->x_cia, im->colstate_h));
+    uint64_t const per_col = (uint64_t)gas_optics->num_layers*gas_optics->grid.n;
+    GRT_TRY(launch_columns(gas_optics, 1, optics->tau, per_col));
+    GRT_TRY(grt_dev_sync(gas_optics->device, grt_dev_stream(gas_optics->device)));
+    return GRTCODE_SUCCESS;
+}
+
+/* Gather the batch's abundances into the [species][level] host layout the prologue reads. */
+static int batch_column_states(GasOptics_t *go, GrtColumns_t const *cols)
+{
+    GrtGasOpticsImpl *im = impl_of(go);
+    int const V = go->num_levels;
+    GRT_REQUIRE_EQ(cols->num_levels, V);
+    if (go->num_molecules > 0)
+    {
+        GRT_REQUIRE_PTR(cols->molecule_ppmv);
+    }
+    for (int c = 0; c < cols->ncol; ++c)
+    {
+        for (int s = 0; s < go->num_molecules; ++s)
+        {
+            GRT_TRY(store_ppmv(go->x + (size_t)(go->mols[s].id - 1)*V,
+                               cols->molecule_ppmv + ((size_t)c*go->num_molecules + s)*V, V));
+        }
+        for (int k = 0; k < go->num_cfcs && cols->cfc_ppmv != NULL; ++k)
+        {
+            GRT_TRY(store_ppmv(go->x_cfc + (size_t)go->cfcs[k].id*V,
+                               cols->cfc_ppmv + ((size_t)c*go->num_cfcs + k)*V, V));
+        }
+        for (int k = 0; k < NUM_CIAS && cols->cia_ppmv != NULL; ++k)
+        {
+            GRT_TRY(store_ppmv(go->x_cia + (size_t)k*V, cols->cia_ppmv + ((size_t)c*NUM_CIAS + k)*V, V));
+        }
+        GRT_TRY(grt_column_state(go, cols->pressure + (size_t)c*V, cols->temperature + (size_t)c*V,
+                                 go->x, go->x_cfc, go->x_cia, im->colstate_h + (size_t)c*im->layout.stride));
+    }
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN int grt_optical_depth_batch(GasOptics_t *gas_optics, GrtColumns_t const *columns, fp_t *tau_dev)
+{
+    GRT_REQUIRE_PTR(gas_optics);
+    GRT_REQUIRE_PTR(gas_optics->impl);
+    GRT_REQUIRE_PTR(columns);
+    GRT_REQUIRE_PTR(tau_dev);
+    GRT_REQUIRE_PTR(columns->pressure);
+    GRT_REQUIRE_PTR(columns->temperature);
+    GRT_REQUIRE_RANGE(columns->ncol, 1, 65535);
+    GRT_TRY(grt_gas_optics_prepare(gas_optics, columns->ncol));
+    GRT_TRY(batch_column_states(gas_optics, columns));
+    uint64_t const per_col = (uint64_t)gas_optics->num_layers*gas_optics->grid.n;
+    GRT_TRY(launch_columns(gas_optics, columns->ncol, tau_dev, per_col));
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN int grt_debug_line_prep(GasOptics_t *gas_optics, fp_t *pressure, fp_t *temperature,
+                               uint64_t *num_lines, uint8_t *slot, double *v0, double *vnn,
+                               double *snn, double *gamma, double *alpha, int64_t *win_s,
+                               int64_t *win_e)
+{
+    GRT_REQUIRE_PTR(gas_optics);
+    GRT_REQUIRE_PTR(gas_optics->impl);
+    GRT_REQUIRE_PTR(num_lines);
+    GRT_TRY(grt_gas_optics_prepare(gas_optics, 1));
+    GrtGasOpticsImpl *im = impl_of(gas_optics);
+    uint64_t const N = im->store.n;
+    *num_lines = N;
+    if (vnn == NULL || N == 0)
+    {
+        return GRTCODE_SUCCESS;
+    }
+    GRT_REQUIRE_PTR(pressure);
+    GRT_REQUIRE_PTR(temperature);
+    Device_t const dev = gas_optics->device;
+    int const L = gas_optics->num_layers;
+    void *s = grt_dev_stream(dev);
+    GRT_TRY(grt_column_state(gas_optics, pressure, temperature, gas_optics->x, gas_optics->x_cfc,
+                             gas_optics->x_cia, im->colstate_h));
+    GRT_TRY(grt_dev_upload(dev, im->colstate_d, im->colstate_h, sizeof(double)*im->layout.stride, s));
+    size_t const cells = (size_t)L*N;
+    double *d = NULL;
+    GRT_TRY(grt_dev_alloc(dev, (void **)&d, sizeof(double)*cells*6));
+    GrtGasOpticsArgs args;
+    GRT_TRY(grt_fill_gas_args(gas_optics, 1, NULL, 0, &args));
+    int rc = grt_dev_check(grt_launch_line_prep(s, &args, 0, d, d + cells, d + 2*cells, d + 3*cells,
+                                                (int64_t *)(d + 4*cells), (int64_t *)(d + 5*cells)),
+                           "line prep kernel");
+    double *outs[4] = {vnn, snn, gamma, alpha};
+    for (int k = 0; k < 4 && rc == GRTCODE_SUCCESS; ++k)
+    {
+        if (outs[k] != NULL) rc = grt_dev_download(dev, outs[k], d + k*cells, sizeof(double)*cells, s);
+    }
+    if (rc == GRTCODE_SUCCESS && win_s != NULL) rc = grt_dev_download(dev, win_s, d + 4*cells, sizeof(double)*cells, s);
+    if (rc == GRTCODE_SUCCESS && win_e != NULL) rc = grt_dev_download(dev, win_e, d + 5*cells, sizeof(double)*cells, s);
+    if (rc == GRTCODE_SUCCESS && slot != NULL) rc = grt_dev_download(dev, slot, im->store.slot, N, s);
+    if (rc == GRTCODE_SUCCESS && v0 != NULL) rc = grt_dev_download(dev, v0, im->store.v0, sizeof(double)*N, s);
+    if (rc == GRTCODE_SUCCESS) rc = grt_dev_sync(dev, s);
+    grt_dev_free(dev, d);
+    GRT_TRY(rc);
+    return GRTCODE_SUCCESS;
+}

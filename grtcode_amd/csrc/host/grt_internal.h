@@ -1,0 +1,101 @@
+/* grt_internal.h -- private declarations of the C99 host layer. */
+#ifndef GRT_INTERNAL_H_
+#define GRT_INTERNAL_H_
+
+#include <stddef.h>
+#include <stdint.h>
+#include "grtcode_hip_api.h"
+#include "grt_ext.h"
+#include "../grt_kernels.h"
+
+/* ---- error convention (reference: utilities/src/debug.h:74-100, verbosity.c:28-38) ----
+ * Every entry point returns an int code; the text (message + one "file: line" entry per
+ * frame that propagated it) accumulates in a process-global 4 kB buffer read back by
+ * grtcode_errstr().  Not thread-safe, like the reference. */
+void grt_err_begin(int code, char const *file, int line, char const *fmt, ...);
+void grt_err_frame(char const *file, int line);
+void grt_log(int level, char const *file, int line, char const *fmt, ...);
+
+#define GRT_FAIL(code, ...) \
+    do { grt_err_begin((code), __FILE__, __LINE__, __VA_ARGS__); return (code); } while (0)
+
+#define GRT_TRY(expr) \
+    do { int rc_ = (expr); if (rc_ != GRTCODE_SUCCESS) { grt_err_frame(__FILE__, __LINE__); return rc_; } } while (0)
+
+#define GRT_REQUIRE_PTR(p) \
+    do { if ((p) == NULL) GRT_FAIL(GRTCODE_NULL_ERR, "null pointer for argument '%s'.", #p); } while (0)
+
+/* value checks mirror debug.h:117-165: NaN -> INVALID, outside [lo,hi] -> RANGE */
+#define GRT_REQUIRE_RANGE(v, lo, hi) \
+    do { double v_ = (double)(v), lo_ = (double)(lo), hi_ = (double)(hi); \
+         if (v_ != v_) GRT_FAIL(GRTCODE_INVALID_ERR, "input value (%e) is Nan.", v_); \
+         if (v_ < lo_) GRT_FAIL(GRTCODE_RANGE_ERR, "value (%e) less than minimum allowed (%e).", v_, lo_); \
+         if (v_ > hi_) GRT_FAIL(GRTCODE_RANGE_ERR, "value (%e) greater than maximum allowed (%e).", v_, hi_); \
+    } while (0)
+
+#define GRT_REQUIRE_EQ(a, b) \
+    do { if ((a) != (b)) GRT_FAIL(GRTCODE_VALUE_ERR, "values (%lld, %lld) are not equal.", \
+                                  (long long)(a), (long long)(b)); } while (0)
+
+#define GRT_INFO(...) grt_log(GRTCODE_INFO, __FILE__, __LINE__, __VA_ARGS__)
+#define GRT_WARN(...) grt_log(GRTCODE_WARN, __FILE__, __LINE__, __VA_ARGS__)
+#define GRT_MESG(...) grt_log(GRTCODE_NONE, __FILE__, __LINE__, __VA_ARGS__)
+
+/* ---- HIP runtime access from C99 (grt_device.c) ---- */
+int grt_dev_require(Device_t device);                   /* GPU ordinal check; HOST_ONLY refused */
+int grt_dev_alloc(Device_t device, void **p, size_t bytes);
+int grt_dev_free(Device_t device, void *p);
+int grt_dev_zero(Device_t device, void *p, size_t bytes, void *stream);
+int grt_dev_upload(Device_t device, void *dst, void const *src, size_t bytes, void *stream);
+int grt_dev_download(Device_t device, void *dst, void const *src, size_t bytes, void *stream);
+int grt_dev_copy(Device_t device, void *dst, void const *src, size_t bytes, void *stream);
+int grt_dev_sync(Device_t device, void *stream);
+int grt_dev_check(int hip_error, char const *what);     /* maps any HIP error to GRTCODE_GPU_ERR */
+void *grt_dev_stream(Device_t device);                  /* library stream of a device (created lazily) */
+int grt_host_alloc_pinned(void **p, size_t bytes);
+int grt_host_free_pinned(void *p);
+
+/* ---- gas-optics private state ---- */
+typedef struct GrtHostLines      /* one molecule's parsed lines (host staging, parse order) */
+{
+    uint64_t n;
+    double *v0, *s0;
+    float *yair, *yself, *en, *nexp, *delta;
+    uint8_t *iso;
+} GrtHostLines;
+
+typedef struct GrtGasOpticsImpl
+{
+    GrtHostLines host[NUM_MOLS];   /* by slot (order of add_molecule) */
+    int store_dirty;               /* merged device store must be (re)built */
+    GrtLineStore store;            /* device SoA, sorted by centre */
+    void *store_block;             /* single device allocation backing `store` */
+    /* spectral tables on device, each [n]: */
+    double *h2o_tables;            /* [4][n] F296,S296,CKDF,CKDS or NULL */
+    double *lin_tables;            /* [GRT_MAX_TABLES][n]; row k used when k < num_lin */
+    int num_lin;
+    int lin_kind[GRT_MAX_TABLES];  /* 0: O3 continuum, 1: CFC, 2: CIA */
+    int lin_ref[GRT_MAX_TABLES];   /* O3: slot; CFC: index into cfcs[]; CIA: index into cia[] */
+    /* column-state staging */
+    GrtColumnLayout layout;
+    int layout_cols;               /* capacity (columns) of the buffers below */
+    double *colstate_h;            /* pinned host */
+    double *colstate_d;
+    int tile, nslice, fast;        /* launch tuning (grt_gas_optics_tune) */
+} GrtGasOpticsImpl;
+
+int grt_gas_optics_prepare(GasOptics_t *go, int ncol);   /* build store/tables/layout if stale */
+/* Host prologue for one column (curtis_godson.c + partition sums), written at dst. */
+int grt_column_state(GasOptics_t const *go, fp_t const *p_mb, fp_t const *t,
+                     fp_t const *x_mol /* [NUM_MOLS][V] by id-1 */, fp_t const *x_cfc /* [NUM_CFCS][V] */,
+                     fp_t const *x_cia /* [NUM_CIAS][V] */, double *dst);
+int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_stride,
+                      GrtGasOpticsArgs *args);
+
+/* loaders */
+int grt_parse_hitran(char const *path, int mol_id, double w0, double wn, GrtHostLines *out);
+void grt_free_host_lines(GrtHostLines *l);
+int grt_load_table_on_grid(char const *path, int expect_cols, SpectralGrid_t const *grid,
+                           fp_t *out /* host [n], zero-filled then interpolated */);
+
+#endif

@@ -1,0 +1,162 @@
+/* grt_optics.c -- Optics_t container: tau, omega, g as (layer, wavenumber) rows in HBM.
+ * Contract: utilities/src/optics.h:30-87 (optics.c:84-357).  The arrays are device
+ * memory; add_optics allocates `result` (caller destroys it) but, unlike the
+ * reference, stages no temporary copies: the kernel reads the K inputs in place. */
+#include <string.h>
+#include "grt_internal.h"
+
+EXTERN int create_optics(Optics_t * const optics, int const num_layers,
+                         SpectralGrid_t const * const grid, Device_t const * const device)
+{
+    GRT_REQUIRE_PTR(optics);
+    GRT_REQUIRE_PTR(grid);
+    GRT_REQUIRE_PTR(device);
+    GRT_REQUIRE_RANGE(num_layers, MIN_NUM_LAYERS, MAX_NUM_LAYERS);
+    GRT_TRY(grt_dev_require(*device));
+    optics->num_layers = num_layers;
+    optics->grid = *grid;
+    optics->device = *device;
+    optics->g = optics->omega = optics->tau = NULL;
+    size_t const bytes = sizeof(fp_t)*(size_t)num_layers*grid->n;
+    void *s = grt_dev_stream(*device);
+    /* one allocation, three rows-of-rows: keeps the triple adjacent in HBM */
+    void *block = NULL;
+    GRT_TRY(grt_dev_alloc(*device, &block, 3*bytes));
+    GRT_TRY(grt_dev_zero(*device, block, 3*bytes, s));          /* optics.c:194-199 */
+    GRT_TRY(grt_dev_sync(*device, s));
+    optics->tau = (fp_t *)block;
+    optics->omega = optics->tau + (size_t)num_layers*grid->n;
+    optics->g = optics->omega + (size_t)num_layers*grid->n;
+    GRT_INFO("Optics object on device %d: %d layers x %zu points", *device, num_layers, (size_t)grid->n);
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN int destroy_optics(Optics_t * const optics)
+{
+    GRT_REQUIRE_PTR(optics);
+    GRT_TRY(grt_dev_free(optics->device, optics->tau));         /* base of the single block */
+    optics->g = optics->omega = optics->tau = NULL;
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN int optics_compatible(Optics_t const * const one, Optics_t const * const two,
+                             int * const result)
+{
+    GRT_REQUIRE_PTR(one);
+    GRT_REQUIRE_PTR(two);
+    GRT_REQUIRE_PTR(result);
+    int same = 0;
+    GRT_TRY(compare_spectral_grids(&one->grid, &two->grid, &same));
+    *result = (one->num_layers == two->num_layers && same == 1 && one->device == two->device) ? 1 : 0;
+    return GRTCODE_SUCCESS;
+}
+
+/* optics.c:84-124 */
+EXTERN int add_optics(Optics_t const * const * const optics, int const num_optics,
+                      Optics_t * const result)
+{
+    GRT_REQUIRE_PTR(optics);
+    GRT_REQUIRE_PTR(result);
+    GRT_REQUIRE_RANGE(num_optics, 1, 8);
+    Optics_t const *first = optics[0];
+    GRT_REQUIRE_PTR(first);
+    GrtOpticsPtrs in;
+    memset(&in, 0, sizeof(in));
+    for (int j = 0; j < num_optics; ++j)
+    {
+        GRT_REQUIRE_PTR(optics[j]);
+        int ok = 0;
+        GRT_TRY(optics_compatible(optics[j], first, &ok));
+        if (!ok)
+        {
+            GRT_FAIL(GRTCODE_VALUE_ERR, "input optics objects (%p, %p) are incompatible.",
+                     (void const *)first, (void const *)optics[j]);
+        }
+        in.tau[j] = optics[j]->tau;
+        in.omega[j] = optics[j]->omega;
+        in.g[j] = optics[j]->g;
+    }
+    GRT_TRY(create_optics(result, first->num_layers, &first->grid, &first->device));
+    void *s = grt_dev_stream(first->device);
+    uint64_t const n = (uint64_t)first->num_layers*first->grid.n;
+    GRT_TRY(grt_dev_check(grt_launch_add_optics(s, n, num_optics, &in, result->tau, result->omega,
+                                                result->g), "add_optics kernel"));
+    GRT_TRY(grt_dev_sync(first->device, s));
+    return GRTCODE_SUCCESS;
+}
+
+/* optics.c:237-302 */
+EXTERN int sample_optics(Optics_t * const dest, Optics_t const * const source,
+                         double const * const w0, double const * const wn)
+{
+    GRT_REQUIRE_PTR(dest);
+    GRT_REQUIRE_PTR(source);
+    if (dest->device != source->device)
+    {
+        GRT_FAIL(GRTCODE_VALUE_ERR, "Device ids (%d, %d) must match.", dest->device, source->device);
+    }
+    if (dest->num_layers != source->num_layers)
+    {
+        GRT_FAIL(GRTCODE_VALUE_ERR, "Number of layers (%d, %d) must match.", dest->num_layers,
+                 source->num_layers);
+    }
+    fp_t lower = dest->grid.w0, upper = dest->grid.wn;
+    uint64_t lo_d = 0, hi_d = dest->grid.n, lo_s = 0, hi_s = 0;
+    if (w0 != NULL)
+    {
+        GRT_TRY(grid_point_index(dest->grid, *w0, &lo_d));
+        lower = *w0;
+    }
+    GRT_TRY(grid_point_index(source->grid, lower, &lo_s));
+    if (wn != NULL)
+    {
+        GRT_TRY(grid_point_index(dest->grid, *wn, &hi_d));
+        upper = *wn;
+    }
+    GRT_TRY(grid_point_index(source->grid, upper, &hi_s));
+    if (upper < lower)
+    {
+        GRT_FAIL(GRTCODE_RANGE_ERR, "value (%e) less than minimum allowed (%e).", upper, lower);
+    }
+    uint64_t const n_d = hi_d - lo_d + 1;      /* the reference's own (n+1 when wn == NULL) count: optics.c:281 */
+    uint64_t const n_s = hi_s - lo_s + 1;
+    if (n_d > n_s || n_d < 2 || ((n_s - 1) % (n_d - 1)) != 0)
+    {
+        GRT_FAIL(GRTCODE_VALUE_ERR, "New grid must be a subdomain of the original (%p).",
+                 (void const *)&source->grid);
+    }
+    uint64_t const factor = (n_s - 1)/(n_d - 1);
+    uint64_t n_copy = n_d;
+    if (lo_d + n_copy > dest->grid.n)
+    {
+        n_copy = dest->grid.n - lo_d;          /* never write past the destination row */
+    }
+    void *s = grt_dev_stream(dest->device);
+    for (int i = 0; i < dest->num_layers; ++i)
+    {
+        uint64_t const od = (uint64_t)i*dest->grid.n + lo_d;
+        uint64_t const os = (uint64_t)i*source->grid.n + lo_s;
+        GRT_TRY(grt_dev_check(grt_launch_sample_optics(s, n_copy, factor, dest->tau + od, dest->omega + od,
+                                                       dest->g + od, source->tau + os, source->omega + os,
+                                                       source->g + os), "sample_optics kernel"));
+    }
+    GRT_TRY(grt_dev_sync(dest->device, s));
+    return GRTCODE_SUCCESS;
+}
+
+/* optics.c:345-357: host arrays -> device rows */
+EXTERN int update_optics(Optics_t * const optics, fp_t const * const tau,
+                         fp_t const * const omega, fp_t const * const g)
+{
+    GRT_REQUIRE_PTR(optics);
+    GRT_REQUIRE_PTR(tau);
+    GRT_REQUIRE_PTR(omega);
+    GRT_REQUIRE_PTR(g);
+    size_t const bytes = sizeof(fp_t)*(size_t)optics->num_layers*optics->grid.n;
+    void *s = grt_dev_stream(optics->device);
+    GRT_TRY(grt_dev_upload(optics->device, optics->tau, tau, bytes, s));
+    GRT_TRY(grt_dev_upload(optics->device, optics->omega, omega, bytes, s));
+    GRT_TRY(grt_dev_upload(optics->device, optics->g, g, bytes, s));
+    GRT_TRY(grt_dev_sync(optics->device, s));
+    return GRTCODE_SUCCESS;
+}

@@ -1,0 +1,305 @@
+/* grt_pipeline.c -- batched, device-resident clear-sky flux pipeline (grt_ext.h).
+ *
+ * This is the production shape of the hot path: what framework/src/driver.c does per
+ * column in column_calculation() (driver.c:360-424: set ppmv -> calculate_optical_depth
+ * -> rayleigh_scattering -> add_optics -> calculate_{lw,sw}_fluxes -> output_fluxes with
+ * -integrated, driver.c:285-356), done for a whole batch of columns with
+ *   - one host prologue + one small upload per column (layer state, a few kB),
+ *   - one line-by-line launch per band for the batch,
+ *   - Rayleigh and the two-object optics combination fused into one streaming pass
+ *     (no temporaries, no per-column allocation as in optics.c:84-124),
+ *   - one solver launch per band, fluxes kept in HBM,
+ *   - one wavefront-shuffle trapezoid launch per band that leaves 6 numbers per band
+ *     and column on the device (ready for an RCCL gather; nothing crosses PCIe).
+ * All work is enqueued on the device's library stream; nothing synchronises.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "grt_internal.h"
+
+typedef struct GrtBand
+{
+    GasOptics_t *gas;
+    uint64_t n;            /* grid points */
+    double *tau_gas;       /* [cols][L][n] */
+    double *tau, *omega, *g;
+    double *flux_up, *flux_down;   /* [cols][V][n] */
+    double **rows_d;       /* [cols][6] device row pointers for the trapezoid */
+    double *zero_row;      /* [n] zeros: stands in for the user level when there is none */
+} GrtBand;
+
+struct GrtPipeline
+{
+    Device_t device;
+    int max_cols, num_levels, user_level;
+    GrtBand band[2];       /* 0: longwave, 1: shortwave */
+    /* per-batch small inputs: pinned host staging + device copies */
+    double *small_h, *small_d;
+    size_t off_n, off_tl, off_tv, off_ts, off_mu, off_tsi, small_doubles;
+    double *emis_d, *albedo_d, *solar_d;
+};
+
+static int band_alloc(GrtPipeline_t *p, GrtBand *b, GasOptics_t *gas)
+{
+    memset(b, 0, sizeof(*b));
+    if (gas == NULL)
+    {
+        return GRTCODE_SUCCESS;
+    }
+    b->gas = gas;
+    b->n = gas->grid.n;
+    size_t const L = (size_t)p->num_levels - 1, V = (size_t)p->num_levels, C = (size_t)p->max_cols;
+    size_t const opt = sizeof(double)*C*L*b->n, flx = sizeof(double)*C*V*b->n;
+    void *blk = NULL;
+    GRT_TRY(grt_dev_alloc(p->device, &blk, 4*opt + 2*flx + sizeof(double)*b->n));
+    b->tau_gas = blk;
+    b->tau = b->tau_gas + C*L*b->n;
+    b->omega = b->tau + C*L*b->n;
+    b->g = b->omega + C*L*b->n;
+    b->flux_up = b->g + C*L*b->n;
+    b->flux_down = b->flux_up + C*V*b->n;
+    b->zero_row = b->flux_down + C*V*b->n;
+    void *s = grt_dev_stream(p->device);
+    GRT_TRY(grt_dev_zero(p->device, b->zero_row, sizeof(double)*b->n, s));
+    /* row table: up TOA, up surface, up user, down TOA, down surface, down user (driver.c:272-280) */
+    double **rows_h = malloc(sizeof(double *)*C*6);
+    for (size_t c = 0; c < C; ++c)
+    {
+        double *up = b->flux_up + c*V*b->n, *dn = b->flux_down + c*V*b->n;
+        rows_h[c*6 + 0] = up;
+        rows_h[c*6 + 1] = up + (V - 1)*b->n;
+        rows_h[c*6 + 2] = p->user_level >= 0 ? up + (size_t)p->user_level*b->n : b->zero_row;
+        rows_h[c*6 + 3] = dn;
+        rows_h[c*6 + 4] = dn + (V - 1)*b->n;
+        rows_h[c*6 + 5] = p->user_level >= 0 ? dn + (size_t)p->user_level*b->n : b->zero_row;
+    }
+    int rc = grt_dev_alloc(p->device, (void **)&b->rows_d, sizeof(double *)*C*6);
+    if (rc == GRTCODE_SUCCESS) rc = grt_dev_upload(p->device, b->rows_d, rows_h, sizeof(double *)*C*6, s);
+    if (rc == GRTCODE_SUCCESS) rc = grt_dev_sync(p->device, s);
+    free(rows_h);
+    GRT_TRY(rc);
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN int grt_pipeline_create(GrtPipeline_t **pipeline, GasOptics_t *lw_gas, GasOptics_t *sw_gas,
+                               int max_columns, int user_level, fp_t const *emissivity,
+                               fp_t const *albedo, fp_t const *solar_flux)
+{
+    GRT_REQUIRE_PTR(pipeline);
+    GRT_REQUIRE_RANGE(max_columns, 1, 65535);
+    GasOptics_t *any = lw_gas ? lw_gas : sw_gas;
+    GRT_REQUIRE_PTR(any);
+    if (lw_gas && sw_gas)
+    {
+        GRT_REQUIRE_EQ(lw_gas->device, sw_gas->device);
+        GRT_REQUIRE_EQ(lw_gas->num_levels, sw_gas->num_levels);
+    }
+    GRT_REQUIRE_RANGE(user_level, -1, any->num_levels - 1);
+    GrtPipeline_t *p = calloc(1, sizeof(*p));
+    p->device = any->device;
+    p->max_cols = max_columns;
+    p->num_levels = any->num_levels;
+    p->user_level = user_level;
+    GRT_TRY(grt_dev_require(p->device));
+    GRT_TRY(band_alloc(p, &p->band[0], lw_gas));
+    GRT_TRY(band_alloc(p, &p->band[1], sw_gas));
+    size_t const L = (size_t)p->num_levels - 1, V = (size_t)p->num_levels, C = (size_t)max_columns;
+    p->off_n = 0;
+    p->off_tl = p->off_n + C*L;
+    p->off_tv = p->off_tl + C*L;
+    p->off_ts = p->off_tv + C*V;
+    p->off_mu = p->off_ts + C;
+    p->off_tsi = p->off_mu + C;
+    p->small_doubles = p->off_tsi + C;
+    GRT_TRY(grt_host_alloc_pinned((void **)&p->small_h, sizeof(double)*p->small_doubles));
+    GRT_TRY(grt_dev_alloc(p->device, (void **)&p->small_d, sizeof(double)*p->small_doubles));
+    void *s = grt_dev_stream(p->device);
+    if (lw_gas != NULL)
+    {
+        GRT_REQUIRE_PTR(emissivity);
+        for (uint64_t i = 0; i < lw_gas->grid.n; ++i)
+        {
+            GRT_REQUIRE_RANGE(emissivity[i], 0., 1.);
+        }
+        GRT_TRY(grt_dev_alloc(p->device, (void **)&p->emis_d, sizeof(double)*lw_gas->grid.n));
+        GRT_TRY(grt_dev_upload(p->device, p->emis_d, emissivity, sizeof(double)*lw_gas->grid.n, s));
+    }
+    if (sw_gas != NULL)
+    {
+        GRT_REQUIRE_PTR(albedo);
+        GRT_REQUIRE_PTR(solar_flux);
+        for (uint64_t i = 0; i < sw_gas->grid.n; ++i)
+        {
+            GRT_REQUIRE_RANGE(albedo[i], 0., 1.);
+        }
+        GRT_TRY(grt_dev_alloc(p->device, (void **)&p->albedo_d, sizeof(double)*sw_gas->grid.n));
+        GRT_TRY(grt_dev_alloc(p->device, (void **)&p->solar_d, sizeof(double)*sw_gas->grid.n));
+        GRT_TRY(grt_dev_upload(p->device, p->albedo_d, albedo, sizeof(double)*sw_gas->grid.n, s));
+        GRT_TRY(grt_dev_upload(p->device, p->solar_d, solar_flux, sizeof(double)*sw_gas->grid.n, s));
+    }
+    GRT_TRY(grt_dev_sync(p->device, s));
+    *pipeline = p;
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN int grt_pipeline_destroy(GrtPipeline_t **pipeline)
+{
+    GRT_REQUIRE_PTR(pipeline);
+    GrtPipeline_t *p = *pipeline;
+    if (p == NULL)
+    {
+        return GRTCODE_SUCCESS;
+    }
+    for (int b = 0; b < 2; ++b)
+    {
+        GRT_TRY(grt_dev_free(p->device, p->band[b].tau_gas));
+        GRT_TRY(grt_dev_free(p->device, p->band[b].rows_d));
+    }
+    GRT_TRY(grt_dev_free(p->device, p->small_d));
+    GRT_TRY(grt_host_free_pinned(p->small_h));
+    GRT_TRY(grt_dev_free(p->device, p->emis_d));
+    GRT_TRY(grt_dev_free(p->device, p->albedo_d));
+    GRT_TRY(grt_dev_free(p->device, p->solar_d));
+    free(p);
+    *pipeline = NULL;
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN void *grt_pipeline_stream(GrtPipeline_t *pipeline)
+{
+    return pipeline ? grt_dev_stream(pipeline->device) : NULL;
+}
+
+EXTERN int grt_pipeline_sync(GrtPipeline_t *pipeline)
+{
+    GRT_REQUIRE_PTR(pipeline);
+    GRT_TRY(grt_dev_sync(pipeline->device, grt_dev_stream(pipeline->device)));
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN int grt_pipeline_views(GrtPipeline_t *pipeline, int band, fp_t **tau_gas, fp_t **tau,
+                              fp_t **omega, fp_t **g, fp_t **flux_up, fp_t **flux_down)
+{
+    GRT_REQUIRE_PTR(pipeline);
+    GRT_REQUIRE_RANGE(band, 0, 1);
+    GrtBand *b = &pipeline->band[band];
+    if (tau_gas) *tau_gas = b->tau_gas;
+    if (tau) *tau = b->tau;
+    if (omega) *omega = b->omega;
+    if (g) *g = b->g;
+    if (flux_up) *flux_up = b->flux_up;
+    if (flux_down) *flux_down = b->flux_down;
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN int grt_pipeline_run(GrtPipeline_t *p, GrtColumns_t const *cols, fp_t *fluxes_dev)
+{
+    GRT_REQUIRE_PTR(p);
+    GRT_REQUIRE_PTR(cols);
+    GRT_REQUIRE_PTR(fluxes_dev);
+    GRT_REQUIRE_RANGE(cols->ncol, 1, p->max_cols);
+    GRT_REQUIRE_EQ(cols->num_levels, p->num_levels);
+    GRT_REQUIRE_PTR(cols->pressure);
+    GRT_REQUIRE_PTR(cols->temperature);
+    int const V = p->num_levels, L = V - 1, C = cols->ncol;
+    void *s = grt_dev_stream(p->device);
+    /* the pinned staging buffers are reused every call: wait for the previous batch's
+       uploads (and, with them, its kernels) before overwriting them */
+    GRT_TRY(grt_dev_sync(p->device, s));
+
+    /* small per-column inputs: air column amounts for Rayleigh (rayleigh.c:104-128 via
+       curtis_godson.c:25-40), temperatures, sun geometry */
+    fp_t const mbtoatm = 0.000986923f;
+    fp_t const c_air = 2.147822334314468e+25;
+    for (int c = 0; c < C; ++c)
+    {
+        fp_t const *pm = cols->pressure + (size_t)c*V;
+        for (int i = 0; i < L; ++i)
+        {
+            fp_t dp = pm[i]*mbtoatm - pm[i + 1]*mbtoatm;
+            dp = dp >= 0.f ? dp : -1.f*dp;
+            p->small_h[p->off_n + (size_t)c*L + i] = c_air*dp;
+        }
+    }
+    if (p->band[0].gas != NULL)
+    {
+        GRT_REQUIRE_PTR(cols->layer_temperature);
+        GRT_REQUIRE_PTR(cols->surface_temperature);
+        for (int c = 0; c < C; ++c)
+        {
+            GRT_REQUIRE_RANGE(cols->surface_temperature[c], MIN_TEMPERATURE, MAX_TEMPERATURE);
+            for (int i = 0; i < L; ++i)
+            {
+                GRT_REQUIRE_RANGE(cols->layer_temperature[(size_t)c*L + i], MIN_TEMPERATURE, MAX_TEMPERATURE);
+            }
+        }
+        memcpy(p->small_h + p->off_tl, cols->layer_temperature, sizeof(double)*(size_t)C*L);
+        memcpy(p->small_h + p->off_tv, cols->temperature, sizeof(double)*(size_t)C*V);
+        memcpy(p->small_h + p->off_ts, cols->surface_temperature, sizeof(double)*(size_t)C);
+    }
+    if (p->band[1].gas != NULL)
+    {
+        GRT_REQUIRE_PTR(cols->cos_zenith);
+        GRT_REQUIRE_PTR(cols->total_solar_irradiance);
+        for (int c = 0; c < C; ++c)
+        {
+            if (!(cols->cos_zenith[c] > 0. && cols->cos_zenith[c] <= 1.))
+            {
+                GRT_FAIL(GRTCODE_RANGE_ERR, "cosine of zenith angle (%e) of column %d outside (0, 1]"
+                         " (night columns are skipped by the caller: driver.c:706).", cols->cos_zenith[c], c);
+            }
+        }
+        memcpy(p->small_h + p->off_mu, cols->cos_zenith, sizeof(double)*(size_t)C);
+        memcpy(p->small_h + p->off_tsi, cols->total_solar_irradiance, sizeof(double)*(size_t)C);
+    }
+    GRT_TRY(grt_dev_upload(p->device, p->small_d, p->small_h, sizeof(double)*p->small_doubles, s));
+
+    for (int bi = 0; bi < 2; ++bi)
+    {
+        GrtBand *b = &p->band[bi];
+        if (b->gas == NULL)
+        {
+            continue;
+        }
+        SpectralGrid_t const *grid = &b->gas->grid;
+        uint64_t const per_opt = (uint64_t)L*b->n, per_flux = (uint64_t)V*b->n;
+        /* gas optics (launch.c:40-226) */
+        GRT_TRY(grt_optical_depth_batch(b->gas, cols, b->tau_gas));
+        /* Rayleigh + add_optics({gas, rayleigh}) (driver.c:268, 382-383) */
+        GRT_TRY(grt_dev_check(grt_launch_clear_sky_optics(s, L, C, grid->w0, grid->dw, b->n,
+                                                          p->small_d + p->off_n, b->tau_gas, b->tau,
+                                                          b->omega, b->g), "clear-sky optics kernel"));
+        if (bi == 0)
+        {
+            GrtLwArgs a;
+            memset(&a, 0, sizeof(a));
+            a.num_levels = V; a.ncol = C; a.w0 = grid->w0; a.dw = grid->dw; a.nw = b->n;
+            a.tau = b->tau; a.omega = b->omega; a.optics_stride = per_opt;
+            a.t_layers = p->small_d + p->off_tl; a.t_levels = p->small_d + p->off_tv;
+            a.t_surf = p->small_d + p->off_ts;
+            a.emis = p->emis_d; a.emis_stride = 0;
+            a.flux_up = b->flux_up; a.flux_down = b->flux_down; a.flux_stride = per_flux;
+            a.user_level = p->user_level;
+            GRT_TRY(grt_dev_check(grt_launch_lw(s, &a), "longwave kernel"));
+        }
+        else
+        {
+            GrtSwArgs a;
+            memset(&a, 0, sizeof(a));
+            a.num_levels = V; a.ncol = C; a.nw = b->n; a.dw = grid->dw;
+            a.tau = b->tau; a.omega = b->omega; a.g = b->g; a.optics_stride = per_opt;
+            a.mu_dir = p->small_d + p->off_mu; a.mu_dif = 0.5;        /* driver.c:110 */
+            a.alb_dir = p->albedo_d; a.alb_dif = p->albedo_d; a.alb_stride = 0;   /* driver.c:118-119 */
+            a.tsi = p->small_d + p->off_tsi; a.solar = p->solar_d;
+            a.flux_up = b->flux_up; a.flux_down = b->flux_down; a.flux_stride = per_flux;
+            a.user_level = p->user_level;
+            GRT_TRY(grt_dev_check(grt_launch_sw(s, &a), "shortwave kernel"));
+        }
+        /* -integrated output (driver.c:302-326) */
+        GRT_TRY(grt_dev_check(grt_launch_integrate_rows(s, (double const *const *)b->rows_d, C*6, b->n,
+                                                        grid->dw, fluxes_dev, GRT_FLUXES_PER_BAND,
+                                                        GRT_FLUXES_PER_COLUMN, bi*GRT_FLUXES_PER_BAND),
+                              "spectral integration kernel"));
+    }
+    return GRTCODE_SUCCESS;
+}

@@ -1,0 +1,106 @@
+/* grt_ext.h -- entry points beyond the reference's ABI.
+ *
+ * The reference ABI (grtcode_hip_api.h) is one column per call, synchronous, with
+ * host-pointer outputs.  That shape cannot fill 256 CUs at coarse grids (3 250 points
+ * in the 1 cm-1 longwave band) and forces 2*V*n doubles over PCIe per call, so the
+ * production path is the batched, device-resident form below; the reference-shaped
+ * calls are its ncol == 1 wrappers plus the copies the old signatures demand.
+ * Everything here is plain C: pointers, sizes, no torch types.
+ */
+#ifndef GRT_EXT_H_
+#define GRT_EXT_H_
+
+#include "grtcode_hip_api.h"
+
+/* ---- partition sums (replaces gas-optics/src/tips2017.c, a missing blob) ----------
+ * Q(mol,T,iso) is served from a user-supplied table when one is loaded, otherwise from
+ * a documented analytic surrogate Q296(mol) * (T/296)^beta (beta = 1 for linear
+ * molecules, 1.5 otherwise).  Only ratios Q(296)/Q(T) reach the optical depths
+ * (parse_HITRAN_file.c:382 x kernels.c:62,85).
+ * Table file: CSV with header, rows "mol_id,iso,T,Q", T ascending per (mol,iso);
+ * linear interpolation in T, clamped at the ends. */
+EXTERN int grt_tips_load(char const *path);
+EXTERN int grt_tips_reset(void);
+EXTERN int grt_tips_is_table(void);
+
+/* ---- struct sizes for FFI callers (ctypes; cf. fortran-bindings/malloc_structs.c:40-66) */
+enum grt_struct_kind
+{
+    GRT_SPECTRAL_GRID = 0, GRT_OPTICS, GRT_GAS_OPTICS, GRT_SOLAR_FLUX, GRT_LONGWAVE, GRT_SHORTWAVE
+};
+EXTERN size_t grt_sizeof(int kind);
+
+/* ---- line lists from memory ------------------------------------------------------
+ * Same effect as add_molecule() reading these records from a HITRAN .par file:
+ * s_raw is the tabulated 296 K strength and is rescaled here exactly as
+ * parse_HITRAN_file.c:372-384 does; yair/yself/en/nexp/delta are narrowed to float as
+ * the file reader does (:197-212).  Lines outside the grid's [w0,wn] are dropped (:340). */
+EXTERN int grt_add_molecule_lines(GasOptics_t *gas_optics, int molecule_id, uint64_t num_lines,
+                                  int const *iso, double const *v0, double const *s_raw,
+                                  double const *yair, double const *yself, double const *en,
+                                  double const *nexp, double const *delta);
+
+/* ---- launch tuning for the line kernel (0 keeps the current/automatic value) ------ */
+EXTERN int grt_gas_optics_tune(GasOptics_t *gas_optics, int tile, int nslice, int fast);
+
+/* ---- batched columns ------------------------------------------------------------- */
+typedef struct GrtColumns
+{
+    int ncol;
+    int num_levels;
+    fp_t const *pressure;               /* [ncol][V] mb, TOA first (as calculate_optical_depth) */
+    fp_t const *temperature;            /* [ncol][V] K */
+    fp_t const *layer_temperature;      /* [ncol][V-1] K */
+    fp_t const *surface_temperature;    /* [ncol] K */
+    fp_t const *molecule_ppmv;          /* [ncol][num_molecules][V], add_molecule order */
+    fp_t const *cfc_ppmv;               /* [ncol][num_cfcs][V], add_cfc order (may be NULL) */
+    fp_t const *cia_ppmv;               /* [ncol][NUM_CIAS][V] by CiaId_t (may be NULL) */
+    fp_t const *cos_zenith;             /* [ncol] */
+    fp_t const *total_solar_irradiance; /* [ncol] W m-2 */
+} GrtColumns_t;
+
+/* launch.c:40-226 for ncol columns in one launch; tau_dev is DEVICE memory [ncol][L][n]. */
+EXTERN int grt_optical_depth_batch(GasOptics_t *gas_optics, GrtColumns_t const *columns,
+                                   fp_t *tau_dev);
+
+/* ---- clear-sky flux pipeline (driver.c:360-424 + 285-356 with -integrated) -------- */
+#define GRT_FLUXES_PER_BAND 6   /* up TOA, up surface, up user level, down TOA, down surface, down user level */
+#define GRT_FLUXES_PER_COLUMN (2*GRT_FLUXES_PER_BAND)   /* longwave six, then shortwave six */
+
+typedef struct GrtPipeline GrtPipeline_t;
+
+/* lw_gas / sw_gas: gas-optics objects on the longwave / shortwave grids (either may be
+   NULL to skip that band).  emissivity [n_lw], albedo [n_sw] (direct == diffuse, as
+   driver.c:118-119) and solar [n_sw] are host arrays copied once. */
+EXTERN int grt_pipeline_create(GrtPipeline_t **pipeline, GasOptics_t *lw_gas, GasOptics_t *sw_gas,
+                               int max_columns, int user_level, fp_t const *emissivity,
+                               fp_t const *albedo, fp_t const *solar_flux);
+EXTERN int grt_pipeline_destroy(GrtPipeline_t **pipeline);
+
+/* Enqueue the whole hot path for columns->ncol (<= max_columns) columns and write the
+   integrated fluxes [ncol][GRT_FLUXES_PER_COLUMN] to fluxes_dev (DEVICE memory).
+   Asynchronous on the library stream; grt_pipeline_sync() waits for it. */
+EXTERN int grt_pipeline_run(GrtPipeline_t *pipeline, GrtColumns_t const *columns, fp_t *fluxes_dev);
+EXTERN int grt_pipeline_sync(GrtPipeline_t *pipeline);
+/* The HIP stream every kernel of this device is enqueued on (for event timing). */
+EXTERN void *grt_pipeline_stream(GrtPipeline_t *pipeline);
+/* Device views of the last run's spectral arrays (for parity tests): band 0 = lw, 1 = sw. */
+EXTERN int grt_pipeline_views(GrtPipeline_t *pipeline, int band, fp_t **tau_gas, fp_t **tau,
+                              fp_t **omega, fp_t **g, fp_t **flux_up, fp_t **flux_down);
+
+/* ---- plain device-memory helpers for FFI callers (tests, bench) -------------------- */
+EXTERN int grt_device_malloc(Device_t device, void **ptr, size_t bytes);
+EXTERN int grt_device_free(Device_t device, void *ptr);
+EXTERN int grt_device_to_host(Device_t device, void *dst_host, void const *src_dev, size_t bytes);
+EXTERN int grt_host_to_device(Device_t device, void *dst_dev, void const *src_host, size_t bytes);
+
+/* ---- parity hook: per-(layer,line) preparation of kernels.c:34-131 and the integer
+ * windows of kernels.c:431-437 for one column, in merged-store order.  Host outputs:
+ * slot/iso [N]; v0 [N]; vnn, snn, gamma, alpha, win_s, win_e [L][N] (win_s > win_e when
+ * the line is skipped).  *num_lines receives N; pass NULL arrays to query N only. */
+EXTERN int grt_debug_line_prep(GasOptics_t *gas_optics, fp_t *pressure, fp_t *temperature,
+                               uint64_t *num_lines, uint8_t *slot, double *v0, double *vnn,
+                               double *snn, double *gamma, double *alpha, int64_t *win_s,
+                               int64_t *win_e);
+
+#endif

@@ -1,0 +1,124 @@
+"""Shared scenario builder for parity tests: one synthetic band + columns, evaluated by the
+oracle (CPU checker) and by the product (C ABI on the GPU) from the SAME files/arrays."""
+import os
+
+import numpy as np
+
+from grtcode_amd import api, synthetic as syn
+
+MOL_ORDER = [syn.H2O, syn.CO2, syn.O3, syn.N2O, syn.CO, syn.CH4, syn.O2]
+MOLTAB = {syn.H2O: (18.010565, 9), syn.CO2: (43.98983, 13), syn.O3: (47.984745, 18), syn.N2O: (44.001062, 5),
+          syn.CO: (27.994915, 9), syn.CH4: (16.0313, 4), syn.O2: (31.98983, 6)}
+CIA_PAIRS = [(0, 0, "cia_n2n2"), (1, 0, "cia_o2n2"), (1, 1, "cia_o2o2")]
+
+
+def mol_mass(mol):
+    return float(np.float32(MOLTAB[mol][0])) / 6.023e23
+
+
+class Band:
+    """A spectral band with synthetic lines + tables written to `root` in the reference's file formats."""
+
+    def __init__(self, root, w0, wn, dw, nlines, mols=MOL_ORDER, seed=20261003, sw=False,
+                 with_ctm=True, with_cfc=True, with_cia=True, line_range=None):
+        os.makedirs(root, exist_ok=True)
+        self.root, self.w0, self.wn, self.dw = root, w0, wn, dw
+        self.nw = int(np.ceil((wn - w0) / dw)) + 1
+        self.mols = list(mols)
+        lo, hi = line_range or (w0, wn)
+        share = {m: syn.LINE_SHARE[m] for m in self.mols}
+        tot = sum(share.values())
+        raw = {m: syn.line_list(m, max(int(round(nlines * share[m] / tot)), 0 if nlines == 0 else 1), lo, hi, seed)
+               for m in self.mols} if nlines > 0 else {m: syn.line_list(m, 0, lo, hi, seed) for m in self.mols}
+        self.par = os.path.join(root, "lines.par")
+        syn.write_hitran_par(self.par, raw)
+        self.lines = syn.read_back_par_values(raw)      # what a loader parses back (raw 296 K strengths)
+        t = syn.tables(sw=sw)
+        self.tab = t
+        self.with_ctm, self.with_cfc, self.with_cia = with_ctm, with_cfc, with_cia
+        self.h2o_dir = os.path.join(root, "h2o_ctm")
+        os.makedirs(self.h2o_dir, exist_ok=True)
+        syn.write_csv(os.path.join(self.h2o_dir, "296MTCKD25_F.csv"), *t["h2o_foreign_296"])
+        syn.write_csv(os.path.join(self.h2o_dir, "296MTCKD25_S.csv"), *t["h2o_self_296"])
+        syn.write_csv(os.path.join(self.h2o_dir, "CKDF.csv"), *t["h2o_foreign_t"], extra_cols=2)
+        syn.write_csv(os.path.join(self.h2o_dir, "CKDS.csv"), *t["h2o_self_t"], extra_cols=2)
+        self.files = {}
+        for name in ("o3_ctm", "cfc11", "cfc12", "cia_n2n2", "cia_o2n2", "cia_o2o2", "solar"):
+            p = os.path.join(root, name + ".csv")
+            syn.write_csv(p, *t[name])
+            self.files[name] = p
+
+    # -- text round trip of a CSV table: what the file actually holds -------------------- #
+    @staticmethod
+    def _csv_values(w, y):
+        return (np.array([float("%.6f" % a) for a in w]), np.array([float("%.9e" % b) for b in y]))
+
+    def table_on_grid(self, orc, name, constant_extrap=False):
+        w, y = self._csv_values(*self.tab[name])
+        return orc.interp_to_grid(self.w0, self.dw, self.nw, w, y, constant_extrap)
+
+    # -- the product ------------------------------------------------------------------- #
+    def gas_optics(self, device, num_levels, from_file=True):
+        grid = api.create_spectral_grid(self.w0, self.wn, self.dw)
+        go = api.GasOpticsObject(num_levels, grid, device, self.par,
+                                 self.h2o_dir if self.with_ctm else None,
+                                 self.files["o3_ctm"] if self.with_ctm else None)
+        for m in self.mols:
+            if from_file:
+                go.add_molecule(m)
+            else:
+                go.add_molecule_lines(m, self.lines[m])
+        if self.with_cfc:
+            go.add_cfc(0, self.files["cfc11"])
+            go.add_cfc(1, self.files["cfc12"])
+        if self.with_cia:
+            for a, b, name in CIA_PAIRS:
+                go.add_cia(a, b, self.files[name])
+        return go, grid
+
+    def set_column(self, go, col):
+        for m in self.mols:
+            go.set_molecule_ppmv(m, col["ppmv"][m])
+        if self.with_cfc:
+            go.set_cfc_ppmv(0, col["cfc_ppmv"][0])
+            go.set_cfc_ppmv(1, col["cfc_ppmv"][1])
+        if self.with_cia:
+            go.set_cia_ppmv(0, col["ppmv"][syn.N2])
+            go.set_cia_ppmv(1, col["ppmv"][syn.O2])
+
+    # -- the checker ------------------------------------------------------------------- #
+    def oracle_inputs(self, orc, lib, col):
+        """Everything orc.gas_optics / Ref.gas_optics need for one column.  1/Q and Q(296) come
+        from the product's provider through the C ABI (the reference's tips2017.c is missing),
+        so parity isolates everything else."""
+        p_atm = col["p"] * np.float64(np.float32(0.000986923))
+        _, _, tavg = orc.layer_means(p_atm, col["t"])
+        mols = []
+        for m in self.mols:
+            ln = dict(self.lines[m])
+            niso = MOLTAB[m][1]
+            q296 = np.array([lib.Q(m, 296.0, int(i)) for i in ln["iso"]])
+            ln["s0"] = orc.rescale_strengths(ln["s0"], ln["en"], ln["v0"], q296) if ln["v0"].size else ln["s0"]
+            q = np.array([[1.0 / lib.Q(m, float(T), k + 1) for k in range(niso)] for T in tavg])
+            mols.append(dict(id=m, num_iso=niso, mass=mol_mass(m), lines=ln, x=col["ppmv"][m] * 1e-6, q=q,
+                             h2o_ctm=int(m == syn.H2O and self.with_ctm), o3_ctm=int(m == syn.O3 and self.with_ctm)))
+        kw = dict(mols=mols)
+        if self.with_ctm:
+            kw["h2o_coefs"] = [self.table_on_grid(orc, k) for k in
+                               ("h2o_foreign_296", "h2o_self_296", "h2o_foreign_t", "h2o_self_t")]
+            kw["o3_xs"] = self.table_on_grid(orc, "o3_ctm")
+        if self.with_cfc:
+            kw["cfcs"] = [(col["cfc_ppmv"][0] * 1e-6, self.table_on_grid(orc, "cfc11")),
+                          (col["cfc_ppmv"][1] * 1e-6, self.table_on_grid(orc, "cfc12"))]
+        if self.with_cia:
+            x = {0: col["ppmv"][syn.N2] * 1e-6, 1: col["ppmv"][syn.O2] * 1e-6}
+            kw["cias"] = [(x[a], x[b], self.table_on_grid(orc, name)) for a, b, name in CIA_PAIRS]
+        return kw
+
+    def oracle_tau(self, checker, orc, lib, col):
+        kw = self.oracle_inputs(orc, lib, col)
+        return checker.gas_optics(col["p"], col["t"], self.w0, self.dw, self.nw, **kw)
+
+
+def rel_err(a, b, floor=1e-300):
+    return np.max(np.abs(a - b) / np.maximum(np.abs(b), floor))
