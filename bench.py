@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- columns/s of the line-by-line hot path on N MI355X (one process per GPU).
+
+Metric (BASELINE.json): columns/sec, 60 layers, 1 cm-1 LBL, LW+SW.  Workload = SURVEY.md §8(d)
+grid G1 (LW 1-3250 + SW 1-50000 cm-1 @ 1 cm-1) with 1.0 M / 1.5 M synthetic lines, seeded
+synthetic columns.  A step = one batch of COLS columns per GPU through the whole path
+(host prologue -> line-by-line tau -> Rayleigh+combine -> LW/SW solver -> spectral integration
+-> [N>1] RCCL gather of the 12 integrated fluxes per column to rank 0).  Line lists and tables
+are resident in HBM before the timed region; per-column inputs are 61-level host profiles.
+Weak scaling: every rank processes its own COLS columns per step (columns shard with no
+data-path collective other than that final gather).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector
+
+
+def cpu_baseline(wl_args, thin_lw=8, thin_sw=8):
+    """Reference OpenMP path (oracle/_ref, the reference's own C) -- or our restatement when the
+    prebuilt reference library is absent -- timed on a bounded sample: one column, full LW+SW grids
+    and solvers, line lists thinned by 1/thin; gas-optics time is scaled back by `thin`."""
+    from oracle.bindings import Oracle, Ref, ref_available
+    from grtcode_amd import api, synthetic as syn, workload as W
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from scenario import MOLTAB, mol_mass
+    cores = min(os.cpu_count() or 1, 16)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    kind = "reference" if ref_available(omp=True) else "port"
+    chk = Ref(omp=True) if kind == "reference" else Oracle()
+    orc = Oracle()
+    lib = api.load_library()
+    col = syn.profile(0, W.NUM_LEVELS)
+    p_atm = col["p"] * np.float64(np.float32(0.000986923))
+    _, _, tavg = orc.layer_means(p_atm, col["t"])
+    total = 0.0
+    detail = {}
+    for band, grid, nlines, thin, seed, sw in (("lw", W.LW_GRID, W.LW_LINES, thin_lw, 20261003, False),
+                                               ("sw", W.SW_GRID, W.SW_LINES, thin_sw, 20261004, True)):
+        w0, wn, dw = grid
+        nw = int(np.ceil((wn - w0) / dw)) + 1
+        lines = W.band_lines(nlines, grid, seed)
+        t = syn.tables(sw=sw)
+        on_grid = lambda name: orc.interp_to_grid(w0, dw, nw, *t[name])
+        mols = []
+        for m in W.MOL_ORDER:
+            ln = {k: v[::thin] for k, v in lines[m].items()}
+            niso = MOLTAB[m][1]
+            q296 = np.array([lib.Q(m, 296.0, int(i)) for i in ln["iso"]])
+            ln["s0"] = orc.rescale_strengths(ln["s0"], ln["en"], ln["v0"], q296)
+            q = np.array([[1.0 / lib.Q(m, float(T), k + 1) for k in range(niso)] for T in tavg])
+            mols.append(dict(id=m, num_iso=niso, mass=mol_mass(m), lines=ln, x=col["ppmv"][m] * 1e-6, q=q,
+                             h2o_ctm=int(m == syn.H2O), o3_ctm=int(m == syn.O3)))
+        kw = dict(mols=mols,
+                  h2o_coefs=[on_grid(k) for k in ("h2o_foreign_296", "h2o_self_296", "h2o_foreign_t", "h2o_self_t")],
+                  o3_xs=on_grid("o3_ctm"),
+                  cfcs=[(col["cfc_ppmv"][0] * 1e-6, on_grid("cfc11")), (col["cfc_ppmv"][1] * 1e-6, on_grid("cfc12"))],
+                  cias=[(col["ppmv"][syn.N2 if a == 0 else syn.O2] * 1e-6, col["ppmv"][syn.N2 if b == 0 else syn.O2] * 1e-6,
+                         on_grid(name)) for a, b, name in W.CIA_PAIRS])
+        t0 = time.perf_counter()
+        tau_gas = chk.gas_optics(col["p"], col["t"], w0, dw, nw, **kw)
+        t_gas = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        L = W.NUM_LEVELS - 1
+        if kind == "reference":
+            g = chk.grid(w0, wn, dw)
+            tr, om, gg = chk.rayleigh(g, L, col["p"])
+            z = np.zeros_like(tau_gas)
+            tau, omega, gsum = chk.add_optics(g, [tau_gas, tr], [z, om], [z, gg])
+            if not sw:
+                up, dn = chk.lw_fluxes(g, col["t_surf"], col["t_layer"], col["t"], tau, omega, np.full(nw, 0.98))
+            else:
+                solar = orc.normalize_solar(w0, dw, on_grid("solar"))
+                up, dn = chk.sw_fluxes(g, omega, gsum, tau, col["mu0"], 0.5, np.full(nw, 0.2), np.full(nw, 0.2),
+                                       col["tsi"], solar)
+        else:
+            tr, om, gg = chk.rayleigh(L, col["p"], w0, dw, nw)
+            z = np.zeros_like(tau_gas)
+            tau, omega, gsum = chk.add_optics([tau_gas, tr], [z, om], [z, gg])
+            if not sw:
+                up, dn = chk.lw_fluxes(w0, dw, col["t_surf"], col["t_layer"], col["t"], tau, omega, np.full(nw, 0.98))
+            else:
+                solar = orc.normalize_solar(w0, dw, on_grid("solar"))
+                up, dn = chk.sw_fluxes(omega, gsum, tau, col["mu0"], 0.5, np.full(nw, 0.2), np.full(nw, 0.2),
+                                       col["tsi"], solar)
+        for r in (up[0], up[-1], dn[0], dn[-1]):
+            orc.integrate_row(r, dw)
+        t_rest = time.perf_counter() - t0
+        detail[band] = dict(gas_optics_s_sample=round(t_gas, 3), rest_s=round(t_rest, 3), thin=thin)
+        total += t_gas * thin + t_rest
+    return {"value": 1.0 / total, "unit": "columns/s", "cores": cores, "kind": kind,
+            "sample": f"1 column, LW+SW at 1 cm-1, 60 layers, line lists thinned 1/{thin_lw} (LW) and 1/{thin_sw} (SW); "
+                      f"gas-optics time scaled back by the thinning factor, all other stages at full size",
+            "seconds_per_column_est": round(total, 2), "detail": detail}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cols", type=int, default=int(os.environ.get("GRT_BENCH_COLS", 8)), help="columns per GPU per step")
+    ap.add_argument("--fast", type=int, default=int(os.environ.get("GRT_BENCH_FAST", 0)))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lw-lines", type=int, default=None)
+    ap.add_argument("--sw-lines", type=int, default=None)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    # the C library reports loaded species on stdout (like the reference's log_mesg); keep stdout
+    # for the single JSON line by pointing fd 1 at stderr until the result is printed
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    import torch
+    import torch.distributed as dist
+    from grtcode_amd import api, workload as W
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    device = api.create_device(local_rank)
+    wl = W.G1Workload(device, args.cols, lw_lines=args.lw_lines or W.LW_LINES,
+                      sw_lines=args.sw_lines or W.SW_LINES, fast=args.fast)
+    (gcols, keep), _ = wl.columns(rank * args.cols, args.cols)
+    out = torch.zeros(args.cols, api.GRT_FLUXES_PER_COLUMN, dtype=torch.float64, device="cuda")
+    gathered = [torch.zeros_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
+    stream = torch.cuda.ExternalStream(wl.pipe.stream(), device=torch.device("cuda", local_rank))
+
+    def step():
+        wl.pipe.run(gcols, out.data_ptr())
+        if world > 1:
+            with torch.cuda.stream(stream):      # RCCL gather ordered after the kernels, no host sync
+                dist.gather(out, gathered, dst=0)
+
+    def barrier():
+        wl.pipe.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    api.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        fluxes = out.cpu().numpy()
+        assert np.all(np.isfinite(fluxes)), "non-finite integrated fluxes"
+        ms = {tag: api.profile_read(tag) for tag in (1, 2, 3, 4, 5)}
+        L, V = W.NUM_LEVELS - 1, W.NUM_LEVELS
+        n_lw, n_sw = wl.grid_lw.n, wl.grid_sw.n
+        S = wl.total_lines
+        # algorithmic bytes of the dominant kernel (line-by-line tau, SW-band launch), per launch:
+        # SURVEY.md §8(d) terms it owns: 60 B/line once per column + per wavenumber 8*C_tab table
+        # reads + 8*L tau written once (C_tab = 4 H2O + 1 O3 + 2 CFC + 3 CIA = 10 tables)
+        bytes_gas = lambda nlines, n: args.cols * (60.0 * nlines + n * (8.0 * 10 + 8.0 * L))
+        dom_ms = ms[2][0] / max(ms[2][1], 1)
+        achieved = bytes_gas(S["sw"], n_sw) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        fsteps = 25
+        points = lambda nlines: float(L) * nlines * (2 * fsteps + 1) * args.cols      # Voigt evaluations per launch
+        valu_flop = 12.0 * points(S["sw"])                                            # ~12 flop far-wing point
+        total_cols = world * args.cols * args.steps
+        line = {
+            "metric": "columns/sec (60-layer, 1 cm-1 LBL, LW+SW)", "value": total_cols / elapsed, "unit": "columns/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "SURVEY §8d grid G1: LW 1-3250 + SW 1-50000 cm-1 @1 cm-1, 60 layers, 7 absorbers, "
+                                   f"{S['lw']} LW + {S['sw']} SW synthetic lines, H2O/O3 continua, 2 CFC, 3 CIA, clear sky, "
+                                   "integrated fluxes",
+                       "columns_per_gpu_per_step": args.cols, "arithmetic": "fast" if args.fast else "reference-order",
+                       "parallelism": f"columns sharded over {world} GPU(s), RCCL gather of 12 fluxes/column"},
+            "roofline": {"kernel": "gas_optics_kernel (line-by-line tau), SW-band launch", "bound": "hbm",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "avg_launch_ms": dom_ms, "launches": ms[2][1],
+                         "note": "this kernel is FP32/FP64-VALU bound by construction (L*S*F Voigt evaluations), see roofline_valu"},
+            "roofline_valu": {"kernel": "gas_optics_kernel, SW-band launch", "bound": "valu_fp32",
+                              "achieved": valu_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0,
+                              "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s (12 flop per Voigt point, SURVEY §8d)",
+                              "frac": (valu_flop / (dom_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS) if dom_ms > 0 else 0.0,
+                              "voigt_points_per_launch": points(S["sw"]),
+                              "gpoints_per_s": points(S["sw"]) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0},
+            "kernel_ms_per_step": {"gas_optics_lw": ms[1][0] / args.steps, "gas_optics_sw": ms[2][0] / args.steps,
+                                   "lw_solver": ms[3][0] / args.steps, "sw_solver": ms[4][0] / args.steps,
+                                   "clear_sky_optics": ms[5][0] / args.steps},
+            "sample_fluxes_col0": {"rlut": fluxes[0, 0], "rlus": fluxes[0, 1], "rlds": fluxes[0, 4],
+                                   "rsut": fluxes[0, 6], "rsdt": fluxes[0, 9], "rsds": fluxes[0, 10]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args)
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
+    wl.destroy()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -138,7 +138,7 @@ create_solar_flux destroy_solar_flux disort_shortwave
 grt_tips_load grt_tips_reset grt_tips_is_table grt_sizeof grt_add_molecule_lines grt_gas_optics_tune
 grt_optical_depth_batch grt_pipeline_create grt_pipeline_destroy grt_pipeline_run grt_pipeline_sync
 grt_pipeline_stream grt_pipeline_views grt_device_malloc grt_device_free grt_device_to_host
-grt_host_to_device grt_debug_line_prep
+grt_host_to_device grt_debug_line_prep grt_profile_enable grt_profile_read
 """.split()
 
 _lib = None
@@ -436,3 +436,13 @@ class Pipeline:
     def destroy(self):
         self.out.free()
         check(self.lib.grt_pipeline_destroy(C.byref(self.p)))
+
+
+def profile_enable(on=True):
+    check(load_library().grt_profile_enable(int(on)))
+
+
+def profile_read(tag, reset=False):
+    ms, n = C.c_double(), C.c_int()
+    check(load_library().grt_profile_read(tag, C.byref(ms), C.byref(n), int(reset)))
+    return ms.value, n.value

@@ -219,3 +219,83 @@ EXTERN size_t grt_sizeof(int kind)
         default: return 0;
     }
 }
+
+/* ---- per-kernel HIP-event timing on the library stream (grt_ext.h: grt_profile_*) ----
+ * bench.py needs the average duration of the dominant kernel measured with HIP events on
+ * the stream it is launched on.  When enabled, launchers bracket that kernel with an event
+ * pair; grt_profile_read() resolves the pairs after the stream has drained. */
+#define GRT_PROFILE_SLOTS 8192
+static int g_profile_on = 0;
+static int g_profile_count = 0;
+static hipEvent_t g_profile_ev[GRT_PROFILE_SLOTS][2];
+static int g_profile_tag[GRT_PROFILE_SLOTS];
+
+EXTERN int grt_profile_enable(int on)
+{
+    g_profile_on = on ? 1 : 0;
+    if (!on)
+    {
+        for (int i = 0; i < g_profile_count; ++i)
+        {
+            hipEventDestroy(g_profile_ev[i][0]);
+            hipEventDestroy(g_profile_ev[i][1]);
+        }
+        g_profile_count = 0;
+    }
+    return GRTCODE_SUCCESS;
+}
+
+int grt_profile_begin(void *stream, int tag)
+{
+    if (!g_profile_on || g_profile_count >= GRT_PROFILE_SLOTS)
+    {
+        return -1;
+    }
+    int const k = g_profile_count;
+    if (hipEventCreate(&g_profile_ev[k][0]) != hipSuccess || hipEventCreate(&g_profile_ev[k][1]) != hipSuccess)
+    {
+        return -1;
+    }
+    g_profile_tag[k] = tag;
+    hipEventRecord(g_profile_ev[k][0], (hipStream_t)stream);
+    g_profile_count++;
+    return k;
+}
+
+void grt_profile_end(void *stream, int slot)
+{
+    if (slot >= 0)
+    {
+        hipEventRecord(g_profile_ev[slot][1], (hipStream_t)stream);
+    }
+}
+
+/* Sum of elapsed milliseconds and number of launches recorded with `tag` since the last
+   reset; call after the stream has been synchronised.  reset != 0 clears the records. */
+EXTERN int grt_profile_read(int tag, double *total_ms, int *launches, int reset)
+{
+    GRT_REQUIRE_PTR(total_ms);
+    GRT_REQUIRE_PTR(launches);
+    double sum = 0.;
+    int n = 0;
+    for (int i = 0; i < g_profile_count; ++i)
+    {
+        if (g_profile_tag[i] == tag)
+        {
+            float ms = 0.f;
+            GRT_TRY(grt_dev_check((int)hipEventElapsedTime(&ms, g_profile_ev[i][0], g_profile_ev[i][1]),
+                                  "hipEventElapsedTime"));
+            sum += ms;
+            ++n;
+        }
+    }
+    *total_ms = sum;
+    *launches = n;
+    if (reset)
+    {
+        int const keep = g_profile_on;
+        grt_profile_enable(0);
+        g_profile_on = keep;
+    }
+    return GRTCODE_SUCCESS;
+}

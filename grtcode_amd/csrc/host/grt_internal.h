@@ -52,6 +52,8 @@ int grt_dev_copy(Device_t device, void *dst, void const *src, size_t bytes, void
 int grt_dev_sync(Device_t device, void *stream);
 int grt_dev_check(int hip_error, char const *what);     /* maps any HIP error to GRTCODE_GPU_ERR */
 void *grt_dev_stream(Device_t device);                  /* library stream of a device (created lazily) */
+int grt_profile_begin(void *stream, int tag);           /* -1 when profiling is off */
+void grt_profile_end(void *stream, int slot);
 int grt_host_alloc_pinned(void **p, size_t bytes);
 int grt_host_free_pinned(void *p);
 

@@ -266,9 +266,11 @@ EXTERN int grt_pipeline_run(GrtPipeline_t *p, GrtColumns_t const *cols, fp_t *fl
         /* gas optics (launch.c:40-226) */
         GRT_TRY(grt_optical_depth_batch(b->gas, cols, b->tau_gas));
         /* Rayleigh + add_optics({gas, rayleigh}) (driver.c:268, 382-383) */
-        GRT_TRY(grt_dev_check(grt_launch_clear_sky_optics(s, L, C, grid->w0, grid->dw, b->n,
-                                                          p->small_d + p->off_n, b->tau_gas, b->tau,
-                                                          b->omega, b->g), "clear-sky optics kernel"));
+        int slot = grt_profile_begin(s, 5);
+        int krc = grt_launch_clear_sky_optics(s, L, C, grid->w0, grid->dw, b->n, p->small_d + p->off_n,
+                                              b->tau_gas, b->tau, b->omega, b->g);
+        grt_profile_end(s, slot);
+        GRT_TRY(grt_dev_check(krc, "clear-sky optics kernel"));
         if (bi == 0)
         {
             GrtLwArgs a;
@@ -280,7 +282,10 @@ EXTERN int grt_pipeline_run(GrtPipeline_t *p, GrtColumns_t const *cols, fp_t *fl
             a.emis = p->emis_d; a.emis_stride = 0;
             a.flux_up = b->flux_up; a.flux_down = b->flux_down; a.flux_stride = per_flux;
             a.user_level = p->user_level;
-            GRT_TRY(grt_dev_check(grt_launch_lw(s, &a), "longwave kernel"));
+            slot = grt_profile_begin(s, 3);
+            krc = grt_launch_lw(s, &a);
+            grt_profile_end(s, slot);
+            GRT_TRY(grt_dev_check(krc, "longwave kernel"));
         }
         else
         {
@@ -293,7 +298,10 @@ EXTERN int grt_pipeline_run(GrtPipeline_t *p, GrtColumns_t const *cols, fp_t *fl
             a.tsi = p->small_d + p->off_tsi; a.solar = p->solar_d;
             a.flux_up = b->flux_up; a.flux_down = b->flux_down; a.flux_stride = per_flux;
             a.user_level = p->user_level;
-            GRT_TRY(grt_dev_check(grt_launch_sw(s, &a), "shortwave kernel"));
+            slot = grt_profile_begin(s, 4);
+            krc = grt_launch_sw(s, &a);
+            grt_profile_end(s, slot);
+            GRT_TRY(grt_dev_check(krc, "shortwave kernel"));
         }
         /* -integrated output (driver.c:302-326) */
         GRT_TRY(grt_dev_check(grt_launch_integrate_rows(s, (double const *const *)b->rows_d, C*6, b->n,

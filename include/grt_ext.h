@@ -88,6 +88,13 @@ EXTERN void *grt_pipeline_stream(GrtPipeline_t *pipeline);
 EXTERN int grt_pipeline_views(GrtPipeline_t *pipeline, int band, fp_t **tau_gas, fp_t **tau,
                               fp_t **omega, fp_t **g, fp_t **flux_up, fp_t **flux_down);
 
+/* ---- HIP-event timing of individual kernels on the library stream -------------------
+ * Tags: 1 = line-by-line kernel on a grid of <= 10 000 points (longwave band at 1 cm-1),
+ * 2 = line-by-line kernel on a larger grid (shortwave band), 3 = LW solver, 4 = SW solver,
+ * 5 = clear-sky optics combine.  Read after grt_pipeline_sync(). */
+EXTERN int grt_profile_enable(int on);
+EXTERN int grt_profile_read(int tag, double *total_ms, int *launches, int reset);
+
 /* ---- plain device-memory helpers for FFI callers (tests, bench) -------------------- */
 EXTERN int grt_device_malloc(Device_t device, void **ptr, size_t bytes);
 EXTERN int grt_device_free(Device_t device, void *ptr);

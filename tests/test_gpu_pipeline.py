@@ -1,0 +1,106 @@
+"""The batched device-resident pipeline (grt_pipeline_*) against the oracle's column-by-column
+restatement of driver.c:360-424 + 285-356, plus size-independent properties at larger sizes."""
+import numpy as np
+import pytest
+
+from grtcode_amd import api, synthetic as syn
+from scenario import Band, MOL_ORDER
+
+pytestmark = pytest.mark.gpu
+
+FLUX_TOL = 1e-3      # W m-2, BASELINE.json north_star tolerance on broadband fluxes
+
+
+def oracle_column(orc, lib, band, col, lw, emis=None, alb=None, solar=None, user_level=-1):
+    L = col["p"].size - 1
+    tau_gas = band.oracle_tau(orc, orc, lib, col)
+    tr, om_r, g_r = orc.rayleigh(L, col["p"], band.w0, band.dw, band.nw)
+    z = np.zeros_like(tau_gas)
+    tau, omega, g = orc.add_optics([tau_gas, tr], [z, om_r], [z, g_r])
+    if lw:
+        up, dn = orc.lw_fluxes(band.w0, band.dw, col["t_surf"], col["t_layer"], col["t"], tau, omega, emis)
+    else:
+        up, dn = orc.sw_fluxes(omega, g, tau, col["mu0"], 0.5, alb, alb, col["tsi"], solar)
+    rows = [up[0], up[-1], up[user_level] if user_level >= 0 else None,
+            dn[0], dn[-1], dn[user_level] if user_level >= 0 else None]
+    integ = [orc.integrate_row(r, band.dw) if r is not None else 0.0 for r in rows]
+    return dict(tau_gas=tau_gas, tau=tau, omega=omega, g=g, up=up, dn=dn, integ=np.array(integ))
+
+
+@pytest.fixture(scope="module")
+def bands(tmp_path_factory):
+    root = tmp_path_factory.mktemp("pipe")
+    lw = Band(str(root / "lw"), 1.0, 400.0, 1.0, 3000)
+    sw = Band(str(root / "sw"), 1.0, 5000.0, 10.0, 3000, sw=True)
+    return lw, sw
+
+
+def test_pipeline_matches_oracle_per_column(bands, oracle, lib, device):
+    lwb, swb = bands
+    V, ncol, user_level = 16, 3, 5
+    cols = [syn.profile(c, V) for c in range(ncol)]
+    go_lw, grid_lw = lwb.gas_optics(device, V)
+    go_sw, grid_sw = swb.gas_optics(device, V)
+    emis = np.full(lwb.nw, 0.98)
+    alb = np.full(swb.nw, 0.2)
+    solar = api.create_solar_flux(grid_sw, swb.files["solar"])
+    w, y = swb._csv_values(*swb.tab["solar"])
+    want_solar = oracle.normalize_solar(swb.w0, swb.dw, oracle.interp_to_grid(swb.w0, swb.dw, swb.nw, w, y))
+    assert np.max(np.abs(solar - want_solar)) <= 1e-15 * want_solar.max()
+    pipe = api.Pipeline(go_lw, go_sw, ncol, user_level, emis, alb, solar)
+    gcols, keep = api.make_columns(cols, MOL_ORDER, cfc_order=(0, 1))
+    pipe.run(gcols)
+    got = pipe.fluxes(ncol)
+    L = V - 1
+    for bi, (band, lw) in enumerate(((lwb, True), (swb, False))):
+        v = pipe.views(bi)
+        tau_gas = api.device_to_host(device, v["tau_gas"], (ncol, L, band.nw))
+        tau = api.device_to_host(device, v["tau"], (ncol, L, band.nw))
+        omega = api.device_to_host(device, v["omega"], (ncol, L, band.nw))
+        up = api.device_to_host(device, v["flux_up"], (ncol, V, band.nw))
+        dn = api.device_to_host(device, v["flux_down"], (ncol, V, band.nw))
+        for c, col in enumerate(cols):
+            w = oracle_column(oracle, lib, band, col, lw, emis, alb, solar, user_level)
+            scale = np.abs(w["tau_gas"]).max(axis=1, keepdims=True)
+            assert np.max(np.abs(tau_gas[c] - w["tau_gas"]) / scale) < 1e-11
+            assert np.max(np.abs(tau[c] - w["tau"]) / np.abs(w["tau"]).max(axis=1, keepdims=True)) < 1e-11
+            assert np.max(np.abs(omega[c] - w["omega"])) < 1e-11
+            fs = max(np.abs(w["up"]).max(), np.abs(w["dn"]).max())
+            assert np.max(np.abs(up[c] - w["up"])) / fs < 1e-10
+            assert np.max(np.abs(dn[c] - w["dn"])) / fs < 1e-10
+            assert np.max(np.abs(got[c, bi * 6: bi * 6 + 6] - w["integ"])) < FLUX_TOL * 1e-6   # far inside 1e-3 W m-2
+    pipe.destroy()
+    go_lw.destroy()
+    go_sw.destroy()
+
+
+def test_pipeline_properties_full_width_band(tmp_path, lib, device):
+    """Size-independent properties on the full 1 cm-1 longwave grid (n = 3250, 60 layers):
+    tau is additive over absorbers and linear in abundance; batched == one-by-one."""
+    band = Band(str(tmp_path), 1.0, 3250.0, 1.0, 30000, with_cfc=False, with_cia=False, with_ctm=False)
+    V = 61
+    col = syn.profile(9, V)
+
+    def tau_for(mols, scale=1.0):
+        b = Band.__new__(Band)
+        b.__dict__.update(band.__dict__)
+        b.mols = mols
+        go, grid = b.gas_optics(device, V, from_file=False)
+        c = dict(col)
+        c["ppmv"] = {k: v * scale for k, v in col["ppmv"].items()}
+        b.set_column(go, c)
+        opt = api.OpticsObject(V - 1, grid, device)
+        go.calculate_optical_depth(c["p"], c["t"], opt)
+        t = opt.read()[0]
+        opt.destroy()
+        go.destroy()
+        return t
+
+    t_all = tau_for([syn.CO2, syn.CH4])
+    t_a, t_b = tau_for([syn.CO2]), tau_for([syn.CH4])
+    scale = t_all.max(axis=1, keepdims=True)
+    assert np.max(np.abs(t_all - (t_a + t_b)) / scale) < 1e-12
+    # CH4 is trace (ps << p): doubling its abundance doubles N_s, and changes gamma only through ps
+    t_b2 = tau_for([syn.CH4], scale=2.0)
+    assert np.max(np.abs(t_b2 - 2.0 * t_b) / t_b.max(axis=1, keepdims=True)) < 1e-4
+    assert np.all(t_all >= 0) and np.all(np.isfinite(t_all))
