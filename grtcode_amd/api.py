@@ -149,7 +149,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get("GRT_LIB_PATH") or LIB_PATH   # GRT_LIB_PATH: timing experiments only
     if not os.path.exists(path):
         raise LibraryMissing(f"{path} not found: build it with `python -m grtcode_amd.build` "
                              "(hipcc --offload-arch=gfx950); there is no fallback path")
@@ -176,8 +176,7 @@ def load_library(path=None):
     lib.grt_pipeline_stream.argtypes = [C.c_void_p]
     lib.grt_pipeline_views.argtypes = [C.c_void_p, C.c_int] + [C.POINTER(C.c_void_p)] * 6
     lib.grt_optical_depth_batch.argtypes = [C.POINTER(GasOptics), C.POINTER(GrtColumns), C.c_void_p]
-    if path == LIB_PATH:
-        _lib = lib
+    _lib = lib
     return lib
 
 

@@ -15,12 +15,17 @@
 //   * all molecules' lines are one list sorted by centre; the tile's candidates are
 //     a contiguous range found by binary search with a conservative halo
 //     (window + max pressure shift); exact integer window test per line.
-//   * phase A: 256 threads prepare 256 lines (one each): shifted centre, S(T),
-//     gamma_L, alpha_D, window indices, Voigt per-line constants -> LDS records.
-//   * phase B: each wave walks its share of the records; the 64 lanes are 64
-//     consecutive points of that line's window (coalesced in LDS, conflict-free
-//     ds_add_f64).  Lines in the pure-Lorentz regime (y >= 70.55) and far-wing
-//     points (|x| >= XLIM0) -- ~99 % of all points -- take one short path each.
+//   * one lane = one line: each lane prepares its line (shifted centre, S(T), gamma_L,
+//     alpha_D, window indices, Voigt per-line constants) and keeps the results in
+//     registers, then walks that line's own window point by point.  At 1 cm-1 a
+//     window is only 51 points, so per-line set-up must be amortised by the lane that
+//     pays it; 64 lanes process 64 lines at once with no LDS staging and no barrier.
+//   * accumulation is a ring inside the wavefront: 64 partial sums, one per grid index of
+//     a 64-point span, rotate through the 64 lanes; each lane adds its own line's value to
+//     the token passing by.  After 64 steps one conflict-free ds_add_f64 per lane flushes
+//     the span.  No LDS traffic and no atomics in the inner loop.  Pure-Lorentz lines
+//     (y >= 70.55), far-wing points (|x| >= XLIM0) and Humlicek region 1 -- together
+//     >99 % of all points -- are evaluated in line.
 //   * near-centre points (Humlicek regions 1-4) are pushed to a per-wave LDS queue
 //     and evaluated later with all 64 lanes busy, so the long polynomial/rational
 //     code is never executed for a single active lane.
@@ -41,33 +46,40 @@
 
 #pragma clang fp contract(off)
 
+// Ablation hooks for timing experiments only (never defined in the product build).
+#if defined(GRT_EXP_NOATOMIC)
+#define GRT_ACC_ADD(ptr, v) (*(ptr) += (v))
+#else
+#define GRT_ACC_ADD(ptr, v) unsafeAtomicAdd((ptr), (v))
+#endif
+
 namespace {
 
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock/64;
-constexpr int kChunk = 256;     // line records per phase-A round (one per thread)
-constexpr int kQueue = 192;     // near-centre queue entries per wave (>= 128)
+constexpr int kQueue = 128;     // near-centre queue entries per wave: drained above 64, <= 64 pushed per step
 
 // RFM_voigt.c:72,79
 constexpr float kRsqrpi = 0.56418958f;
 constexpr float kSqrln2 = 0.832554611f;
 
-struct LineRecords
-{
-    double dwno[kChunk];    // wavenumber of window point 0: s*wres + w0 (kernels.c:438)
-    double wnoadj[kChunk];  // shifted centre
-    double amp[kChunk];     // S(T) * N_s
-    float repwid[kChunk];   // sqrt(ln2)/alpha_D (float, RFM_voigt.c:94)
-    float y[kChunk];        // repwid * gamma_L (float, RFM_voigt.c:95)
-    int s[kChunk];          // first window point; skipped line: s > e
-    int e[kChunk];          // last window point
-};
-
 struct Prepared
 {
     double vnn, snn, gamma, alpha;
     long long s, e;         // s > e: line skipped (kernels.c:433)
+    int c_minus_fsteps;     // centre index - fsteps: the window start before clipping at 0
 };
+
+// exp(x) for the FAST form: range reduction in fp64, 2^fraction on the hardware
+// transcendental unit (v_exp_f32, ~1 ulp of fp32), exact scaling by 2^n.  Relative error
+// ~1e-7, the same class as the fp32 line-shape value it multiplies.
+__device__ __forceinline__ double exp_fast(double x)
+{
+    double const z = x*1.4426950408889634;
+    double const n = rint(z);
+    float const r = __builtin_amdgcn_exp2f((float)(z - n));
+    return ldexp((double)r, (int)n);
+}
 
 // kernels.c:34-131 for one (layer, line) + the window of kernels.c:431-437.
 // lay: pavg, tavg, 1/tavg, log(296/tavg); ms: ps, pavg-ps, ns, doppler factor.
@@ -90,21 +102,28 @@ __device__ __forceinline__ Prepared prepare_line(GrtLineStore const &ls, uint64_
     if (FAST)
     {
         double const invT = lay[2];
-        p.snn = ls.s0[j]*exp((c2*en)*invT)*(1.0 - exp((c2*v0)*invT))*q[ls.iso[j] - 1];
-        p.gamma = exp(nexp*lay[3])*fma(yair, pf, yself*ps);
+        p.snn = ls.s0[j]*exp_fast((c2*en)*invT)*(1.0 - exp_fast((c2*v0)*invT))*q[ls.iso[j] - 1];
+        p.gamma = exp_fast(nexp*lay[3])*fma(yair, pf, yself*ps);
     }
     else
     {
+#if defined(GRT_EXP_NOPREP)
+        p.snn = ls.s0[j]*(c2*en/T)*(1.f - (c2*v0/T))*q[ls.iso[j] - 1];
+        p.gamma = (tref/T + nexp)*(yair*pf + yself*ps);
+#else
         p.snn = ls.s0[j]*exp(c2*en/T)*(1.f - exp(c2*v0/T))*q[ls.iso[j] - 1];   // kernels.c:83-85
         p.gamma = pow(tref/T, nexp)*(yair*pf + yself*ps);                  // kernels.c:105-106
+#endif
     }
     p.alpha = sqrt_ln2*p.vnn*dop;                                    // kernels.c:127
     double const fc = floor((2*((p.vnn - w0)/wres) + 1)/2);          // kernels.c:431-432
     p.s = 1;
     p.e = 0;
+    p.c_minus_fsteps = 0;
     if (fc >= 0. && fc < (double)nw)
     {
         long long const c = (long long)fc;
+        p.c_minus_fsteps = (int)(c - fsteps);
         p.s = (c - fsteps) < 0 ? 0 : c - fsteps;                     // kernels.c:435
         p.e = (c + fsteps) >= nw ? nw - 1 : c + fsteps;              // kernels.c:436-437
     }
@@ -233,15 +252,75 @@ __device__ __forceinline__ float voigt_x(double dwno, int k, double wres, double
     return (float)((dwno + (double)k*wres - wnoadj)*(double)repwid);
 }
 
+// Wave-wide integer min/max (butterfly over the 64 lanes).
+__device__ __forceinline__ int wave_min(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        int const o = __shfl_xor(v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int wave_max(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        int const o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// One step of the accumulation ring: every lane hands its partial sum to the lane below it
+// (lane l receives from lane (l+1) & 63), so the token for slot (lane + t) & 63 arrives where
+// that slot is evaluated at step t + 1.
+__device__ __forceinline__ double ring_pass(double v)
+{
+    // v_mov_b32_dpp wave_rol:1 (DPP control 0x134): lane l <- lane l+1, lane 63 <- lane 0;
+    // register-file latency, no LDS crossbar trip (direction verified on gfx950 hardware)
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x134, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x134, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// Near-centre points wait here until a wave has 64 of them (struct-of-arrays in LDS).
+struct NearQueue
+{
+    double amp[kWaves][kQueue];     // S(T)*N_s of the line
+    float xi[kWaves][kQueue];
+    float y[kWaves][kQueue];
+    float repwid[kWaves][kQueue];
+    int idx[kWaves][kQueue];        // accumulator index f - F0
+};
+
+// Evaluate queued near-centre points with all lanes busy (Humlicek regions 1-4) and add them
+// to the tile.  Kept out of line: it is cold code, and inlining it into every unrolled ring step
+// would push the hot loop out of the instruction cache.
+__device__ __noinline__ void drain_near(double *acc, double const *q_amp, float const *q_xi,
+                                        float const *q_y, float const *q_rep, int const *q_idx,
+                                        int count, int lane)
+{
+    for (int i = lane; i < count; i += 64)
+    {
+        double const k = (double)(kRsqrpi*q_rep[i])*voigt_near(q_xi[i], q_y[i]);   // RFM_voigt.c:278
+        GRT_ACC_ADD(&acc[q_idx[i]], q_amp[i]*k);                                   // kernels.c:459
+    }
+}
+
+// waves_per_eu(4): cap at 128 VGPRs so four workgroups share a CU; measured +7 % over the
+// compiler's default 137 VGPRs / 3 waves per SIMD (f32 VALU issue 3.0 vs 3.3 cycles per wave64 op)
 template <bool FAST>
-__global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, long long fsteps)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) void gas_optics_kernel(GrtGasOpticsArgs a, long long fsteps)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *acc = reinterpret_cast<double *>(smem);                               // [tile]
-    LineRecords *rec = reinterpret_cast<LineRecords *>(smem + sizeof(double)*a.tile);
-    int *qslot = reinterpret_cast<int *>(rec + 1);                                // [kWaves][kQueue]
-    int *qpoint = qslot + kWaves*kQueue;                                          // [kWaves][kQueue]
-    long long *range = reinterpret_cast<long long *>(qpoint + kWaves*kQueue);     // [2]
+    NearQueue *nq = reinterpret_cast<NearQueue *>(smem + sizeof(double)*a.tile);
+    long long *range = reinterpret_cast<long long *>(nq + 1);                     // [2]
 
     int const tid = threadIdx.x;
     int const lane = tid & 63;
@@ -251,9 +330,11 @@ __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, 
     int const layer = blockIdx.y;
     int const col = blockIdx.z;
     long long const nw = (long long)a.nw;
-    long long const F0 = (long long)tile_idx*a.tile;
-    long long const F1 = (F0 + a.tile < nw) ? F0 + a.tile : nw;                   // [F0,F1)
+    long long const F0l = (long long)tile_idx*a.tile;
+    long long const F1l = (F0l + a.tile < nw) ? F0l + a.tile : nw;                // [F0,F1)
+    int const F0 = (int)F0l, F1 = (int)F1l;
     int const L = a.lay.num_layers;
+    int const W = (int)(2*fsteps + 1);                                            // full window
 
     double const *cs = a.colstate + (uint64_t)col*a.lay.stride;
     double const *lay = cs + a.lay.off_lay + (uint64_t)layer*4;
@@ -269,8 +350,8 @@ __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, 
     if (tid == 0)
     {
         double const shift = a.lines.dmax*fabs(lay[0]);
-        double const wlo = a.w0 + ((double)(F0 - fsteps) - 1.5)*a.wres - shift;
-        double const whi = a.w0 + ((double)(F1 + fsteps) + 0.5)*a.wres + shift;
+        double const wlo = a.w0 + ((double)(F0l - fsteps) - 1.5)*a.wres - shift;
+        double const whi = a.w0 + ((double)(F1l + fsteps) + 0.5)*a.wres + shift;
         uint64_t lo = 0, hi = a.lines.n;
         while (lo < hi)
         {
@@ -297,134 +378,225 @@ __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, 
     uint64_t const jend = (uint64_t)range[1];
 
     int qcount = 0;                      // wave-uniform
-    int *myq_slot = qslot + wave*kQueue;
-    int *myq_point = qpoint + wave*kQueue;
+    double *q_amp = nq->amp[wave];
+    float *q_xi = nq->xi[wave], *q_y = nq->y[wave], *q_rep = nq->repwid[wave];
+    int *q_idx = nq->idx[wave];
 
-    // Evaluate queued near-centre points with all lanes busy.
     auto drain = [&](int count)
     {
-        for (int i = lane; i < count; i += 64)
-        {
-            int const l = myq_slot[i];
-            int const f = myq_point[i];
-            float const repwid = rec->repwid[l];
-            float const y = rec->y[l];
-            float const xi = voigt_x(rec->dwno[l], f - rec->s[l], a.wres, rec->wnoadj[l], repwid);
-            double const k = (double)(kRsqrpi*repwid)*voigt_near(xi, y);           // RFM_voigt.c:278
-            unsafeAtomicAdd(&acc[f - F0], rec->amp[l]*k);                          // kernels.c:459
-        }
+        drain_near(acc, q_amp, q_xi, q_y, q_rep, q_idx, count, lane);
     };
 
-    for (uint64_t base = jbeg; base < jend; base += kChunk)
+    float const wres_f = (float)a.wres;
+
+    // Each wave takes 64 consecutive lines per round: one line per lane, per-line constants in
+    // registers.  Accumulation is a ring: 64 partial sums ("tokens"), one per grid index of a
+    // 64-point span, rotate through the 64 lanes; the lane holding a token adds its own line's
+    // value at that grid index and passes the token on.  After 64 steps every token has met every
+    // line and sits in lane (f - span start): one conflict-free ds_add_f64 per lane flushes the
+    // span into the tile.  The inner loop touches neither LDS nor atomics.
+    for (uint64_t base = jbeg + (uint64_t)wave*64; base < jend; base += kBlock)
     {
-        // ---- phase A: one line per thread -> LDS record ----
-        uint64_t const j = base + tid;
-        int rs = 1, re = 0;
+        uint64_t const j = base + lane;
+        int s = 1, lo = 1, hi = 0, c = 0;
+        double dwno = 0., wnoadj = 0., amp = 0.;
+        float repwid = 1.f, y = 0.f;
         if (j < jend)
         {
             int const slot = a.lines.slot[j];
             double const *ms = cs + a.lay.off_ms + ((uint64_t)slot*L + layer)*4;
             double const *q = cs + a.lay.off_q + ((uint64_t)slot*L + layer)*GRT_MAX_ISO;
             Prepared const p = prepare_line<FAST>(a.lines, j, lay, ms, q, a.w0, a.wres, fsteps, nw);
-            if (p.s <= p.e && p.s < F1 && p.e >= F0)
+            if (p.s <= p.e && p.s < F1l && p.e >= F0l)
             {
-                rs = (int)p.s;
-                re = (int)p.e;
-                float const repwid = (float)((double)kSqrln2/p.alpha);            // RFM_voigt.c:94
-                rec->repwid[tid] = repwid;
-                rec->y[tid] = (float)((double)repwid*p.gamma);                     // RFM_voigt.c:95
-                rec->dwno[tid] = (double)p.s*a.wres + a.w0;                        // kernels.c:438
-                rec->wnoadj[tid] = p.vnn;
-                rec->amp[tid] = p.snn*ms[2];                                       // snn*n (kernels.c:459)
+                s = (int)p.s;
+                lo = s > F0 ? s : F0;
+                hi = (int)p.e < F1 - 1 ? (int)p.e : F1 - 1;
+                c = p.c_minus_fsteps + (int)fsteps;
+                repwid = (float)((double)kSqrln2/p.alpha);                            // RFM_voigt.c:94
+                y = (float)((double)repwid*p.gamma);                                  // RFM_voigt.c:95
+                dwno = (double)p.s*a.wres + a.w0;                                     // kernels.c:438
+                wnoadj = p.vnn;
+                amp = p.snn*ms[2];                                                    // snn*n (kernels.c:459)
             }
         }
-        rec->s[tid] = rs;
-        rec->e[tid] = re;
-        __syncthreads();
-
-        // ---- phase B: lanes = consecutive window points of one line ----
-        int const nrec = (jend - base) < (uint64_t)kChunk ? (int)(jend - base) : kChunk;
-        for (int l = wave; l < nrec; l += kWaves)
+        // span of grid indices touched by this wave's 64 lines (already clipped to the tile)
+        int const fb = wave_min(lo <= hi ? lo : 0x7fffffff);
+        int const fe = wave_max(lo <= hi ? hi : (int)0x80000000);
+        if (fb > fe)
         {
-            int const s = __builtin_amdgcn_readfirstlane(rec->s[l]);
-            int const e = __builtin_amdgcn_readfirstlane(rec->e[l]);
-            if (s > e)
+            continue;
+        }
+        bool const lorentz = (y >= 70.55f);                                           // RFM_voigt.c:97
+        float const yq = y*y;
+        // XLIM0 (:109) and XLIM1 (:111-118); the reference takes these square roots in double and
+        // narrows, which the correctly rounded sqrtf reproduces exactly (53 >= 2*24 + 2 bits)
+        float const xlim0 = sqrtf(15100.0f + y*(40.0f - y*3.6f));
+        // Humlicek region 1 (XLIM1 <= |x| < XLIM0, :172-183) is a cheap rational: evaluated in line.
+        float xlim1 = (y >= 8.425f) ? 0.0f : sqrtf(164.0f - y*(4.3f + y*1.8f));
+        if (y <= 0.000001f)
+        {
+            xlim1 = xlim0;                                                            // :122-126
+        }
+        float const a0 = (float)((double)yq + 0.5);                                   // :177
+        float const d0r = a0*a0;
+        float const d2r = (float)((double)(yq + yq) - 1.0);                           // :179
+        float const xq_near = lorentz ? -1.f : xlim1*xlim1;   // |x| < XLIM1 of a Voigt line -> queue
+
+        // FAST form: x from exact integer offsets to the line's centre index plus the fp32 sub-grid
+        // offset of the centre; the far-wing value RSQRPI*REPWID*(Y*RSQRPI)/(X^2+Y^2) (:170,:278) and
+        // the pure-Lorentz value REPWID*Y/(pi(X^2+Y^2)) (:103) are the same Lorentzian.
+        float const dc = (float)(wnoadj - ((double)c*a.wres + a.w0));
+        float const cl = (repwid*y)*0.318309886f;                                     // 1/pi
+        float const c1 = (kRsqrpi*repwid)*(kRsqrpi*y);                                // region 1 scale
+        float const x0q = lorentz ? 0.f : xlim0*xlim0;
+        // reference-order form
+        float const num = repwid*y;                                                   // :103
+        float const yrrtpi = y*kRsqrpi;                                               // :108
+        double const norm = (double)(kRsqrpi*repwid);                                 // :278
+
+        // canonical fp32 x of the FAST form: x(f) = fma(float(f - c), wr, ndcr) -- a function of the
+        // integer offset to the line's centre index only, so the pre-pass and the ring agree bit
+        // for bit on which points are "inner"
+        float const wr = wres_f*repwid;
+        float const ndcr = -dc*repwid;
+
+        // ---- pre-pass: the few points of each line inside XLIM0 (Voigt lines only) ----
+        // Each lane walks the grid points around ITS OWN line centre; region 1 is evaluated in
+        // line, regions 2-4 go to the near-centre queue.  The ring below then skips exactly these
+        // points, which keeps its loop free of branches.
+        {
+            bool const voigt_line = (lo <= hi) & !lorentz;
+            int const reach = voigt_line ? (int)(xlim0/(repwid*wres_f)) + 2 : -1;
+            int const rmax = wave_max(reach);
+            for (int r = -rmax; r <= rmax; ++r)
             {
-                continue;
-            }
-            int const lo = s > (int)F0 ? s : (int)F0;
-            int const hi = e < (int)(F1 - 1) ? e : (int)(F1 - 1);
-            double const dwno = rec->dwno[l];
-            double const wnoadj = rec->wnoadj[l];
-            double const amp = rec->amp[l];
-            float const repwid = rec->repwid[l];
-            float const y = rec->y[l];
-            float const yq = y*y;
-            if (y >= 70.55f)
-            {
-                // pure Lorentz: RFM_voigt.c:97-106 (quotient in double)
-                float const num = repwid*y;
-                for (int f = lo + lane; f <= hi; f += 64)
+                int const f = c + r;
+                bool const cand = (r >= -reach) & (r <= reach) & (f >= lo) & (f <= hi);
+                float xi, xq;
+                bool inner, near;
+                if (FAST)
                 {
-                    float const xi = voigt_x(dwno, f - s, a.wres, wnoadj, repwid);
-                    double const k = (double)num/(M_PI*(double)(xi*xi + yq));
-                    unsafeAtomicAdd(&acc[f - F0], amp*k);
+                    xi = fmaf((float)r, wr, ndcr);
+                    xq = xi*xi;
+                    inner = cand & (xq < x0q);
+                    near = inner & (xq < xq_near);
                 }
-                continue;
-            }
-            float const yrrtpi = y*kRsqrpi;                                        // RFM_voigt.c:108
-            float const xlim0 = (float)sqrt((double)(15100.0f + y*(40.0f - y*3.6f)));  // :109
-            double const norm = (double)(kRsqrpi*repwid);                          // :278
-            for (int fb = lo; fb <= hi; fb += 64)
-            {
-                if (qcount > kQueue - 64)
+                else
                 {
-                    drain(qcount);
-                    qcount = 0;
-                }
-                int const f = fb + lane;
-                bool near = false;
-                if (f <= hi)
-                {
-                    float const xi = voigt_x(dwno, f - s, a.wres, wnoadj, repwid);
+                    xi = cand ? voigt_x(dwno, f - s, a.wres, wnoadj, repwid) : 0.f;
                     float const abx = fabsf(xi);
-                    if (abx >= xlim0)
+                    xq = abx*abx;
+                    inner = cand & (abx < xlim0);
+                    near = inner & (abx < xlim1);
+                }
+                if (inner & !near)
+                {
+                    // region 1: D = RSQRPI/(D0 + XQ (D2 + XQ)); K = D Y (A0 + XQ) (:181-182), then :278
+                    if (FAST)
                     {
-                        float const kf = yrrtpi/(abx*abx + yq);                    // :170
-                        unsafeAtomicAdd(&acc[f - F0], amp*(norm*(double)kf));
+                        float const k1 = c1*(a0 + xq)*__builtin_amdgcn_rcpf(fmaf(xq, d2r + xq, d0r));
+                        GRT_ACC_ADD(&acc[f - F0], amp*(double)k1);
                     }
                     else
                     {
-                        near = true;
+                        float const d = kRsqrpi/(d0r + xq*(d2r + xq));
+                        float const kf = d*y*(a0 + xq);
+                        GRT_ACC_ADD(&acc[f - F0], amp*(norm*(double)kf));
                     }
                 }
                 unsigned long long const m = __ballot(near);
                 if (m != 0ull)
                 {
+                    if (qcount > kQueue - 64)
+                    {
+                        drain(qcount);
+                        qcount = 0;
+                    }
                     if (near)
                     {
                         int const pos = qcount + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
                                         __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                        myq_slot[pos] = l;
-                        myq_point[pos] = f;
+                        q_amp[pos] = amp;
+                        q_xi[pos] = voigt_x(dwno, f - s, a.wres, wnoadj, repwid);
+                        q_y[pos] = y;
+                        q_rep[pos] = repwid;
+                        q_idx[pos] = f - F0;
                     }
                     qcount += __popcll(m);
                 }
             }
         }
-        drain(qcount);
-        qcount = 0;
-        __syncthreads();
+
+        // ---- ring: every remaining point (far wing of Voigt lines, all of the Lorentz lines) ----
+        for (int fbp = fb; fbp <= fe; fbp += 64)
+        {
+            double token = 0.;
+            int slot = lane;                        // (lane + t) & 63
+            if (FAST)
+            {
+                float const base_rel = (float)(fbp - c);
+                // in-window test on the offset to the centre index: |rel - mid| <= half
+                float const mid = 0.5f*(float)(lo + hi) - (float)c;
+                float const half = lo <= hi ? 0.5f*(float)(hi - lo) + 0.25f : -1.f;
+#pragma unroll 4
+                for (int t = 0; t < 64; ++t)
+                {
+                    float const rel = base_rel + (float)slot;
+                    float const xi = fmaf(rel, wr, ndcr);
+                    float const xq = xi*xi;
+                    bool const keep = (fabsf(rel - mid) <= half) & (xq >= x0q);
+                    float kf = keep ? cl*__builtin_amdgcn_rcpf(xq + yq) : 0.f;
+                    asm volatile("" : "+v"(kf));    // select in fp32, then widen once
+                    token = fma(amp, (double)kf, token);
+                    token = ring_pass(token);
+                    slot = (slot + 1) & 63;
+                }
+            }
+            else
+            {
+#pragma unroll 2
+                for (int t = 0; t < 64; ++t)
+                {
+                    int const f = fbp + slot;
+                    if ((f >= lo) & (f <= hi))
+                    {
+                        float const xi = voigt_x(dwno, f - s, a.wres, wnoadj, repwid);
+                        float const abx = fabsf(xi);
+                        float const xq = abx*abx;
+                        if (lorentz)
+                        {
+                            // pure Lorentz: RFM_voigt.c:97-106 (quotient in double)
+                            token += amp*((double)num/(M_PI*(double)(xq + yq)));
+                        }
+                        else if (abx >= xlim0)
+                        {
+                            float const kf = yrrtpi/(xq + yq);                    // :170
+                            token += amp*(norm*(double)kf);
+                        }
+                    }
+                    token = ring_pass(token);
+                    slot = (slot + 1) & 63;
+                }
+            }
+            int const f = fbp + lane;
+            if (f <= fe)
+            {
+                GRT_ACC_ADD(&acc[f - F0], token);
+            }
+        }
     }
+    drain(qcount);
+    __syncthreads();
 
     // ---- epilogue: fold in continua / CFC / CIA and write the tile once ----
     bool const add_tables = (slice == 0);
     double const *cont = cs + a.lay.off_cont + (uint64_t)layer*GRT_MAX_TABLES;
     double const *h2o = cs + a.lay.off_h2o + (uint64_t)layer*4;
     double *out = a.tau + (uint64_t)col*a.tau_col_stride + (uint64_t)layer*a.nw;
-    for (long long f = F0 + tid; f < F1; f += kBlock)
+    for (long long f = F0l + tid; f < F1l; f += kBlock)
     {
-        double v = acc[f - F0];
+        double v = acc[f - F0l];
         if (add_tables)
         {
             if (a.lay.has_h2o_ctm)
@@ -480,7 +652,7 @@ __global__ __launch_bounds__(kBlock) void line_prep_kernel(GrtGasOpticsArgs a, l
 
 size_t gas_optics_lds_bytes(int tile)
 {
-    return sizeof(double)*tile + sizeof(LineRecords) + sizeof(int)*2*kWaves*kQueue + 2*sizeof(long long);
+    return sizeof(double)*tile + sizeof(NearQueue) + 2*sizeof(long long);
 }
 
 } // namespace
