@@ -109,7 +109,8 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cols", type=int, default=int(os.environ.get("GRT_BENCH_COLS", 8)), help="columns per GPU per step")
-    ap.add_argument("--fast", type=int, default=int(os.environ.get("GRT_BENCH_FAST", 0)))
+    ap.add_argument("--fast", type=int, default=int(os.environ.get("GRT_BENCH_FAST", 1)),
+                    help="1: fused arithmetic form of the line kernel (production); 0: reference operation order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lw-lines", type=int, default=None)
     ap.add_argument("--sw-lines", type=int, default=None)
@@ -129,7 +130,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from grtcode_amd import api, workload as W
+    from grtcode_amd import api, multi, workload as W
 
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -138,7 +139,8 @@ def main():
     device = api.create_device(local_rank)
     wl = W.G1Workload(device, args.cols, lw_lines=args.lw_lines or W.LW_LINES,
                       sw_lines=args.sw_lines or W.SW_LINES, fast=args.fast)
-    (gcols, keep), _ = wl.columns(rank * args.cols, args.cols)
+    first, count = multi.shard(world * args.cols, rank, world)      # weak scaling: args.cols columns per rank
+    (gcols, keep), _ = wl.columns(first, count)
     out = torch.zeros(args.cols, api.GRT_FLUXES_PER_COLUMN, dtype=torch.float64, device="cuda")
     gathered = [torch.zeros_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
     stream = torch.cuda.ExternalStream(wl.pipe.stream(), device=torch.device("cuda", local_rank))
@@ -147,7 +149,7 @@ def main():
         wl.pipe.run(gcols, out.data_ptr())
         if world > 1:
             with torch.cuda.stream(stream):      # RCCL gather ordered after the kernels, no host sync
-                dist.gather(out, gathered, dst=0)
+                multi.gather_fluxes(out, rank, world, gathered)
 
     def barrier():
         wl.pipe.sync()
@@ -164,10 +166,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = multi.max_over_ranks(elapsed, torch.device("cuda", local_rank))
 
     if rank == 0:
         fluxes = out.cpu().numpy()
@@ -185,6 +184,15 @@ def main():
         fsteps = 25
         points = lambda nlines: float(L) * nlines * (2 * fsteps + 1) * args.cols      # Voigt evaluations per launch
         valu_flop = 12.0 * points(S["sw"])                                            # ~12 flop far-wing point
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("cols") == args.cols and tj.get("fast") == args.fast:
+                    traffic = tj["gas_optics_sw"]["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
         total_cols = world * args.cols * args.steps
         line = {
             "metric": "columns/sec (60-layer, 1 cm-1 LBL, LW+SW)", "value": total_cols / elapsed, "unit": "columns/s",
@@ -197,7 +205,7 @@ def main():
                        "parallelism": f"columns sharded over {world} GPU(s), RCCL gather of 12 fluxes/column"},
             "roofline": {"kernel": "gas_optics_kernel (line-by-line tau), SW-band launch", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "avg_launch_ms": dom_ms, "launches": ms[2][1],
+                         "traffic": traffic, "avg_launch_ms": dom_ms, "launches": ms[2][1],
                          "note": "this kernel is FP32/FP64-VALU bound by construction (L*S*F Voigt evaluations), see roofline_valu"},
             "roofline_valu": {"kernel": "gas_optics_kernel, SW-band launch", "bound": "valu_fp32",
                               "achieved": valu_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0,

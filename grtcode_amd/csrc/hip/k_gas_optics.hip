@@ -299,9 +299,9 @@ struct NearQueue
 };
 
 // Evaluate queued near-centre points with all lanes busy (Humlicek regions 1-4) and add them
-// to the tile.  Kept out of line: it is cold code, and inlining it into every unrolled ring step
-// would push the hot loop out of the instruction cache.
-__device__ __noinline__ void drain_near(double *acc, double const *q_amp, float const *q_xi,
+// to the tile.  Only the pre-pass and the kernel tail call it (never the ring loop), so it is
+// inlined: an out-of-line call costs scratch traffic for the call ABI on every drain.
+__device__ __forceinline__ void drain_near(double *acc, double const *q_amp, float const *q_xi,
                                         float const *q_y, float const *q_rep, int const *q_idx,
                                         int count, int lane)
 {
@@ -312,10 +312,12 @@ __device__ __noinline__ void drain_near(double *acc, double const *q_amp, float 
     }
 }
 
-// waves_per_eu(4): cap at 128 VGPRs so four workgroups share a CU; measured +7 % over the
-// compiler's default 137 VGPRs / 3 waves per SIMD (f32 VALU issue 3.0 vs 3.3 cycles per wave64 op)
+// Register budget: the fused form needs 128 VGPRs (4 waves per SIMD), the reference-order form
+// 146 (3 waves per SIMD); neither spills.  (Forcing 128 on the reference-order form costs 72 B/lane
+// of scratch, which showed up as ~1.4 GB of extra WRITE_SIZE per shortwave launch.)
 template <bool FAST>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) void gas_optics_kernel(GrtGasOpticsArgs a, long long fsteps)
+__global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, long long fsteps, unsigned ngroups,
+                                                                                          unsigned perm_stride)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *acc = reinterpret_cast<double *>(smem);                               // [tile]
@@ -325,10 +327,23 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
     int const tid = threadIdx.x;
     int const lane = tid & 63;
     int const wave = tid >> 6;
-    int const tile_idx = blockIdx.x/a.nslice;
-    int const slice = blockIdx.x - tile_idx*a.nslice;
-    int const layer = blockIdx.y;
-    int const col = blockIdx.z;
+    // XCD-aware work order.  Workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share
+    // one), and all (layer, column) workgroups of one (tile, line slice) "group" read the SAME slice
+    // of the line list.  Every XCD gets an equal, contiguous share of the work items, ordered group
+    // by group with layer/column varying fastest, so the ~10^2 workgroups resident on an XCD share
+    // one or two line slices (~1 MB) that live in its 4 MB L2 instead of being re-fetched over the
+    // fabric (FETCH_SIZE 17 GB -> 0.06 GB per shortwave launch).  Groups are visited in a
+    // golden-ratio stride permutation so that each XCD's share mixes cheap and expensive spectral
+    // regions (high-wavenumber tiles carry more near-centre work).  Placement affects speed only.
+    unsigned const nb = gridDim.x, xcd = blockIdx.x & 7u, q8 = nb >> 3, r8 = nb & 7u;
+    unsigned const work = (xcd < r8 ? xcd*(q8 + 1u) : r8*(q8 + 1u) + (xcd - r8)*q8) + (blockIdx.x >> 3);
+    unsigned const per_group = (unsigned)a.lay.num_layers*(unsigned)a.ncol;
+    unsigned const pos = work/per_group, rem = work - pos*per_group;
+    unsigned const group = (unsigned)(((unsigned long long)pos*perm_stride) % ngroups);
+    int const col = (int)(rem/(unsigned)a.lay.num_layers);
+    int const layer = (int)(rem - (unsigned)col*(unsigned)a.lay.num_layers);
+    int const tile_idx = (int)(group/(unsigned)a.nslice);
+    int const slice = (int)(group - (unsigned)tile_idx*(unsigned)a.nslice);
     long long const nw = (long long)a.nw;
     long long const F0l = (long long)tile_idx*a.tile;
     long long const F1l = (F0l + a.tile < nw) ? F0l + a.tile : nw;                // [F0,F1)
@@ -590,11 +605,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
     __syncthreads();
 
     // ---- epilogue: fold in continua / CFC / CIA and write the tile once ----
+    // Two consecutive grid points per lane: one 16-byte store per lane (1 KiB per wave instruction)
+    // whenever the row start is 16-byte aligned, which also is the store shape WRITE_SIZE is
+    // calibrated for on gfx950.
     bool const add_tables = (slice == 0);
     double const *cont = cs + a.lay.off_cont + (uint64_t)layer*GRT_MAX_TABLES;
     double const *h2o = cs + a.lay.off_h2o + (uint64_t)layer*4;
     double *out = a.tau + (uint64_t)col*a.tau_col_stride + (uint64_t)layer*a.nw;
-    for (long long f = F0l + tid; f < F1l; f += kBlock)
+    bool const pair_ok = (a.nslice == 1) && ((reinterpret_cast<uintptr_t>(out + F0l) & 15u) == 0);
+    auto finish = [&](long long f) -> double
     {
         double v = acc[f - F0l];
         if (add_tables)
@@ -612,13 +631,26 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) 
                 v += cont[k]*a.tables[(uint64_t)k*a.nw + f];
             }
         }
-        if (a.nslice == 1)
+        return v;
+    };
+    for (long long f = F0l + 2*tid; f < F1l; f += 2*kBlock)
+    {
+        double const v0 = finish(f);
+        bool const has1 = f + 1 < F1l;
+        double const v1 = has1 ? finish(f + 1) : 0.;
+        if (pair_ok && has1)
         {
-            out[f] = v;
+            *reinterpret_cast<double2 *>(out + f) = make_double2(v0, v1);
+        }
+        else if (a.nslice == 1)
+        {
+            out[f] = v0;
+            if (has1) out[f + 1] = v1;
         }
         else
         {
-            unsafeAtomicAdd(&out[f], v);
+            unsafeAtomicAdd(&out[f], v0);
+            if (has1) unsafeAtomicAdd(&out[f + 1], v1);
         }
     }
 }
@@ -668,17 +700,32 @@ extern "C" int grt_launch_gas_optics(void *stream, GrtGasOpticsArgs const *a)
     {
         return (int)hipErrorInvalidValue;
     }
-    unsigned const tiles = (unsigned)((a->nw + a->tile - 1)/a->tile);
-    dim3 const grid(tiles*a->nslice, a->lay.num_layers, a->ncol);
+    unsigned long long const tiles = (a->nw + a->tile - 1)/a->tile;
+    unsigned long long const ngroups = tiles*a->nslice;
+    unsigned long long const blocks = ngroups*a->lay.num_layers*a->ncol;
+    if (blocks == 0 || blocks > 0x7fffffffull)
+    {
+        return (int)hipErrorInvalidValue;
+    }
+    dim3 const grid((unsigned)blocks, 1, 1);
+    // stride of the group permutation: nearest integer to ngroups/phi^2 that is coprime with ngroups
+    unsigned stride = (unsigned)((double)ngroups*0.3819660112501051);
+    if (stride < 1) stride = 1;
+    for (;; ++stride)
+    {
+        unsigned x = stride, y = (unsigned)ngroups;
+        while (y != 0) { unsigned const t = x % y; x = y; y = t; }
+        if (x == 1) break;
+    }
     size_t const lds = gas_optics_lds_bytes(a->tile);
     hipStream_t const s = (hipStream_t)stream;
     if (a->fast)
     {
-        hipLaunchKernelGGL(gas_optics_kernel<true>, grid, dim3(kBlock), lds, s, *a, fsteps);
+        hipLaunchKernelGGL(gas_optics_kernel<true>, grid, dim3(kBlock), lds, s, *a, fsteps, (unsigned)ngroups, stride);
     }
     else
     {
-        hipLaunchKernelGGL(gas_optics_kernel<false>, grid, dim3(kBlock), lds, s, *a, fsteps);
+        hipLaunchKernelGGL(gas_optics_kernel<false>, grid, dim3(kBlock), lds, s, *a, fsteps, (unsigned)ngroups, stride);
     }
     return (int)hipGetLastError();
 }

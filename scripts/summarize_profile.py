@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof_<tag>/ (written by scripts/profile_round.sh on the GPU box) into the small,
+tracked summaries under profiles/: kernel stats, HBM-side traffic per launch (FETCH_SIZE doubled as
+MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as is, both in KiB units), SQ counters.
+
+    python scripts/summarize_profile.py r1
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def short(name):
+    for k in ("gas_optics_kernel", "sw_kernel", "lw_kernel", "clear_sky_kernel", "integrate_rows_kernel",
+              "fillBufferAligned", "copyBuffer"):
+        if k in name:
+            return k
+    return name[:40]
+
+
+stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0]
+shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+bench = json.load(open(os.path.join(src, "bench_under_trace.json")))
+
+# per-launch averages by (kernel, grid) from the kernel trace
+trace = glob.glob(os.path.join(src, "trace", "*", "*kernel_trace.csv"))[0]
+dur = collections.defaultdict(list)
+for r in csv.DictReader(open(trace)):
+    dur[(short(r["Kernel_Name"]), r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size", ""))].append(
+        (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+
+
+def counters(sub, names):
+    f = glob.glob(os.path.join(src, sub, "*", "*counter_collection.csv"))
+    out = collections.defaultdict(lambda: collections.defaultdict(list))
+    if not f:
+        return out
+    for r in csv.DictReader(open(f[0])):
+        if r["Counter_Name"] in names:
+            out[(short(r["Kernel_Name"]), r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return out
+
+
+fetch = counters("pmc_fetch", {"FETCH_SIZE"})
+write = counters("pmc_write", {"WRITE_SIZE"})
+sq = counters("pmc_sq", {"SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY",
+                         "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES"})
+summary = {"tag": tag, "command": "python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline",
+           "bench_line_under_trace": {k: bench[k] for k in ("value", "ms_per_step", "kernel_ms_per_step", "config")},
+           "kernels": {}}
+mean = lambda v: sum(v) / len(v)
+for key in sorted(set(fetch) | set(write)):
+    name, grid = key
+    f = mean(fetch[key]["FETCH_SIZE"]) if key in fetch else None
+    w = mean(write[key]["WRITE_SIZE"]) if key in write else None
+    entry = {"grid_threads": int(grid), "launches_seen": len(fetch[key]["FETCH_SIZE"]) if key in fetch else None,
+             "FETCH_SIZE_KiB_per_launch": f, "WRITE_SIZE_KiB_per_launch": w,
+             "hbm_bytes_per_launch": (2.0 * (f or 0.0) + (w or 0.0)) * 1024.0,
+             "note": "FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B); WRITE_SIZE checked against the "
+                     "memset/solver kernels' known byte counts in this run"}
+    if key in sq:
+        entry["sq"] = {c: mean(v) for c, v in sq[key].items()}
+    summary["kernels"][f"{name}@{grid}"] = entry
+json.dump(summary, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
+
+# what bench.py reads back into roofline.traffic (dominant kernel = SW-band launch = largest grid)
+gas = {k: v for k, v in summary["kernels"].items() if k.startswith("gas_optics_kernel")}
+if gas:
+    sw_key = max(gas, key=lambda k: gas[k]["grid_threads"])
+    lw_key = min(gas, key=lambda k: gas[k]["grid_threads"])
+    cfg = bench["config"]
+    json.dump({"tag": tag, "cols": cfg["columns_per_gpu_per_step"], "fast": 1 if cfg["arithmetic"] == "fast" else 0,
+               "gas_optics_sw": gas[sw_key], "gas_optics_lw": gas[lw_key]},
+              open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
+print(json.dumps(summary, indent=1)[:1800])

@@ -104,3 +104,32 @@ def test_pipeline_properties_full_width_band(tmp_path, lib, device):
     t_b2 = tau_for([syn.CH4], scale=2.0)
     assert np.max(np.abs(t_b2 - 2.0 * t_b) / t_b.max(axis=1, keepdims=True)) < 1e-4
     assert np.all(t_all >= 0) and np.all(np.isfinite(t_all))
+
+
+def test_pipeline_fast_form_fluxes_within_north_star_tolerance(bands, oracle, lib, device):
+    """The production (fused) arithmetic form: integrated fluxes within 1e-3 W m-2 of the oracle
+    (BASELINE.json north_star) -- in practice ~1e-6 -- and spectral tau within 2e-6 of the layer maximum."""
+    lwb, swb = bands
+    V, ncol = 16, 2
+    cols = [syn.profile(40 + c, V) for c in range(ncol)]
+    go_lw, grid_lw = lwb.gas_optics(device, V)
+    go_sw, grid_sw = swb.gas_optics(device, V)
+    go_lw.tune(fast=1)
+    go_sw.tune(fast=1)
+    emis, alb = np.full(lwb.nw, 0.98), np.full(swb.nw, 0.2)
+    solar = api.create_solar_flux(grid_sw, swb.files["solar"])
+    pipe = api.Pipeline(go_lw, go_sw, ncol, -1, emis, alb, solar)
+    gcols, keep = api.make_columns(cols, MOL_ORDER, cfc_order=(0, 1))
+    pipe.run(gcols)
+    got = pipe.fluxes(ncol)
+    for bi, (band, lw) in enumerate(((lwb, True), (swb, False))):
+        tau_gas = api.device_to_host(device, pipe.views(bi)["tau_gas"], (ncol, V - 1, band.nw))
+        for c, col in enumerate(cols):
+            w = oracle_column(oracle, lib, band, col, lw, emis, alb, solar)
+            scale = np.abs(w["tau_gas"]).max(axis=1, keepdims=True)
+            assert np.max(np.abs(tau_gas[c] - w["tau_gas"]) / scale) < 2e-6
+            assert np.max(np.abs(got[c, bi * 6: bi * 6 + 6] - w["integ"])) < FLUX_TOL
+            assert got[c, bi * 6 + 2] == 0.0 and got[c, bi * 6 + 5] == 0.0      # no user level requested
+    pipe.destroy()
+    go_lw.destroy()
+    go_sw.destroy()
