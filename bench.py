@@ -133,7 +133,9 @@ def main():
     from grtcode_amd import api, multi, workload as W
 
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # GRT_BENCH_FORCE_DIST=1 exercises the RCCL path (init, stream-ordered gather, max-reduce) at world size 1
+    force_dist = os.environ.get("GRT_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     device = api.create_device(local_rank)
@@ -142,19 +144,23 @@ def main():
     first, count = multi.shard(world * args.cols, rank, world)      # weak scaling: args.cols columns per rank
     (gcols, keep), _ = wl.columns(first, count)
     out = torch.zeros(args.cols, api.GRT_FLUXES_PER_COLUMN, dtype=torch.float64, device="cuda")
-    gathered = [torch.zeros_like(out) for _ in range(world)] if (world > 1 and rank == 0) else None
+    use_dist = world > 1 or force_dist
+    gathered = [torch.zeros_like(out) for _ in range(world)] if (use_dist and rank == 0) else None
     stream = torch.cuda.ExternalStream(wl.pipe.stream(), device=torch.device("cuda", local_rank))
 
     def step():
         wl.pipe.run(gcols, out.data_ptr())
-        if world > 1:
+        if use_dist:
             with torch.cuda.stream(stream):      # RCCL gather ordered after the kernels, no host sync
-                multi.gather_fluxes(out, rank, world, gathered)
+                if world > 1:
+                    multi.gather_fluxes(out, rank, world, gathered)
+                else:
+                    dist.gather(out, gathered, dst=0)
 
     def barrier():
         wl.pipe.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -226,7 +232,7 @@ def main():
         print(json.dumps(line), flush=True)
         os.dup2(2, 1)
     wl.destroy()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

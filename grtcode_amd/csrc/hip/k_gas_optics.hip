@@ -63,6 +63,23 @@ constexpr int kQueue = 128;     // near-centre queue entries per wave: drained a
 constexpr float kRsqrpi = 0.56418958f;
 constexpr float kSqrln2 = 0.832554611f;
 
+// One line of the merged store, as loaded from HBM (37 bytes).
+struct RawLine
+{
+    double v0, s0;
+    float yair, yself, en, nexp, delta;
+    int iso, slot;
+};
+
+__device__ __forceinline__ RawLine load_line(GrtLineStore const &ls, uint64_t j)
+{
+    RawLine r;
+    r.v0 = ls.v0[j]; r.s0 = ls.s0[j];
+    r.yair = ls.yair[j]; r.yself = ls.yself[j]; r.en = ls.en[j]; r.nexp = ls.nexp[j]; r.delta = ls.delta[j];
+    r.iso = ls.iso[j]; r.slot = ls.slot[j];
+    return r;
+}
+
 struct Prepared
 {
     double vnn, snn, gamma, alpha;
@@ -84,39 +101,48 @@ __device__ __forceinline__ double exp_fast(double x)
 // kernels.c:34-131 for one (layer, line) + the window of kernels.c:431-437.
 // lay: pavg, tavg, 1/tavg, log(296/tavg); ms: ps, pavg-ps, ns, doppler factor.
 template <bool FAST>
-__device__ __forceinline__ Prepared prepare_line(GrtLineStore const &ls, uint64_t j,
+__device__ __forceinline__ Prepared prepare_line(RawLine const &ln,
                                                  double const *lay, double const *ms,
                                                  double const *q, double w0, double wres,
-                                                 long long fsteps, long long nw)
+                                                 double inv_wres, long long fsteps, long long nw)
 {
     double const c2 = -1.4387686f;           // kernels.c:75
     double const tref = 296.f;               // kernels.c:97
     double const sqrt_ln2 = 0.83255461115f;  // kernels.c:117
     double const pavg = lay[0], T = lay[1];
     double const ps = ms[0], pf = ms[1], dop = ms[3];
-    double const v0 = ls.v0[j];
-    double const en = ls.en[j], nexp = ls.nexp[j];
-    double const yair = ls.yair[j], yself = ls.yself[j], delta = ls.delta[j];
+    double const v0 = ln.v0;
+    double const en = ln.en, nexp = ln.nexp;
+    double const yair = ln.yair, yself = ln.yself, delta = ln.delta;
     Prepared p;
     p.vnn = v0 + delta*pavg;                                         // kernels.c:44
     if (FAST)
     {
         double const invT = lay[2];
-        p.snn = ls.s0[j]*exp_fast((c2*en)*invT)*(1.0 - exp_fast((c2*v0)*invT))*q[ls.iso[j] - 1];
+        p.snn = ln.s0*exp_fast((c2*en)*invT)*(1.0 - exp_fast((c2*v0)*invT))*q[ln.iso - 1];
         p.gamma = exp_fast(nexp*lay[3])*fma(yair, pf, yself*ps);
     }
     else
     {
 #if defined(GRT_EXP_NOPREP)
-        p.snn = ls.s0[j]*(c2*en/T)*(1.f - (c2*v0/T))*q[ls.iso[j] - 1];
+        p.snn = ln.s0*(c2*en/T)*(1.f - (c2*v0/T))*q[ln.iso - 1];
         p.gamma = (tref/T + nexp)*(yair*pf + yself*ps);
 #else
-        p.snn = ls.s0[j]*exp(c2*en/T)*(1.f - exp(c2*v0/T))*q[ls.iso[j] - 1];   // kernels.c:83-85
+        p.snn = ln.s0*exp(c2*en/T)*(1.f - exp(c2*v0/T))*q[ln.iso - 1];   // kernels.c:83-85
         p.gamma = pow(tref/T, nexp)*(yair*pf + yself*ps);                  // kernels.c:105-106
 #endif
     }
     p.alpha = sqrt_ln2*p.vnn*dop;                                    // kernels.c:127
-    double const fc = floor((2*((p.vnn - w0)/wres) + 1)/2);          // kernels.c:431-432
+    // kernels.c:431-432: fcenterid = floor((2*((vnn - w0)/wres) + 1)/2), bit-exact.  The quotient is
+    // first formed with the reciprocal (error <= 2 ulp); floor() of the two can only differ when the
+    // argument sits within a few ulp of an integer, in which case the true division is used.
+    double const dv = p.vnn - w0;
+    double u = (2*(dv*inv_wres) + 1)/2;
+    if (fabs(u - rint(u)) <= 4e-15*fmax(1., fabs(u)))
+    {
+        u = (2*(dv/wres) + 1)/2;
+    }
+    double const fc = floor(u);
     p.s = 1;
     p.e = 0;
     p.c_minus_fsteps = 0;
@@ -134,6 +160,14 @@ __device__ __forceinline__ Prepared prepare_line(GrtLineStore const &ls, uint64_
 // callers).  Returns K before the final RSQRPI*REPWID scaling (:278).  The region
 // coefficients depend on y only; the reference caches them per line, we evaluate them
 // per queued point (the queue is dense, see file header).
+template <bool FAST>
+__device__ __forceinline__ float quot(float a, float b)
+{
+    // reference-order form: IEEE division; fused form: a * v_rcp_f32(b) (1 ulp)
+    return FAST ? a*__builtin_amdgcn_rcpf(b) : a/b;
+}
+
+template <bool FAST>
 __device__ __forceinline__ double voigt_near(float xi, float y)
 {
     float const yq = y*y;
@@ -155,7 +189,7 @@ __device__ __forceinline__ double voigt_near(float xi, float y)
         float const a0 = (float)((double)yq + 0.5);
         float const d0 = a0*a0;
         float const d2 = (float)((double)(yq + yq) - 1.0);
-        float const d = kRsqrpi/(d0 + xq*(d2 + xq));
+        float const d = quot<FAST>(kRsqrpi, d0 + xq*(d2 + xq));
         return (double)(d*y*(a0 + xq));
     }
     if (abx >= xlim2)
@@ -167,7 +201,7 @@ __device__ __forceinline__ double voigt_near(float xi, float y)
         float const e0 = 1.875f + yq*(8.25f + yq*(5.5f + yq));
         float const e2 = 5.25f + yq*(1.0f + yq*3.0f);
         float const e4 = 0.75f*h6;
-        float const d = kRsqrpi/(h0 + xq*(h2 + xq*(h4 + xq*(h6 + xq))));
+        float const d = quot<FAST>(kRsqrpi, h0 + xq*(h2 + xq*(h4 + xq*(h6 + xq))));
         return (double)(d*y*(e0 + xq*(e2 + xq*(e4 + xq))));
     }
     if (abx < xlim3)
@@ -193,7 +227,7 @@ __device__ __forceinline__ double voigt_near(float xi, float y)
                          + y*(12.79568f + y*1.9099744f))));
         float const p6 = -0.07272979f + y*(0.9377051f + y*(4.266322f + y*1.273316f));
         float const p8 = 0.0005480304f + y*0.3183291f;
-        float const d = 1.7724538f/(z0 + xq*(z2 + xq*(z4 + xq*(z6 + xq*(z8 + xq)))));
+        float const d = quot<FAST>(1.7724538f, z0 + xq*(z2 + xq*(z4 + xq*(z6 + xq*(z8 + xq)))));
         return (double)(d*(p0 + xq*(p2 + xq*(p4 + xq*(p6 + xq*p8)))));
     }
     // region 4: six-term rational sums, accumulated in double like the reference's
@@ -214,10 +248,10 @@ __device__ __forceinline__ double voigt_near(float xi, float y)
         for (int J = 0; J < 6; ++J)
         {
             float dm = xi - T[J];
-            float const mf = 1.0f/(dm*dm + ypy0q);
+            float const mf = quot<FAST>(1.0f, dm*dm + ypy0q);
             float const xm = mf*dm, ym = mf*ypy0;
             float dp = xi + T[J];
-            float const pf = 1.0f/(dp*dp + ypy0q);
+            float const pf = quot<FAST>(1.0f, dp*dp + ypy0q);
             float const xp = pf*dp, yp = pf*ypy0;
             k = k + (double)(C[J]*(ym + yp)) - (double)(S[J]*(xm - xp));
         }
@@ -230,14 +264,14 @@ __device__ __forceinline__ double voigt_near(float xi, float y)
         {
             float dm = xi - T[J];
             float const mq = dm*dm;
-            float const mf = 1.0f/(mq + ypy0q);
+            float const mf = quot<FAST>(1.0f, mq + ypy0q);
             float const xm = mf*dm, ym = mf*ypy0;
             float dp = xi + T[J];
             float const pq = dp*dp;
-            float const pf = 1.0f/(pq + ypy0q);
+            float const pf = quot<FAST>(1.0f, pq + ypy0q);
             float const xp = pf*dp, yp = pf*ypy0;
-            k = k + (double)((C[J]*(mq*mf - y0*ym) + S[J]*yf*xm)/(mq + y0q))
-                  + (double)((C[J]*(pq*pf - y0*yp) - S[J]*yf*xp)/(pq + y0q));
+            k = k + (double)quot<FAST>(C[J]*(mq*mf - y0*ym) + S[J]*yf*xm, mq + y0q)
+                  + (double)quot<FAST>(C[J]*(pq*pf - y0*yp) - S[J]*yf*xp, pq + y0q);
         }
         k = (double)y*k + exp((double)(-xq));
     }
@@ -283,8 +317,14 @@ __device__ __forceinline__ double ring_pass(double v)
     // v_mov_b32_dpp wave_rol:1 (DPP control 0x134): lane l <- lane l+1, lane 63 <- lane 0;
     // register-file latency, no LDS crossbar trip (direction verified on gfx950 hardware)
     int lo = __double2loint(v), hi = __double2hiint(v);
+#if defined(GRT_RING_BPERMUTE)
+    int const src = ((threadIdx.x + 1) & 63) << 2;
+    lo = __builtin_amdgcn_ds_bpermute(src, lo);
+    hi = __builtin_amdgcn_ds_bpermute(src, hi);
+#else
     lo = __builtin_amdgcn_update_dpp(lo, lo, 0x134, 0xf, 0xf, true);
     hi = __builtin_amdgcn_update_dpp(hi, hi, 0x134, 0xf, 0xf, true);
+#endif
     return __hiloint2double(hi, lo);
 }
 
@@ -295,20 +335,22 @@ struct NearQueue
     float xi[kWaves][kQueue];
     float y[kWaves][kQueue];
     float repwid[kWaves][kQueue];
+    float far[kWaves][kQueue];      // what the ring adds for this point (fused form), to be taken back
     int idx[kWaves][kQueue];        // accumulator index f - F0
 };
 
 // Evaluate queued near-centre points with all lanes busy (Humlicek regions 1-4) and add them
 // to the tile.  Only the pre-pass and the kernel tail call it (never the ring loop), so it is
 // inlined: an out-of-line call costs scratch traffic for the call ABI on every drain.
+template <bool FAST>
 __device__ __forceinline__ void drain_near(double *acc, double const *q_amp, float const *q_xi,
-                                        float const *q_y, float const *q_rep, int const *q_idx,
-                                        int count, int lane)
+                                        float const *q_y, float const *q_rep, float const *q_far,
+                                        int const *q_idx, int count, int lane)
 {
     for (int i = lane; i < count; i += 64)
     {
-        double const k = (double)(kRsqrpi*q_rep[i])*voigt_near(q_xi[i], q_y[i]);   // RFM_voigt.c:278
-        GRT_ACC_ADD(&acc[q_idx[i]], q_amp[i]*k);                                   // kernels.c:459
+        double const k = (double)(kRsqrpi*q_rep[i])*voigt_near<FAST>(q_xi[i], q_y[i]) - q_far[i];   // RFM_voigt.c:278
+        GRT_ACC_ADD(&acc[q_idx[i]], q_amp[i]*k);                                                   // kernels.c:459
     }
 }
 
@@ -323,6 +365,10 @@ __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, 
     double *acc = reinterpret_cast<double *>(smem);                               // [tile]
     NearQueue *nq = reinterpret_cast<NearQueue *>(smem + sizeof(double)*a.tile);
     long long *range = reinterpret_cast<long long *>(nq + 1);                     // [2]
+    // this layer's slice of the column state: [slot][4] means + [slot][GRT_MAX_ISO] 1/Q, staged once
+    // so that the per-line set-up never chases pointers through global memory
+    double *ms_l = reinterpret_cast<double *>(range + 2);                         // [num_slots][4]
+    double *q_l = ms_l + 4*GRT_MAX_SLOTS;                                         // [num_slots][GRT_MAX_ISO]
 
     int const tid = threadIdx.x;
     int const lane = tid & 63;
@@ -357,6 +403,14 @@ __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, 
     for (int i = tid; i < a.tile; i += kBlock)
     {
         acc[i] = 0.0;
+    }
+    for (int i = tid; i < a.lay.num_slots*4; i += kBlock)
+    {
+        ms_l[i] = cs[a.lay.off_ms + ((uint64_t)(i >> 2)*L + layer)*4 + (i & 3)];
+    }
+    for (int i = tid; i < a.lay.num_slots*GRT_MAX_ISO; i += kBlock)
+    {
+        q_l[i] = cs[a.lay.off_q + ((uint64_t)(i/GRT_MAX_ISO)*L + layer)*GRT_MAX_ISO + (i % GRT_MAX_ISO)];
     }
 
     // Candidate line range: every line whose centre index can fall within
@@ -394,15 +448,16 @@ __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, 
 
     int qcount = 0;                      // wave-uniform
     double *q_amp = nq->amp[wave];
-    float *q_xi = nq->xi[wave], *q_y = nq->y[wave], *q_rep = nq->repwid[wave];
+    float *q_xi = nq->xi[wave], *q_y = nq->y[wave], *q_rep = nq->repwid[wave], *q_far = nq->far[wave];
     int *q_idx = nq->idx[wave];
 
     auto drain = [&](int count)
     {
-        drain_near(acc, q_amp, q_xi, q_y, q_rep, q_idx, count, lane);
+        drain_near<FAST>(acc, q_amp, q_xi, q_y, q_rep, q_far, q_idx, count, lane);
     };
 
     float const wres_f = (float)a.wres;
+    double const inv_wres = 1./a.wres;
 
     // Each wave takes 64 consecutive lines per round: one line per lane, per-line constants in
     // registers.  Accumulation is a ring: 64 partial sums ("tokens"), one per grid index of a
@@ -413,22 +468,27 @@ __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, 
     for (uint64_t base = jbeg + (uint64_t)wave*64; base < jend; base += kBlock)
     {
         uint64_t const j = base + lane;
+        RawLine ln = {};
+        if (j < jend)
+        {
+            ln = load_line(a.lines, j);
+        }
         int s = 1, lo = 1, hi = 0, c = 0;
         double dwno = 0., wnoadj = 0., amp = 0.;
         float repwid = 1.f, y = 0.f;
         if (j < jend)
         {
-            int const slot = a.lines.slot[j];
-            double const *ms = cs + a.lay.off_ms + ((uint64_t)slot*L + layer)*4;
-            double const *q = cs + a.lay.off_q + ((uint64_t)slot*L + layer)*GRT_MAX_ISO;
-            Prepared const p = prepare_line<FAST>(a.lines, j, lay, ms, q, a.w0, a.wres, fsteps, nw);
+            double const *ms = ms_l + ln.slot*4;
+            double const *q = q_l + ln.slot*GRT_MAX_ISO;
+            Prepared const p = prepare_line<FAST>(ln, lay, ms, q, a.w0, a.wres, inv_wres, fsteps, nw);
             if (p.s <= p.e && p.s < F1l && p.e >= F0l)
             {
                 s = (int)p.s;
                 lo = s > F0 ? s : F0;
                 hi = (int)p.e < F1 - 1 ? (int)p.e : F1 - 1;
                 c = p.c_minus_fsteps + (int)fsteps;
-                repwid = (float)((double)kSqrln2/p.alpha);                            // RFM_voigt.c:94
+                repwid = FAST ? kSqrln2*__builtin_amdgcn_rcpf((float)p.alpha)         // 1 ulp of fp32
+                              : (float)((double)kSqrln2/p.alpha);                     // RFM_voigt.c:94
                 y = (float)((double)repwid*p.gamma);                                  // RFM_voigt.c:95
                 dwno = (double)p.s*a.wres + a.w0;                                     // kernels.c:438
                 wnoadj = p.vnn;
@@ -483,7 +543,13 @@ __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, 
         {
             bool const voigt_line = (lo <= hi) & !lorentz;
             int const reach = voigt_line ? (int)(xlim0/(repwid*wres_f)) + 2 : -1;
+#if defined(GRT_EXP_NOPREPASS)
+            int const rmax = wave_max(reach) > 1000000 ? 1 : -1;
+#else
             int const rmax = wave_max(reach);
+#endif
+            // (staggering the lanes' walks to spread the LDS adds was measured: no gain -- this loop is
+            // instruction-bound, not conflict-bound)
             for (int r = -rmax; r <= rmax; ++r)
             {
                 int const f = c + r;
@@ -505,13 +571,25 @@ __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, 
                     inner = cand & (abx < xlim0);
                     near = inner & (abx < xlim1);
                 }
+                // what the ring will add for this point: nothing in the reference-order form (it skips
+                // inner points); in the fused form the far-wing value, computed here by the very same
+                // instruction sequence so that the fp64 correction below cancels it exactly
+                float kfar = 0.f;
+                if (FAST && near)
+                {
+                    kfar = cl*__builtin_amdgcn_rcpf(fmaf(xi, xi, yq));
+                }
                 if (inner & !near)
                 {
                     // region 1: D = RSQRPI/(D0 + XQ (D2 + XQ)); K = D Y (A0 + XQ) (:181-182), then :278
                     if (FAST)
                     {
-                        float const k1 = c1*(a0 + xq)*__builtin_amdgcn_rcpf(fmaf(xq, d2r + xq, d0r));
-                        GRT_ACC_ADD(&acc[f - F0], amp*(double)k1);
+                        // K1 - Kfar = cl [(A0+XQ)/(D0+XQ(D2+XQ)) - 1/(XQ+YQ)]
+                        //           = cl (1.5 XQ - 0.5 A0) / [(D0+XQ(D2+XQ)) (XQ+YQ)]
+                        // (A0 = YQ+0.5, D0 = A0^2, D2 = 2YQ-1): one reciprocal, no cancellation
+                        float const den = fmaf(xq, d2r + xq, d0r)*fmaf(xi, xi, yq);
+                        float const corr = cl*fmaf(1.5f, xq, -0.5f*a0)*__builtin_amdgcn_rcpf(den);
+                        GRT_ACC_ADD(&acc[f - F0], amp*(double)corr);
                     }
                     else
                     {
@@ -536,6 +614,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, 
                         q_xi[pos] = voigt_x(dwno, f - s, a.wres, wnoadj, repwid);
                         q_y[pos] = y;
                         q_rep[pos] = repwid;
+                        q_far[pos] = kfar;
                         q_idx[pos] = f - F0;
                     }
                     qcount += __popcll(m);
@@ -543,8 +622,16 @@ __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, 
             }
         }
 
-        // ---- ring: every remaining point (far wing of Voigt lines, all of the Lorentz lines) ----
+        // ---- ring ----
+        // reference-order form: every remaining point (far wing of Voigt lines, all of the Lorentz
+        // lines); fused form: the Lorentzian at EVERY window point -- the pre-pass has already added
+        // (true value - Lorentzian) for the inner points, so no test is needed here.
+#if defined(GRT_EXP_NORING)
+        if (amp == 12345.678) acc[lane] = amp + wr + ndcr + cl + yq + num + yrrtpi + norm + dwno + wnoadj + xlim0 + xlim1 + s + c;
+        for (int fbp = fb; fbp <= fe && amp == 12345.678; fbp += 64)
+#else
         for (int fbp = fb; fbp <= fe; fbp += 64)
+#endif
         {
             double token = 0.;
             int slot = lane;                        // (lane + t) & 63
@@ -559,9 +646,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, 
                 {
                     float const rel = base_rel + (float)slot;
                     float const xi = fmaf(rel, wr, ndcr);
-                    float const xq = xi*xi;
-                    bool const keep = (fabsf(rel - mid) <= half) & (xq >= x0q);
-                    float kf = keep ? cl*__builtin_amdgcn_rcpf(xq + yq) : 0.f;
+                    float kf = (fabsf(rel - mid) <= half) ? cl*__builtin_amdgcn_rcpf(fmaf(xi, xi, yq)) : 0.f;
                     asm volatile("" : "+v"(kf));    // select in fp32, then widen once
                     token = fma(amp, (double)kf, token);
                     token = ring_pass(token);
@@ -672,7 +757,7 @@ __global__ __launch_bounds__(kBlock) void line_prep_kernel(GrtGasOpticsArgs a, l
     int const slot = a.lines.slot[j];
     double const *ms = cs + a.lay.off_ms + ((uint64_t)slot*L + layer)*4;
     double const *q = cs + a.lay.off_q + ((uint64_t)slot*L + layer)*GRT_MAX_ISO;
-    Prepared const p = prepare_line<FAST>(a.lines, j, lay, ms, q, a.w0, a.wres, fsteps, (long long)a.nw);
+    Prepared const p = prepare_line<FAST>(load_line(a.lines, j), lay, ms, q, a.w0, a.wres, 1./a.wres, fsteps, (long long)a.nw);
     uint64_t const o = (uint64_t)layer*a.lines.n + j;
     vnn[o] = p.vnn;
     snn[o] = p.snn;
@@ -684,7 +769,7 @@ __global__ __launch_bounds__(kBlock) void line_prep_kernel(GrtGasOpticsArgs a, l
 
 size_t gas_optics_lds_bytes(int tile)
 {
-    return sizeof(double)*tile + sizeof(NearQueue) + 2*sizeof(long long);
+    return sizeof(double)*tile + sizeof(NearQueue) + 2*sizeof(long long) + sizeof(double)*GRT_MAX_SLOTS*(4 + GRT_MAX_ISO);
 }
 
 } // namespace

@@ -4,6 +4,7 @@
  * This library has no CPU execution path: HOST_ONLY objects are refused. */
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <hip/hip_runtime_api.h>
 #include "grt_internal.h"
 
@@ -174,6 +175,69 @@ int grt_host_free_pinned(void *p)
     {
         GRT_TRY(grt_dev_check((int)hipHostFree(p), "hipHostFree"));
     }
+    return GRTCODE_SUCCESS;
+}
+
+/* ---- the reference's gmalloc/gmemcpy/gmemset/gfree macro layer (include/debug.h) ----
+ * loc == HOST_ONLY addresses host memory; loc >= 0 a HIP device.  Synchronous, like the
+ * reference's cudaMemcpy-based macros (utilities/src/debug.h:307-348). */
+EXTERN int grt_gmalloc(void **ptr, size_t bytes, Device_t loc)
+{
+    GRT_REQUIRE_PTR(ptr);
+    if (loc == HOST_ONLY)
+    {
+        GRT_TRY(malloc_ptr(ptr, bytes));
+        return GRTCODE_SUCCESS;
+    }
+    GRT_TRY(grt_dev_alloc(loc, ptr, bytes));
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN int grt_gfree(void **ptr, Device_t loc)
+{
+    GRT_REQUIRE_PTR(ptr);
+    if (loc == HOST_ONLY)
+    {
+        GRT_TRY(free_ptr(ptr));
+        return GRTCODE_SUCCESS;
+    }
+    GRT_TRY(grt_dev_free(loc, *ptr));
+    *ptr = NULL;
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN int grt_gmemset(void *ptr, int value, size_t bytes, Device_t loc)
+{
+    GRT_REQUIRE_PTR(ptr);
+    if (loc == HOST_ONLY)
+    {
+        memset(ptr, value, bytes);
+        return GRTCODE_SUCCESS;
+    }
+    GRT_TRY(grt_dev_require(loc));
+    GRT_TRY(grt_dev_check((int)hipMemset(ptr, value, bytes), "hipMemset"));
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN int grt_gmemcpy(void *dst, void const *src, size_t bytes, Device_t loc, int direction)
+{
+    GRT_REQUIRE_PTR(dst);
+    GRT_REQUIRE_PTR(src);
+    if (loc == HOST_ONLY)
+    {
+        memcpy(dst, src, bytes);
+        return GRTCODE_SUCCESS;
+    }
+    void *s = grt_dev_stream(loc);
+    if (direction == 1)     /* FROM_DEVICE */
+    {
+        GRT_TRY(grt_dev_download(loc, dst, src, bytes, s));
+    }
+    else
+    {
+        GRT_TRY(grt_dev_upload(loc, dst, src, bytes, s));
+    }
+    GRT_TRY(grt_dev_sync(loc, s));
     return GRTCODE_SUCCESS;
 }
 

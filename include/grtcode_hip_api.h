@@ -17,6 +17,7 @@
 #ifndef GRTCODE_HIP_API_H_
 #define GRTCODE_HIP_API_H_
 
+#include <float.h>
 #include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>

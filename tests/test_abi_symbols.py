@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     names = set()
-    for h in ("grtcode_hip_api.h", "grt_ext.h"):
+    for h in ("grtcode_hip_api.h", "grt_ext.h", "debug.h"):
         src = open(os.path.join(ROOT, "include", h)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         for m in re.finditer(r"\bEXTERN\s+[\w\s\*]+?\b(\w+)\s*\(", src):
