@@ -20,6 +20,12 @@ dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
 
+def newest(pattern):
+    """gpurun merges successive runs into the same directory: take the most recent file."""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:] 
+
+
 def short(name):
     for k in ("gas_optics_kernel", "sw_kernel", "lw_kernel", "clear_sky_kernel", "integrate_rows_kernel",
               "fillBufferAligned", "copyBuffer"):
@@ -28,12 +34,12 @@ def short(name):
     return name[:40]
 
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0]
+stats = newest(os.path.join(src, "trace", "*", "*kernel_stats.csv"))[0]
 shutil.copy(stats, os.path.join(dst, f"{tag}_kernel_stats.csv"))
 bench = json.load(open(os.path.join(src, "bench_under_trace.json")))
 
 # per-launch averages by (kernel, grid) from the kernel trace
-trace = glob.glob(os.path.join(src, "trace", "*", "*kernel_trace.csv"))[0]
+trace = newest(os.path.join(src, "trace", "*", "*kernel_trace.csv"))[0]
 dur = collections.defaultdict(list)
 for r in csv.DictReader(open(trace)):
     dur[(short(r["Kernel_Name"]), r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size", ""))].append(
@@ -41,7 +47,7 @@ for r in csv.DictReader(open(trace)):
 
 
 def counters(sub, names):
-    f = glob.glob(os.path.join(src, sub, "*", "*counter_collection.csv"))
+    f = newest(os.path.join(src, sub, "*", "*counter_collection.csv"))
     out = collections.defaultdict(lambda: collections.defaultdict(list))
     if not f:
         return out

@@ -71,6 +71,21 @@ def main():
         "n_ref": cg["n_ref"], "pavg_ref": cg["pavg_ref"], "tavg_ref": cg["tavg_ref"],
         "ps_ref": cg["ps_ref"], "ns_ref": cg["ns_ref"],
     }
+    # CIRC case 1: the only real atmosphere in the reference tree (circ/src/circ1.h:7-24769); the 49 180-point
+    # albedo/solar tables are not kept (the CIRC driver accepts a constant albedo: basic-circ-test.c:127-137)
+    c1src = open(os.path.join(REF, "circ/src/circ1.h")).read()
+    c1 = c_arrays(c1src)
+    scal = lambda name: float(re.search(name + r"\s*=\s*(" + NUM + ")", c1src).group(1))
+    vec["circ1"] = {
+        "source": "circ/src/circ1.h",
+        "level_pressure_mb": c1["level_pressure"], "level_temperature": c1["level_temperature"],
+        "layer_pressure_mb": c1["layer_pressure"], "layer_temperature": c1["layer_temperature"],
+        "surface_temperature": scal("surface_temperature"), "solar_zenith_angle_deg": scal("solar_zenith_angle"),
+        "toa_solar_irradiance": scal("toa_solar_irradiance"),
+        "abundance": {k.replace("_abundance", ""): c1[k] for k in c1 if k.endswith("_abundance")},
+        # LBLRTM broadband reference values quoted by circ/src/basic-circ-test.c:447-495 (sanity magnitudes)
+        "lblrtm": {"rlut": 304.27, "rlus": 445.12, "rlds": 288.2, "rsut": 175.0, "rsus": 137.40, "rsdt": 912.79, "rsds": 701.2},
+    }
     tips = open(os.path.join(REF, "gas-optics/test/test_tips2017.c")).read()
     temp = float(re.search(r"#define TEMPERATURE\s+(" + NUM + ")", tips).group(1))
     vec["test_tips2017"] = {
