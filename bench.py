@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lw-lines", type=int, default=None)
     ap.add_argument("--sw-lines", type=int, default=None)
+    ap.add_argument("--lw-dw", type=float, default=None, help="exploration only: longwave grid spacing (default 1 cm-1)")
+    ap.add_argument("--sw-dw", type=float, default=None, help="exploration only: shortwave grid spacing (default 1 cm-1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -139,8 +141,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     device = api.create_device(local_rank)
+    lw_grid = (W.LW_GRID[0], W.LW_GRID[1], args.lw_dw or W.LW_GRID[2])
+    sw_grid = (W.SW_GRID[0], W.SW_GRID[1], args.sw_dw or W.SW_GRID[2])
     wl = W.G1Workload(device, args.cols, lw_lines=args.lw_lines or W.LW_LINES,
-                      sw_lines=args.sw_lines or W.SW_LINES, fast=args.fast)
+                      sw_lines=args.sw_lines or W.SW_LINES, fast=args.fast, lw_grid=lw_grid, sw_grid=sw_grid)
     first, count = multi.shard(world * args.cols, rank, world)      # weak scaling: args.cols columns per rank
     (gcols, keep), _ = wl.columns(first, count)
     out = torch.zeros(args.cols, api.GRT_FLUXES_PER_COLUMN, dtype=torch.float64, device="cuda")
@@ -187,7 +191,7 @@ def main():
         bytes_gas = lambda nlines, n: args.cols * (60.0 * nlines + n * (8.0 * 10 + 8.0 * L))
         dom_ms = ms[2][0] / max(ms[2][1], 1)
         achieved = bytes_gas(S["sw"], n_sw) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        fsteps = 25
+        fsteps = int(np.ceil(25.0 / sw_grid[2]))
         points = lambda nlines: float(L) * nlines * (2 * fsteps + 1) * args.cols      # Voigt evaluations per launch
         valu_flop = 12.0 * points(S["sw"])                                            # ~12 flop far-wing point
         traffic = None

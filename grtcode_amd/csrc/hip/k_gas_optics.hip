@@ -57,6 +57,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kWaves = kBlock/64;
+constexpr int kDirectWindow = 32;   // windows up to this many points skip the ring (see the kernel)
 constexpr int kQueue = 128;     // near-centre queue entries per wave: drained above 64, <= 64 pushed per step
 
 // RFM_voigt.c:72,79
@@ -487,8 +488,19 @@ __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, 
                 lo = s > F0 ? s : F0;
                 hi = (int)p.e < F1 - 1 ? (int)p.e : F1 - 1;
                 c = p.c_minus_fsteps + (int)fsteps;
-                repwid = FAST ? kSqrln2*__builtin_amdgcn_rcpf((float)p.alpha)         // 1 ulp of fp32
-                              : (float)((double)kSqrln2/p.alpha);                     // RFM_voigt.c:94
+                // RFM_voigt.c:94: REPWID = float(SQRLN2/DOPADJ).  It scales x inside exp(-x^2), where a
+                // 1-ulp difference is amplified by 2x^2, so it must round as the reference's does: the
+                // fused form takes the hardware reciprocal and one fp64 Newton step (error ~1e-14, i.e.
+                // the correctly rounded float except on exact ties) instead of a full fp64 division.
+                if (FAST)
+                {
+                    double const r0 = (double)__builtin_amdgcn_rcpf((float)p.alpha);
+                    repwid = (float)((double)kSqrln2*(r0*fma(-p.alpha, r0, 2.0)));
+                }
+                else
+                {
+                    repwid = (float)((double)kSqrln2/p.alpha);
+                }
                 y = (float)((double)repwid*p.gamma);                                  // RFM_voigt.c:95
                 dwno = (double)p.s*a.wres + a.w0;                                     // kernels.c:438
                 wnoadj = p.vnn;
@@ -620,6 +632,44 @@ __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, 
                     qcount += __popcll(m);
                 }
             }
+        }
+
+        // ---- narrow windows (coarse grids, e.g. 7 points at 10 cm-1): a 64-step ring pass would be
+        // mostly idle, so each lane simply walks its own window and adds into the tile.  Lanes start
+        // at different window points so that neighbouring lines do not hit one LDS word together.
+        if (W <= kDirectWindow)
+        {
+            int k = lane % W;
+            for (int kk = 0; kk < W; ++kk)
+            {
+                int const f = c - (int)fsteps + k;
+                k = k + 1 == W ? 0 : k + 1;
+                if ((f >= lo) & (f <= hi))
+                {
+                    if (FAST)
+                    {
+                        float const xi = fmaf((float)(f - c), wr, ndcr);
+                        float const kf = cl*__builtin_amdgcn_rcpf(fmaf(xi, xi, yq));
+                        GRT_ACC_ADD(&acc[f - F0], amp*(double)kf);
+                    }
+                    else
+                    {
+                        float const xi = voigt_x(dwno, f - s, a.wres, wnoadj, repwid);
+                        float const abx = fabsf(xi);
+                        float const xq = abx*abx;
+                        if (lorentz)
+                        {
+                            GRT_ACC_ADD(&acc[f - F0], amp*((double)num/(M_PI*(double)(xq + yq))));   // :103
+                        }
+                        else if (abx >= xlim0)
+                        {
+                            float const kf = yrrtpi/(xq + yq);                                    // :170
+                            GRT_ACC_ADD(&acc[f - F0], amp*(norm*(double)kf));
+                        }
+                    }
+                }
+            }
+            continue;
         }
 
         // ---- ring ----

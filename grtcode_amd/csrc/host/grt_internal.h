@@ -84,6 +84,7 @@ typedef struct GrtGasOpticsImpl
     double *colstate_h;            /* pinned host */
     double *colstate_d;
     int tile, nslice, fast;        /* launch tuning (grt_gas_optics_tune) */
+    int profile_tag;               /* 0: by grid size; the pipeline sets 1 (longwave) / 2 (shortwave) */
 } GrtGasOpticsImpl;
 
 int grt_gas_optics_prepare(GasOptics_t *go, int ncol);   /* build store/tables/layout if stale */

@@ -48,6 +48,7 @@ static int band_alloc(GrtPipeline_t *p, GrtBand *b, GasOptics_t *gas)
     }
     b->gas = gas;
     b->n = gas->grid.n;
+    ((GrtGasOpticsImpl *)gas->impl)->profile_tag = (b == &p->band[0]) ? 1 : 2;
     size_t const L = (size_t)p->num_levels - 1, V = (size_t)p->num_levels, C = (size_t)p->max_cols;
     size_t const opt = sizeof(double)*C*L*b->n, flx = sizeof(double)*C*V*b->n;
     void *blk = NULL;

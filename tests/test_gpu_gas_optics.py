@@ -121,3 +121,20 @@ def test_empty_line_list_leaves_only_continua(tmp_path, oracle, lib, device):
     assert tau.max() > 0
     opt.destroy()
     go.destroy()
+
+
+@pytest.mark.parametrize("dw,fast", [(10.0, 0), (10.0, 1), (5.0, 1), (2.0, 1)])
+def test_coarse_grids_narrow_windows(tmp_path, oracle, lib, device, dw, fast):
+    """Coarse grids (ERA5 runs its shortwave at 10 cm-1: 7-point windows) take the direct-walk path."""
+    band = Band(str(tmp_path), 1.0, 3001.0, dw, 5000, sw=True)
+    col = syn.profile(6, 17)
+    go, grid = band.gas_optics(device, 17, from_file=False)
+    go.tune(fast=fast)
+    band.set_column(go, col)
+    opt = api.OpticsObject(16, grid, device)
+    go.calculate_optical_depth(col["p"], col["t"], opt)
+    tau = opt.read()[0]
+    want = band.oracle_tau(oracle, oracle, lib, col)
+    assert tau_close(tau, want) < (2e-6 if fast else TAU_TOL)
+    opt.destroy()
+    go.destroy()
