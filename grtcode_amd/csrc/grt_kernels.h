@@ -34,6 +34,8 @@ typedef struct GrtLineStore
     uint8_t const *iso;     /* 1-based isotopologue id */
     uint8_t const *slot;    /* molecule slot (order of add_molecule) */
     double dmax;            /* max |delta| over the store: bound on the pressure shift */
+    double ymax;            /* max of yair, yself over the store [cm-1 atm-1] and */
+    double nmax;            /* max |nexp|: bound on the Lorentz half-width of any line in a layer */
 } GrtLineStore;
 
 /* Per-column layer state prepared on the host in the reference's arithmetic
@@ -69,10 +71,14 @@ typedef struct GrtGasOpticsArgs
     uint64_t tau_col_stride;  /* doubles between columns */
     int tile;                 /* wavenumbers per workgroup (multiple of 64) */
     int nslice;               /* line slices per tile (>=1); >1 uses global atomics */
-    int fast;                 /* 0: reference operation order; 1: fused-multiply-add form */
+    int fast;                 /* 0: reference operation order; 1: fused form, far wings by cell moments
+                                 where the window is wide enough; 2: fused form, every point in the ring */
 } GrtGasOpticsArgs;
 
 int grt_launch_gas_optics(void *stream, GrtGasOpticsArgs const *a);
+/* fast == 1 only: the cell-moment kernel (k_gas_optics_mp.hip) and whether it applies to a grid */
+int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a);
+int grt_gas_optics_mp_applicable(GrtGasOpticsArgs const *a);
 
 /* Debug/parity hook: per-(layer,line) preparation only (kernels.c:34-131) and the
    integer window [s,e] of kernels.c:431-437 (s=1,e=0 when the line is skipped). */

@@ -39,321 +39,9 @@
 // and adds and uses the hardware reciprocal.
 //
 // No MFMA: there is no dense contraction here.  The kernel is FP32/FP64-VALU bound.
-#include <hip/hip_runtime.h>
-#include <math.h>
-#include <stdint.h>
-#include "../grt_kernels.h"
-
-#pragma clang fp contract(off)
-
-// Ablation hooks for timing experiments only (never defined in the product build).
-#if defined(GRT_EXP_NOATOMIC)
-#define GRT_ACC_ADD(ptr, v) (*(ptr) += (v))
-#else
-#define GRT_ACC_ADD(ptr, v) unsafeAtomicAdd((ptr), (v))
-#endif
+#include "gas_optics_dev.h"
 
 namespace {
-
-constexpr int kBlock = 256;
-constexpr int kWaves = kBlock/64;
-constexpr int kDirectWindow = 32;   // windows up to this many points skip the ring (see the kernel)
-constexpr int kQueue = 128;     // near-centre queue entries per wave: drained above 64, <= 64 pushed per step
-
-// RFM_voigt.c:72,79
-constexpr float kRsqrpi = 0.56418958f;
-constexpr float kSqrln2 = 0.832554611f;
-
-// One line of the merged store, as loaded from HBM (37 bytes).
-struct RawLine
-{
-    double v0, s0;
-    float yair, yself, en, nexp, delta;
-    int iso, slot;
-};
-
-__device__ __forceinline__ RawLine load_line(GrtLineStore const &ls, uint64_t j)
-{
-    RawLine r;
-    r.v0 = ls.v0[j]; r.s0 = ls.s0[j];
-    r.yair = ls.yair[j]; r.yself = ls.yself[j]; r.en = ls.en[j]; r.nexp = ls.nexp[j]; r.delta = ls.delta[j];
-    r.iso = ls.iso[j]; r.slot = ls.slot[j];
-    return r;
-}
-
-struct Prepared
-{
-    double vnn, snn, gamma, alpha;
-    long long s, e;         // s > e: line skipped (kernels.c:433)
-    int c_minus_fsteps;     // centre index - fsteps: the window start before clipping at 0
-};
-
-// exp(x) for the FAST form: range reduction in fp64, 2^fraction on the hardware
-// transcendental unit (v_exp_f32, ~1 ulp of fp32), exact scaling by 2^n.  Relative error
-// ~1e-7, the same class as the fp32 line-shape value it multiplies.
-__device__ __forceinline__ double exp_fast(double x)
-{
-    double const z = x*1.4426950408889634;
-    double const n = rint(z);
-    float const r = __builtin_amdgcn_exp2f((float)(z - n));
-    return ldexp((double)r, (int)n);
-}
-
-// kernels.c:34-131 for one (layer, line) + the window of kernels.c:431-437.
-// lay: pavg, tavg, 1/tavg, log(296/tavg); ms: ps, pavg-ps, ns, doppler factor.
-template <bool FAST>
-__device__ __forceinline__ Prepared prepare_line(RawLine const &ln,
-                                                 double const *lay, double const *ms,
-                                                 double const *q, double w0, double wres,
-                                                 double inv_wres, long long fsteps, long long nw)
-{
-    double const c2 = -1.4387686f;           // kernels.c:75
-    double const tref = 296.f;               // kernels.c:97
-    double const sqrt_ln2 = 0.83255461115f;  // kernels.c:117
-    double const pavg = lay[0], T = lay[1];
-    double const ps = ms[0], pf = ms[1], dop = ms[3];
-    double const v0 = ln.v0;
-    double const en = ln.en, nexp = ln.nexp;
-    double const yair = ln.yair, yself = ln.yself, delta = ln.delta;
-    Prepared p;
-    p.vnn = v0 + delta*pavg;                                         // kernels.c:44
-    if (FAST)
-    {
-        double const invT = lay[2];
-        p.snn = ln.s0*exp_fast((c2*en)*invT)*(1.0 - exp_fast((c2*v0)*invT))*q[ln.iso - 1];
-        p.gamma = exp_fast(nexp*lay[3])*fma(yair, pf, yself*ps);
-    }
-    else
-    {
-#if defined(GRT_EXP_NOPREP)
-        p.snn = ln.s0*(c2*en/T)*(1.f - (c2*v0/T))*q[ln.iso - 1];
-        p.gamma = (tref/T + nexp)*(yair*pf + yself*ps);
-#else
-        p.snn = ln.s0*exp(c2*en/T)*(1.f - exp(c2*v0/T))*q[ln.iso - 1];   // kernels.c:83-85
-        p.gamma = pow(tref/T, nexp)*(yair*pf + yself*ps);                  // kernels.c:105-106
-#endif
-    }
-    p.alpha = sqrt_ln2*p.vnn*dop;                                    // kernels.c:127
-    // kernels.c:431-432: fcenterid = floor((2*((vnn - w0)/wres) + 1)/2), bit-exact.  The quotient is
-    // first formed with the reciprocal (error <= 2 ulp); floor() of the two can only differ when the
-    // argument sits within a few ulp of an integer, in which case the true division is used.
-    double const dv = p.vnn - w0;
-    double u = (2*(dv*inv_wres) + 1)/2;
-    if (fabs(u - rint(u)) <= 4e-15*fmax(1., fabs(u)))
-    {
-        u = (2*(dv/wres) + 1)/2;
-    }
-    double const fc = floor(u);
-    p.s = 1;
-    p.e = 0;
-    p.c_minus_fsteps = 0;
-    if (fc >= 0. && fc < (double)nw)
-    {
-        long long const c = (long long)fc;
-        p.c_minus_fsteps = (int)(c - fsteps);
-        p.s = (c - fsteps) < 0 ? 0 : c - fsteps;                     // kernels.c:435
-        p.e = (c + fsteps) >= nw ? nw - 1 : c + fsteps;              // kernels.c:436-437
-    }
-    return p;
-}
-
-// RFM_voigt.c:172-277: Humlicek regions 1-4 for one point (region 0 is handled by the
-// callers).  Returns K before the final RSQRPI*REPWID scaling (:278).  The region
-// coefficients depend on y only; the reference caches them per line, we evaluate them
-// per queued point (the queue is dense, see file header).
-template <bool FAST>
-__device__ __forceinline__ float quot(float a, float b)
-{
-    // reference-order form: IEEE division; fused form: a * v_rcp_f32(b) (1 ulp)
-    return FAST ? a*__builtin_amdgcn_rcpf(b) : a/b;
-}
-
-template <bool FAST>
-__device__ __forceinline__ double voigt_near(float xi, float y)
-{
-    float const yq = y*y;
-    float const abx = fabsf(xi);
-    float const xq = abx*abx;
-    float xlim1 = (y >= 8.425f) ? 0.0f : (float)sqrt((double)(164.0f - y*(4.3f + y*1.8f)));
-    float xlim2 = 6.8f - y;
-    float const xlim3 = 2.4f*y;
-    float const xlim4 = 18.1f*y + 1.65f;
-    if (y <= 0.000001f)
-    {
-        // RFM_voigt.c:122-126: no Lorentz width -> regions 1 and 2 are switched off
-        float const xlim0 = (float)sqrt((double)(15100.0f + y*(40.0f - y*3.6f)));
-        xlim1 = xlim0;
-        xlim2 = xlim0;
-    }
-    if (abx >= xlim1)
-    {
-        float const a0 = (float)((double)yq + 0.5);
-        float const d0 = a0*a0;
-        float const d2 = (float)((double)(yq + yq) - 1.0);
-        float const d = quot<FAST>(kRsqrpi, d0 + xq*(d2 + xq));
-        return (double)(d*y*(a0 + xq));
-    }
-    if (abx >= xlim2)
-    {
-        float const h0 = 0.5625f + yq*(4.5f + yq*(10.5f + yq*(6.0f + yq)));
-        float const h2 = -4.5f + yq*(9.0f + yq*(6.0f + yq*4.0f));
-        float const h4 = 10.5f - yq*(6.0f - yq*6.0f);
-        float const h6 = -6.0f + yq*4.0f;
-        float const e0 = 1.875f + yq*(8.25f + yq*(5.5f + yq));
-        float const e2 = 5.25f + yq*(1.0f + yq*3.0f);
-        float const e4 = 0.75f*h6;
-        float const d = quot<FAST>(kRsqrpi, h0 + xq*(h2 + xq*(h4 + xq*(h6 + xq))));
-        return (double)(d*y*(e0 + xq*(e2 + xq*(e4 + xq))));
-    }
-    if (abx < xlim3)
-    {
-        float const z0 = 272.1014f + y*(1280.829f + y*(2802.870f + y*(3764.966f
-                         + y*(3447.629f + y*(2256.981f + y*(1074.409f + y*(369.1989f
-                         + y*(88.26741f + y*(13.39880f + y)))))))));
-        float const z2 = 211.678f + y*(902.3066f + y*(1758.336f + y*(2037.310f
-                         + y*(1549.675f + y*(793.4273f + y*(266.2987f
-                         + y*(53.59518f + y*5.0f)))))));
-        float const z4 = 78.86585f + y*(308.1852f + y*(497.3014f + y*(479.2576f
-                         + y*(269.2916f + y*(80.39278f + y*10.0f)))));
-        float const z6 = 22.03523f + y*(55.02933f + y*(92.75679f + y*(53.59518f
-                         + y*10.0f)));
-        float const z8 = 1.496460f + y*(13.39880f + y*5.0f);
-        float const p0 = 153.5168f + y*(549.3954f + y*(919.4955f + y*(946.8970f
-                         + y*(662.8097f + y*(328.2151f + y*(115.3772f + y*(27.93941f
-                         + y*(4.264678f + y*0.3183291f))))))));
-        float const p2 = -34.16955f + y*(-1.322256f + y*(124.5975f + y*(189.7730f
-                         + y*(139.4665f + y*(56.81652f + y*(12.79458f
-                         + y*1.2733163f))))));
-        float const p4 = 2.584042f + y*(10.46332f + y*(24.01655f + y*(29.81482f
-                         + y*(12.79568f + y*1.9099744f))));
-        float const p6 = -0.07272979f + y*(0.9377051f + y*(4.266322f + y*1.273316f));
-        float const p8 = 0.0005480304f + y*0.3183291f;
-        float const d = quot<FAST>(1.7724538f, z0 + xq*(z2 + xq*(z4 + xq*(z6 + xq*(z8 + xq)))));
-        return (double)(d*(p0 + xq*(p2 + xq*(p4 + xq*(p6 + xq*p8)))));
-    }
-    // region 4: six-term rational sums, accumulated in double like the reference's
-    // fp_t output slot (RFM_voigt.c:233-276)
-    float const C[6] = {1.0117281f, -0.75197147f, 0.012557727f,
-                        0.010022008f, -0.00024206814f, 0.00000050084806f};
-    float const S[6] = {1.393237f, 0.23115241f, -0.15535147f,
-                        0.0062183662f, 0.000091908299f, -0.00000062752596f};
-    float const T[6] = {0.31424038f, 0.94778839f, 1.5976826f,
-                        2.2795071f, 3.0206370f, 3.8897249f};
-    float const y0 = 1.5f, y0py0 = 3.f, y0q = 2.25f;
-    float const ypy0 = y + y0;
-    float const ypy0q = ypy0*ypy0;
-    double k = 0.0;
-    if (abx <= xlim4)
-    {
-#pragma unroll
-        for (int J = 0; J < 6; ++J)
-        {
-            float dm = xi - T[J];
-            float const mf = quot<FAST>(1.0f, dm*dm + ypy0q);
-            float const xm = mf*dm, ym = mf*ypy0;
-            float dp = xi + T[J];
-            float const pf = quot<FAST>(1.0f, dp*dp + ypy0q);
-            float const xp = pf*dp, yp = pf*ypy0;
-            k = k + (double)(C[J]*(ym + yp)) - (double)(S[J]*(xm - xp));
-        }
-    }
-    else
-    {
-        float const yf = y + y0py0;
-#pragma unroll
-        for (int J = 0; J < 6; ++J)
-        {
-            float dm = xi - T[J];
-            float const mq = dm*dm;
-            float const mf = quot<FAST>(1.0f, mq + ypy0q);
-            float const xm = mf*dm, ym = mf*ypy0;
-            float dp = xi + T[J];
-            float const pq = dp*dp;
-            float const pf = quot<FAST>(1.0f, pq + ypy0q);
-            float const xp = pf*dp, yp = pf*ypy0;
-            k = k + (double)quot<FAST>(C[J]*(mq*mf - y0*ym) + S[J]*yf*xm, mq + y0q)
-                  + (double)quot<FAST>(C[J]*(pq*pf - y0*yp) - S[J]*yf*xp, pq + y0q);
-        }
-        k = (double)y*k + exp((double)(-xq));
-    }
-    return k;
-}
-
-// x-coordinate of window point k of a line: RFM_voigt.c:102/165 with DWNO from
-// kernels.c:438.  (k converts exactly; the sum order is the reference's.)
-__device__ __forceinline__ float voigt_x(double dwno, int k, double wres, double wnoadj,
-                                          float repwid)
-{
-    return (float)((dwno + (double)k*wres - wnoadj)*(double)repwid);
-}
-
-// Wave-wide integer min/max (butterfly over the 64 lanes).
-__device__ __forceinline__ int wave_min(int v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-    {
-        int const o = __shfl_xor(v, off, 64);
-        v = o < v ? o : v;
-    }
-    return v;
-}
-
-__device__ __forceinline__ int wave_max(int v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
-    {
-        int const o = __shfl_xor(v, off, 64);
-        v = o > v ? o : v;
-    }
-    return v;
-}
-
-// One step of the accumulation ring: every lane hands its partial sum to the lane below it
-// (lane l receives from lane (l+1) & 63), so the token for slot (lane + t) & 63 arrives where
-// that slot is evaluated at step t + 1.
-__device__ __forceinline__ double ring_pass(double v)
-{
-    // v_mov_b32_dpp wave_rol:1 (DPP control 0x134): lane l <- lane l+1, lane 63 <- lane 0;
-    // register-file latency, no LDS crossbar trip (direction verified on gfx950 hardware)
-    int lo = __double2loint(v), hi = __double2hiint(v);
-#if defined(GRT_RING_BPERMUTE)
-    int const src = ((threadIdx.x + 1) & 63) << 2;
-    lo = __builtin_amdgcn_ds_bpermute(src, lo);
-    hi = __builtin_amdgcn_ds_bpermute(src, hi);
-#else
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x134, 0xf, 0xf, true);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x134, 0xf, 0xf, true);
-#endif
-    return __hiloint2double(hi, lo);
-}
-
-// Near-centre points wait here until a wave has 64 of them (struct-of-arrays in LDS).
-struct NearQueue
-{
-    double amp[kWaves][kQueue];     // S(T)*N_s of the line
-    float xi[kWaves][kQueue];
-    float y[kWaves][kQueue];
-    float repwid[kWaves][kQueue];
-    float far[kWaves][kQueue];      // what the ring adds for this point (fused form), to be taken back
-    int idx[kWaves][kQueue];        // accumulator index f - F0
-};
-
-// Evaluate queued near-centre points with all lanes busy (Humlicek regions 1-4) and add them
-// to the tile.  Only the pre-pass and the kernel tail call it (never the ring loop), so it is
-// inlined: an out-of-line call costs scratch traffic for the call ABI on every drain.
-template <bool FAST>
-__device__ __forceinline__ void drain_near(double *acc, double const *q_amp, float const *q_xi,
-                                        float const *q_y, float const *q_rep, float const *q_far,
-                                        int const *q_idx, int count, int lane)
-{
-    for (int i = lane; i < count; i += 64)
-    {
-        double const k = (double)(kRsqrpi*q_rep[i])*voigt_near<FAST>(q_xi[i], q_y[i]) - q_far[i];   // RFM_voigt.c:278
-        GRT_ACC_ADD(&acc[q_idx[i]], q_amp[i]*k);                                                   // kernels.c:459
-    }
-}
 
 // Register budget: the fused form needs 128 VGPRs (4 waves per SIMD), the reference-order form
 // 146 (3 waves per SIMD); neither spills.  (Forcing 128 on the reference-order form costs 72 B/lane
@@ -374,23 +62,8 @@ __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, 
     int const tid = threadIdx.x;
     int const lane = tid & 63;
     int const wave = tid >> 6;
-    // XCD-aware work order.  Workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share
-    // one), and all (layer, column) workgroups of one (tile, line slice) "group" read the SAME slice
-    // of the line list.  Every XCD gets an equal, contiguous share of the work items, ordered group
-    // by group with layer/column varying fastest, so the ~10^2 workgroups resident on an XCD share
-    // one or two line slices (~1 MB) that live in its 4 MB L2 instead of being re-fetched over the
-    // fabric (FETCH_SIZE 17 GB -> 0.06 GB per shortwave launch).  Groups are visited in a
-    // golden-ratio stride permutation so that each XCD's share mixes cheap and expensive spectral
-    // regions (high-wavenumber tiles carry more near-centre work).  Placement affects speed only.
-    unsigned const nb = gridDim.x, xcd = blockIdx.x & 7u, q8 = nb >> 3, r8 = nb & 7u;
-    unsigned const work = (xcd < r8 ? xcd*(q8 + 1u) : r8*(q8 + 1u) + (xcd - r8)*q8) + (blockIdx.x >> 3);
-    unsigned const per_group = (unsigned)a.lay.num_layers*(unsigned)a.ncol;
-    unsigned const pos = work/per_group, rem = work - pos*per_group;
-    unsigned const group = (unsigned)(((unsigned long long)pos*perm_stride) % ngroups);
-    int const col = (int)(rem/(unsigned)a.lay.num_layers);
-    int const layer = (int)(rem - (unsigned)col*(unsigned)a.lay.num_layers);
-    int const tile_idx = (int)(group/(unsigned)a.nslice);
-    int const slice = (int)(group - (unsigned)tile_idx*(unsigned)a.nslice);
+    WorkItem const wi = decode_work(a, ngroups, perm_stride);
+    int const col = wi.col, layer = wi.layer, tile_idx = wi.tile_idx, slice = wi.slice;
     long long const nw = (long long)a.nw;
     long long const F0l = (long long)tile_idx*a.tile;
     long long const F1l = (F0l + a.tile < nw) ? F0l + a.tile : nw;                // [F0,F1)
@@ -405,43 +78,11 @@ __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, 
     {
         acc[i] = 0.0;
     }
-    for (int i = tid; i < a.lay.num_slots*4; i += kBlock)
-    {
-        ms_l[i] = cs[a.lay.off_ms + ((uint64_t)(i >> 2)*L + layer)*4 + (i & 3)];
-    }
-    for (int i = tid; i < a.lay.num_slots*GRT_MAX_ISO; i += kBlock)
-    {
-        q_l[i] = cs[a.lay.off_q + ((uint64_t)(i/GRT_MAX_ISO)*L + layer)*GRT_MAX_ISO + (i % GRT_MAX_ISO)];
-    }
+    stage_column_state(a, cs, layer, ms_l, q_l, tid);
 
-    // Candidate line range: every line whose centre index can fall within
-    // [F0 - fsteps, F1 - 1 + fsteps], with one extra grid step and the largest
-    // possible pressure shift as margin.  Exact membership is decided per line.
     if (tid == 0)
     {
-        double const shift = a.lines.dmax*fabs(lay[0]);
-        double const wlo = a.w0 + ((double)(F0l - fsteps) - 1.5)*a.wres - shift;
-        double const whi = a.w0 + ((double)(F1l + fsteps) + 0.5)*a.wres + shift;
-        uint64_t lo = 0, hi = a.lines.n;
-        while (lo < hi)
-        {
-            uint64_t const mid = (lo + hi) >> 1;
-            if (a.lines.v0[mid] < wlo) lo = mid + 1; else hi = mid;
-        }
-        uint64_t const jlo = lo;
-        hi = a.lines.n;
-        while (lo < hi)
-        {
-            uint64_t const mid = (lo + hi) >> 1;
-            if (a.lines.v0[mid] <= whi) lo = mid + 1; else hi = mid;
-        }
-        uint64_t const jhi = lo;
-        uint64_t const per = (jhi - jlo + a.nslice - 1)/a.nslice;
-        uint64_t const b = jlo + per*slice;
-        uint64_t e = b + per;
-        if (e > jhi) e = jhi;
-        range[0] = (long long)(b < jhi ? b : jhi);
-        range[1] = (long long)e;
+        candidate_range(a, lay, F0l, F1l, fsteps, slice, range);
     }
     __syncthreads();
     uint64_t const jbeg = (uint64_t)range[0];
@@ -739,55 +380,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, 
     drain(qcount);
     __syncthreads();
 
-    // ---- epilogue: fold in continua / CFC / CIA and write the tile once ----
-    // Two consecutive grid points per lane: one 16-byte store per lane (1 KiB per wave instruction)
-    // whenever the row start is 16-byte aligned, which also is the store shape WRITE_SIZE is
-    // calibrated for on gfx950.
-    bool const add_tables = (slice == 0);
-    double const *cont = cs + a.lay.off_cont + (uint64_t)layer*GRT_MAX_TABLES;
-    double const *h2o = cs + a.lay.off_h2o + (uint64_t)layer*4;
-    double *out = a.tau + (uint64_t)col*a.tau_col_stride + (uint64_t)layer*a.nw;
-    bool const pair_ok = (a.nslice == 1) && ((reinterpret_cast<uintptr_t>(out + F0l) & 15u) == 0);
-    auto finish = [&](long long f) -> double
-    {
-        double v = acc[f - F0l];
-        if (add_tables)
-        {
-            if (a.lay.has_h2o_ctm)
-            {
-                // kernels.c:484-487; h2o = {N*(296/T), Ps, P-Ps, 296-T};
-                // tables F296,S296,CKDF,CKDS (launch.c:165-170)
-                double const CF = a.h2o_tables[f], CS = a.h2o_tables[a.nw + f];
-                double const T0F = a.h2o_tables[2*a.nw + f], T0 = a.h2o_tables[3*a.nw + f];
-                v += h2o[0]*((CS*h2o[1]*exp(T0*h2o[3])) + (CF*h2o[2]*exp(T0F*h2o[3])));
-            }
-            for (int k = 0; k < a.lay.num_tables; ++k)
-            {
-                v += cont[k]*a.tables[(uint64_t)k*a.nw + f];
-            }
-        }
-        return v;
-    };
-    for (long long f = F0l + 2*tid; f < F1l; f += 2*kBlock)
-    {
-        double const v0 = finish(f);
-        bool const has1 = f + 1 < F1l;
-        double const v1 = has1 ? finish(f + 1) : 0.;
-        if (pair_ok && has1)
-        {
-            *reinterpret_cast<double2 *>(out + f) = make_double2(v0, v1);
-        }
-        else if (a.nslice == 1)
-        {
-            out[f] = v0;
-            if (has1) out[f + 1] = v1;
-        }
-        else
-        {
-            unsafeAtomicAdd(&out[f], v0);
-            if (has1) unsafeAtomicAdd(&out[f + 1], v1);
-        }
-    }
+    write_tile(a, acc, cs, col, layer, slice, F0l, F1l, tid);
 }
 
 template <bool FAST>
@@ -843,17 +436,13 @@ extern "C" int grt_launch_gas_optics(void *stream, GrtGasOpticsArgs const *a)
         return (int)hipErrorInvalidValue;
     }
     dim3 const grid((unsigned)blocks, 1, 1);
-    // stride of the group permutation: nearest integer to ngroups/phi^2 that is coprime with ngroups
-    unsigned stride = (unsigned)((double)ngroups*0.3819660112501051);
-    if (stride < 1) stride = 1;
-    for (;; ++stride)
-    {
-        unsigned x = stride, y = (unsigned)ngroups;
-        while (y != 0) { unsigned const t = x % y; x = y; y = t; }
-        if (x == 1) break;
-    }
+    unsigned const stride = golden_stride(ngroups);
     size_t const lds = gas_optics_lds_bytes(a->tile);
     hipStream_t const s = (hipStream_t)stream;
+    if (a->fast == 1)
+    {
+        return grt_launch_gas_optics_mp(stream, a);
+    }
     if (a->fast)
     {
         hipLaunchKernelGGL(gas_optics_kernel<true>, grid, dim3(kBlock), lds, s, *a, fsteps, (unsigned)ngroups, stride);

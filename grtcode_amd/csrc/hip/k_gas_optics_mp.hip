@@ -1,0 +1,497 @@
+// k_gas_optics_mp.hip -- line-by-line optical depth, fused form, far wings by cell moments.
+//
+// Same result as gas_optics_kernel<true> (k_gas_optics.hip; reference: kernels.c:410-465 +
+// RFM_voigt.c:85-281) but the work is organised around what the 1 cm-1 problem really is: about
+// 300 lines per grid point, each spread over a 51-point window in which all but the few points next
+// to the centre see a plain Lorentzian
+//
+//     K(r) = cl / (x^2 + y^2),   x = (r - delta) wr         (RFM_voigt.c:103,170,278)
+//          = A / ((r - delta)^2 + eta^2),   A = cl/wr^2,  eta = y/wr = gamma_L / wres
+//
+// with r = f - c the integer offset of grid point f from the line's centre index c
+// (kernels.c:431-437: the window is c +- fsteps, so every line of a "cell" c has the same window)
+// and |delta| <= 1/2.  For |r| > R the sum over the lines of one cell is a short power series
+//
+//     sum_i A_i / ((r - delta_i)^2 + eta_i^2) = sum_{k>=1} M_k(c) r^-(k+1),
+//     M_k = sum_i A_i Im(z_i^k)/eta_i,   z_i = delta_i + i eta_i,
+//
+// (geometric in |z|/r; R is chosen per layer so that 8 terms leave < 1e-7 of the far-wing value).
+// So each line costs: its per-layer preparation, 8 moment terms, and its 2R+1 near points; the far
+// wings of ALL lines are then one pass over the tile (2 (fsteps - R) cells x 8 terms per grid point,
+// independent of the number of lines).  At 1 cm-1 that removes ~80 % of the line-shape evaluations;
+// at 0.1 cm-1 (501-point windows) ~97 %.
+//
+// Near points (|r| <= R) run through a wave ring as before, but 16 slots wide: four independent
+// rings, one per DPP row, rotate with row_ror:1; 16 steps cover 16 grid points for 64 lines.  The
+// token carries its slot number with it, so nothing depends on the direction of the rotation.
+// Humlicek region 1 (XLIM1 <= |x| < XLIM0) is evaluated inside the ring whenever it lies within R;
+// regions 2-4 go through the per-wave queue exactly as in the ring kernel.
+#include "gas_optics_dev.h"
+
+namespace {
+
+constexpr int kMom = 8;         // moments per cell
+constexpr int kRcap = 12;       // widest near field taken for the sake of region 1 (the moment bound may ask for more)
+constexpr int kCellLoop = 4;    // waves whose lines span at most this many cells reduce in registers first
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
+// row_ror:1 (DPP control 0x121): rotation by one lane inside each row of 16 lanes
+__device__ __forceinline__ double row_pass(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x121, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x121, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+
+// Wave-wide integer min / max as scalars: rotations inside the rows of 16 lanes (every lane of a row
+// ends up with the row's extreme, whatever the direction of row_ror), then the four rows on the
+// scalar unit.
+__device__ __forceinline__ int wave_min_s(int v)
+{
+    v = min(v, dpp_i<0x121>(v));
+    v = min(v, dpp_i<0x122>(v));
+    v = min(v, dpp_i<0x124>(v));
+    v = min(v, dpp_i<0x128>(v));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+__device__ __forceinline__ int wave_max_s(int v)
+{
+    v = max(v, dpp_i<0x121>(v));
+    v = max(v, dpp_i<0x122>(v));
+    v = max(v, dpp_i<0x124>(v));
+    v = max(v, dpp_i<0x128>(v));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+// Row sums of eight values per lane, transposed: on return lane l holds the sum over its row of 16
+// lanes of m[4 b3 + 2 b2 + b1] (b_i = bits of l & 15).  Three halving exchanges (partner = lane ^ 15,
+// lane ^ 7, lane ^ 3: row_mirror, row_half_mirror, reversed quad), each lane keeping the half of the
+// values its bit selects and adding the partner's copy of that half, then one exchange with lane ^ 1.
+// 14 selects + 8 DPP adds instead of 8 x 4 DPP adds.
+__device__ __forceinline__ float row_sum_transposed(float const (&m)[8], bool b3, bool b2, bool b1)
+{
+    float w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+    {
+        float const keep = b3 ? m[i + 4] : m[i];
+        float const send = b3 ? m[i] : m[i + 4];
+        w[i] = keep + dpp_f<0x140>(send);               // row_mirror
+    }
+    float x[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+    {
+        float const keep = b2 ? w[i + 2] : w[i];
+        float const send = b2 ? w[i] : w[i + 2];
+        x[i] = keep + dpp_f<0x141>(send);               // row_half_mirror
+    }
+    float const keep = b1 ? x[1] : x[0];
+    float const send = b1 ? x[0] : x[1];
+    float const y = keep + dpp_f<0x1B>(send);           // quad_perm:[3,2,1,0]
+    return y + dpp_f<0xB1>(y);                          // quad_perm:[1,0,3,2]
+}
+
+__global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs a, long long fsteps_ll, unsigned ngroups,
+                                                                unsigned perm_stride, int ncell)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int const fsteps = (int)fsteps_ll;
+    double *acc = reinterpret_cast<double *>(smem);                               // [tile]
+    NearQueue *nq = reinterpret_cast<NearQueue *>(smem + sizeof(double)*a.tile);
+    long long *range = reinterpret_cast<long long *>(nq + 1);                     // [2]
+    double *ms_l = reinterpret_cast<double *>(range + 2);                         // [num_slots][4]
+    double *q_l = ms_l + 4*a.lay.num_slots;                                       // [num_slots][GRT_MAX_ISO]
+    float *mom = reinterpret_cast<float *>(q_l + GRT_MAX_ISO*a.lay.num_slots);    // [kMom][ncell]
+    float *invr = mom + (size_t)kMom*ncell;                                       // [fsteps + 1]
+
+    int const tid = threadIdx.x;
+    int const lane = tid & 63;
+    int const wave = tid >> 6;
+    WorkItem const wi = decode_work(a, ngroups, perm_stride);
+    int const col = wi.col, layer = wi.layer, tile_idx = wi.tile_idx, slice = wi.slice;
+    long long const nw = (long long)a.nw;
+    long long const F0l = (long long)tile_idx*a.tile;
+    long long const F1l = (F0l + a.tile < nw) ? F0l + a.tile : nw;                // [F0,F1)
+    int const F0 = (int)F0l, F1 = (int)F1l;
+    int const cell0 = F0 - fsteps;                                                // cell of mom[.][0]
+
+    double const *cs = a.colstate + (uint64_t)col*a.lay.stride;
+    double const *lay = cs + a.lay.off_lay + (uint64_t)layer*4;
+
+    for (int i = tid; i < a.tile; i += kBlock)
+    {
+        acc[i] = 0.0;
+    }
+    for (int i = tid; i < kMom*ncell; i += kBlock)
+    {
+        mom[i] = 0.f;
+    }
+    for (int i = tid; i <= fsteps; i += kBlock)
+    {
+        invr[i] = i > 0 ? 1.0f/(float)i : 0.f;
+    }
+    stage_column_state(a, cs, layer, ms_l, q_l, tid);
+    if (tid == 0)
+    {
+        candidate_range(a, lay, F0l, F1l, fsteps_ll, slice, range);
+    }
+    __syncthreads();
+    uint64_t const jbeg = (uint64_t)range[0];
+    uint64_t const jend = (uint64_t)range[1];
+
+    float const wres_f = (float)a.wres;
+    double const inv_wres = 1./a.wres;
+    float const inv_wres_f = (float)inv_wres;
+
+    // ---- near-field radius R of this (tile, layer): workgroup-uniform ----
+    // moment series: every line has |z| <= sqrt(1/4 + eta_max^2), eta_max from the largest half-width
+    // any line of the store can have in this layer (kernels.c:105-106); ratio |z|/(R+1) <= 0.128 keeps
+    // the 8-term remainder below 1e-7 of the far-wing value.  If that asks for more than the window,
+    // the whole window is "near" and no moments are formed.
+    int R;
+    bool use_moments;
+    {
+        double const gmax = a.lines.ymax*fabs(lay[0])*exp(a.lines.nmax*fabs(lay[3]));
+        double const eta = gmax*inv_wres;
+        int const r_mp = (int)ceil(7.8*sqrt(0.25 + eta*eta)) - 1;
+        int const r_lo = r_mp < 3 ? 3 : r_mp;
+        // Humlicek region 1 reaches XLIM0 <= 123.4 Doppler units from the centre: evaluate it inside
+        // the ring where that is within kRcap grid steps for every line of the tile
+        double dop = 0.;
+        for (int sl = 0; sl < a.lay.num_slots; ++sl)
+        {
+            dop = fmax(dop, ms_l[sl*4 + 3]);
+        }
+        double const w_hi = a.w0 + (double)(F1l + fsteps)*a.wres;
+        double const alpha_max = 0.83255461115*w_hi*dop;
+        double const reach = 123.4*alpha_max/(0.832554611*a.wres) + 2.;
+        int const r_reg1 = reach < (double)kRcap ? (int)reach : kRcap;
+        R = r_lo > r_reg1 ? r_lo : r_reg1;
+        use_moments = (R + 4 <= fsteps);
+        if (!use_moments)
+        {
+            R = fsteps;
+        }
+    }
+
+    int qcount = 0;                      // wave-uniform
+    double *q_amp = nq->amp[wave];
+    float *q_xi = nq->xi[wave], *q_y = nq->y[wave], *q_rep = nq->repwid[wave], *q_far = nq->far[wave];
+    int *q_idx = nq->idx[wave];
+    auto drain = [&](int count)
+    {
+        drain_near<true>(acc, q_amp, q_xi, q_y, q_rep, q_far, q_idx, count, lane);
+    };
+
+    for (uint64_t base = jbeg + (uint64_t)wave*64; base < jend; base += kBlock)
+    {
+        uint64_t const j = base + lane;
+        RawLine ln = {};
+        if (j < jend)
+        {
+            ln = load_line(a.lines, j);
+        }
+        int s = 1, lo = 1, hi = 0, c = 0;
+        bool valid = false;
+        double dwno = 0., wnoadj = 0., amp = 0.;
+        float repwid = 1.f, y = 0.f;
+        if (j < jend)
+        {
+            double const *ms = ms_l + ln.slot*4;
+            double const *q = q_l + ln.slot*GRT_MAX_ISO;
+            Prepared const p = prepare_line<true>(ln, lay, ms, q, a.w0, a.wres, inv_wres, fsteps_ll, nw);
+            if (p.s <= p.e && p.s < F1l && p.e >= F0l)
+            {
+                valid = true;
+                s = (int)p.s;
+                lo = s > F0 ? s : F0;
+                hi = (int)p.e < F1 - 1 ? (int)p.e : F1 - 1;
+                c = p.c_minus_fsteps + fsteps;
+                // RFM_voigt.c:94, rounded as the reference's REPWID (see k_gas_optics.hip)
+                double const r0 = (double)__builtin_amdgcn_rcpf((float)p.alpha);
+                repwid = (float)((double)kSqrln2*(r0*fma(-p.alpha, r0, 2.0)));
+                y = (float)((double)repwid*p.gamma);                                  // RFM_voigt.c:95
+                dwno = (double)p.s*a.wres + a.w0;                                     // kernels.c:438
+                wnoadj = p.vnn;
+                amp = p.snn*ms[2];                                                    // snn*n (kernels.c:459)
+            }
+        }
+        if (__ballot(valid) == 0ull)
+        {
+            continue;
+        }
+        bool const lorentz = (y >= 70.55f);                                           // RFM_voigt.c:97
+        float const yq = y*y;
+        float const xlim0 = sqrtf(15100.0f + y*(40.0f - y*3.6f));                     // :109
+        float xlim1 = (y >= 8.425f) ? 0.0f : sqrtf(164.0f - y*(4.3f + y*1.8f));       // :111-118
+        if (y <= 0.000001f)
+        {
+            xlim1 = xlim0;                                                            // :122-126
+        }
+        float const a0 = (float)((double)yq + 0.5);                                   // :177
+        float const d0r = a0*a0;
+        float const d2r = (float)((double)(yq + yq) - 1.0);                           // :179
+        float const xq_near = lorentz ? -1.f : xlim1*xlim1;   // |x| < XLIM1 of a Voigt line -> queue
+        float const x0q = lorentz ? 0.f : xlim0*xlim0;
+        // canonical fp32 x: x(f) = fma(float(f - c), wr, ndcr), a function of the integer offset to the
+        // line's centre index only (pre-pass and ring agree bit for bit)
+        float const dc = (float)(wnoadj - ((double)c*a.wres + a.w0));
+        float const cl = (repwid*y)*0.318309886f;                                     // 1/pi
+        float const wr = wres_f*repwid;
+        float const ndcr = -dc*repwid;
+
+        // ---- moments of the Lorentzian about the cell centre ----
+#if defined(GRT_MP_NOMOM)
+        if (use_moments && amp == 12345.678)
+#else
+        if (use_moments)
+#endif
+        {
+            float const rwr = __builtin_amdgcn_rcpf(wr);
+            float const eta2 = (yq*rwr)*rwr;
+            float const delta = dc*inv_wres_f;
+            float const amp_f = valid ? (float)(amp*(double)((cl*rwr)*rwr)) : 0.f;
+            float m[kMom];
+            {
+                float u = 1.f, pk = 0.f;                    // Re z^k, Im z^k / eta
+#pragma unroll
+                for (int k = 0; k < kMom; ++k)
+                {
+                    float const un = fmaf(delta, u, -eta2*pk);
+                    pk = fmaf(delta, pk, u);
+                    u = un;
+                    m[k] = amp_f*pk;
+                }
+            }
+            int const cmin = wave_min_s(valid ? c : 0x7fffffff);
+            int const cmax = wave_max_s(valid ? c : (int)0x80000000);
+            if (cmax - cmin < kCellLoop)
+            {
+                // the usual case: the wave's 64 lines (sorted by centre) share one or two cells.  Reduce
+                // in registers, then one LDS add per (row, moment): 32 lanes, 4 per address.
+                for (int cc = cmin; cc <= cmax; ++cc)
+                {
+                    bool const mine = valid & (c == cc);
+                    if (__ballot(mine) == 0ull)
+                    {
+                        continue;
+                    }
+                    float mm[kMom];
+#pragma unroll
+                    for (int k = 0; k < kMom; ++k)
+                    {
+                        mm[k] = mine ? m[k] : 0.f;
+                    }
+                    float const t = row_sum_transposed(mm, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0);
+                    if ((lane & 1) == 0)
+                    {
+                        unsafeAtomicAdd(&mom[((lane >> 1) & 7)*ncell + (cc - cell0)], t);
+                    }
+                }
+            }
+            else if (valid)
+            {
+#pragma unroll
+                for (int k = 0; k < kMom; ++k)
+                {
+                    unsafeAtomicAdd(&mom[k*ncell + (c - cell0)], m[k]);
+                }
+            }
+        }
+
+        // ---- pre-pass: near-centre points (regions 2-4) anywhere in the window, and region-1 points
+        // beyond the near field; each lane walks the grid points around ITS OWN line centre ----
+        {
+            bool const voigt_line = valid & !lorentz;
+            float const rwr = __builtin_amdgcn_rcpf(wr);
+            int const reach1 = voigt_line ? (int)(sqrtf(xq_near)*rwr) + 1 : -1;
+            int reach0 = voigt_line ? (int)(xlim0*rwr) + 1 : -1;
+            reach0 = reach0 > R ? reach0 : -1;
+            int const reach = reach1 > reach0 ? reach1 : reach0;
+#if defined(GRT_MP_NOPREPASS)
+            int const rmax = wave_max_s(reach) > 1000000 ? 1 : -1;
+#else
+            int const rmax = wave_max_s(reach);
+#endif
+            for (int r = -rmax; r <= rmax; ++r)
+            {
+                int const f = c + r;
+                bool const cand = (r >= -reach) & (r <= reach) & (f >= lo) & (f <= hi);
+                float const xi = fmaf((float)r, wr, ndcr);
+                float const xq = xi*xi;
+                bool const inner = cand & (xq < x0q);
+                bool const near = inner & (xq < xq_near);
+                bool const beyond = (r > R) | (r < -R);
+                if (inner & !near & beyond)
+                {
+                    // region 1 minus the Lorentzian the moments supply (see k_gas_optics.hip):
+                    // cl (1.5 XQ - 0.5 A0) / [(D0+XQ(D2+XQ)) (XQ+YQ)]
+                    float const den = fmaf(xq, d2r + xq, d0r)*fmaf(xi, xi, yq);
+                    float const corr = cl*fmaf(1.5f, xq, -0.5f*a0)*__builtin_amdgcn_rcpf(den);
+                    GRT_ACC_ADD(&acc[f - F0], amp*(double)corr);
+                }
+                unsigned long long const mk = __ballot(near);
+                if (mk != 0ull)
+                {
+                    if (qcount > kQueue - 64)
+                    {
+                        drain(qcount);
+                        qcount = 0;
+                    }
+                    if (near)
+                    {
+                        int const pos = qcount + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32),
+                                        __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                        q_amp[pos] = amp;
+                        q_xi[pos] = voigt_x(dwno, f - s, a.wres, wnoadj, repwid);
+                        q_y[pos] = y;
+                        q_rep[pos] = repwid;
+                        // the Lorentzian this point also receives (ring: the very same instruction
+                        // sequence, so it cancels exactly; moments: to ~1e-8), to be taken back
+                        q_far[pos] = cl*__builtin_amdgcn_rcpf(fmaf(xi, xi, yq));
+                        q_idx[pos] = f - F0;
+                    }
+                    qcount += __popcll(mk);
+                }
+            }
+        }
+
+        // ---- near field: |f - c| <= R, clipped to the line's window and the tile ----
+        int const lo_n = valid ? (lo > c - R ? lo : c - R) : 1;
+        int const hi_n = valid ? (hi < c + R ? hi : c + R) : 0;
+        int const fb = wave_min_s(lo_n <= hi_n ? lo_n : 0x7fffffff);
+        int const fe = wave_max_s(lo_n <= hi_n ? hi_n : (int)0x80000000);
+        if (fb > fe)
+        {
+            continue;
+        }
+        float const mid = 0.5f*(float)(lo_n + hi_n) - (float)c;
+        float const half = lo_n <= hi_n ? 0.5f*(float)(hi_n - lo_n) + 0.25f : -1.f;
+#if defined(GRT_MP_NORING)
+        if (amp == 12345.678) acc[lane] = amp + cl + wr + ndcr + d0r + d2r + a0 + mid + half + xq_near + x0q;
+        for (int fbp = fb; fbp <= fe && amp == 12345.678; fbp += 16)
+#else
+        for (int fbp = fb; fbp <= fe; fbp += 16)
+#endif
+        {
+            double token = 0.;
+            float slotf = (float)(lane & 15);
+            float const base_rel = (float)(fbp - c);
+#pragma unroll 4
+            for (int t = 0; t < 16; ++t)
+            {
+                float const rel = base_rel + slotf;
+                float const xi = fmaf(rel, wr, ndcr);
+                float const xq = xi*xi;
+                float const d = fmaf(xi, xi, yq);
+                // region 1 (RFM_voigt.c:172-183): K = c (A0+XQ)/(D0+XQ(D2+XQ)); elsewhere the Lorentzian
+                bool const reg1 = (xq >= xq_near) & (xq < x0q);
+                float const den = reg1 ? fmaf(xq, d2r + xq, d0r) : d;
+                float const num = reg1 ? cl*(a0 + xq) : cl;
+                float kf = (fabsf(rel - mid) <= half) ? num*__builtin_amdgcn_rcpf(den) : 0.f;
+                asm volatile("" : "+v"(kf));        // select in fp32, then widen once
+                token = fma(amp, (double)kf, token);
+                token = row_pass(token);
+                slotf = dpp_f<0x121>(slotf);
+            }
+            int const f = fbp + (int)slotf;
+            if (f <= fe)
+            {
+                GRT_ACC_ADD(&acc[f - F0], token);
+            }
+        }
+    }
+    drain(qcount);
+    __syncthreads();
+
+    // ---- far field: every grid point of the tile gathers the moment series of the cells at
+    // distance R < |f - c| <= fsteps (the cells' windows, kernels.c:435-437) ----
+#if defined(GRT_MP_NOFAR)
+    if (use_moments && lay[0] == 12345.678)
+#else
+    if (use_moments)
+#endif
+    {
+        for (int i = tid; i < F1 - F0; i += kBlock)
+        {
+            double sum = 0.;
+            for (int r = R + 1; r <= fsteps; ++r)
+            {
+                float const u = invr[r];
+                float const *ma = mom + (i + fsteps - r);       // cell f - r: offset +r
+                float const *mb = mom + (i + fsteps + r);       // cell f + r: offset -r
+                float pa = ma[(kMom - 1)*ncell], pb = mb[(kMom - 1)*ncell];
+#pragma unroll
+                for (int k = kMom - 2; k >= 0; --k)
+                {
+                    pa = fmaf(pa, u, ma[k*ncell]);
+                    pb = fmaf(pb, -u, mb[k*ncell]);
+                }
+                sum += (double)((pa + pb)*(u*u));
+            }
+            acc[i] += sum;
+        }
+        __syncthreads();
+    }
+    write_tile(a, acc, cs, col, layer, slice, F0l, F1l, tid);
+}
+
+size_t mp_lds_bytes(int tile, int ncell, int fsteps, int num_slots)
+{
+    return sizeof(double)*tile + sizeof(NearQueue) + 2*sizeof(long long) + sizeof(double)*num_slots*(4 + GRT_MAX_ISO)
+           + sizeof(float)*((size_t)kMom*ncell + fsteps + 1);
+}
+
+} // namespace
+
+// 0 when the moment kernel does not apply to this grid (narrow windows, or a window that does not fit LDS).
+extern "C" int grt_gas_optics_mp_applicable(GrtGasOpticsArgs const *a)
+{
+    long long const fsteps = (long long)ceil((double)25.f/a->wres);   // kernels.c:417
+    if (fsteps < 16 || fsteps > 4096)
+    {
+        return 0;
+    }
+    return mp_lds_bytes(a->tile, a->tile + 2*(int)fsteps, (int)fsteps, a->lay.num_slots) <= 64*1024;
+}
+
+extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
+{
+    if (a->tile <= 0 || (a->tile % 64) != 0 || a->nslice < 1 || a->ncol < 1 || !grt_gas_optics_mp_applicable(a))
+    {
+        return (int)hipErrorInvalidValue;
+    }
+    long long const fsteps = (long long)ceil((double)25.f/a->wres);
+    if (a->nw > 0x7fffffffull)
+    {
+        return (int)hipErrorInvalidValue;
+    }
+    unsigned long long const tiles = (a->nw + a->tile - 1)/a->tile;
+    unsigned long long const ngroups = tiles*a->nslice;
+    unsigned long long const blocks = ngroups*a->lay.num_layers*a->ncol;
+    if (blocks == 0 || blocks > 0x7fffffffull)
+    {
+        return (int)hipErrorInvalidValue;
+    }
+    int const ncell = a->tile + 2*(int)fsteps;
+    size_t const lds = mp_lds_bytes(a->tile, ncell, (int)fsteps, a->lay.num_slots);
+    hipLaunchKernelGGL(gas_optics_mp_kernel, dim3((unsigned)blocks), dim3(kBlock), lds, (hipStream_t)stream, *a, fsteps,
+                       (unsigned)ngroups, golden_stride(ngroups), ncell);
+    return (int)hipGetLastError();
+}

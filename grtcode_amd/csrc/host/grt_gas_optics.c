@@ -675,7 +675,8 @@ EXTERN int grt_gas_optics_tune(GasOptics_t *gas_optics, int tile, int nslice, in
         GRT_REQUIRE_RANGE(nslice, 1, 64);
         im->nslice = nslice;
     }
-    im->fast = fast ? 1 : 0;
+    GRT_REQUIRE_RANGE(fast, 0, 2);
+    im->fast = fast;
     return GRTCODE_SUCCESS;
 }
 
@@ -709,6 +710,8 @@ static int build_store(GasOptics_t *go)
     }
     im->store.n = total;
     im->store.dmax = 0.;
+    im->store.ymax = 0.;
+    im->store.nmax = 0.;
     if (total == 0)
     {
         im->store_dirty = 0;
@@ -750,6 +753,9 @@ static int build_store(GasOptics_t *go)
         iso[k] = h->iso[j]; slot[k] = keys[k].slot;
         double const ad = fabs((double)h->delta[j]);
         if (ad > im->store.dmax) im->store.dmax = ad;
+        if ((double)h->yair[j] > im->store.ymax) im->store.ymax = (double)h->yair[j];
+        if ((double)h->yself[j] > im->store.ymax) im->store.ymax = (double)h->yself[j];
+        if (fabs((double)h->nexp[j]) > im->store.nmax) im->store.nmax = fabs((double)h->nexp[j]);
     }
     free(keys);
     int rc = grt_dev_alloc(go->device, &im->store_block, bytes);
@@ -912,14 +918,16 @@ int grt_column_state(GasOptics_t const *go, fp_t const *p_mb, fp_t const *t, fp_
     return GRTCODE_SUCCESS;
 }
 
-static void auto_tune(GasOptics_t const *go, int ncol, int *tile, int *nslice)
+static void auto_tune(GasOptics_t const *go, int ncol, int moments, int *tile, int *nslice)
 {
     GrtGasOpticsImpl const *im = impl_of(go);
     uint64_t const nw = go->grid.n;
     int t = im->tile;
     if (t == 0)
     {
-        t = nw >= 1024 ? 1024 : (int)(((nw + 63)/64)*64);
+        /* the moment kernel keeps tile + 2*fsteps cells of 8 moments in LDS next to the tile */
+        int const want = moments ? 512 : 1024;
+        t = nw >= (uint64_t)want ? want : (int)(((nw + 63)/64)*64);
     }
     int ns = im->nslice;
     if (ns == 0)
@@ -951,8 +959,20 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
     a->ncol = ncol;
     a->tau = tau;
     a->tau_col_stride = tau_col_stride;
-    auto_tune(go, ncol, &a->tile, &a->nslice);
     a->fast = im->fast;
+    if (im->fast == 1)
+    {
+        /* fused form: far wings by cell moments where the grid's windows are wide enough for that */
+        auto_tune(go, ncol, 1, &a->tile, &a->nslice);
+        if (!grt_gas_optics_mp_applicable(a))
+        {
+            a->fast = 2;
+        }
+    }
+    if (a->fast != 1)
+    {
+        auto_tune(go, ncol, 0, &a->tile, &a->nslice);
+    }
     return GRTCODE_SUCCESS;
 }
 

@@ -66,8 +66,8 @@ class G1Workload:
         self.go_lw, self.grid_lw = build_band(device, lw_grid, self.lw_lines, self.lw_files, num_levels)
         self.go_sw, self.grid_sw = build_band(device, sw_grid, self.sw_lines, self.sw_files, num_levels)
         if fast:
-            self.go_lw.tune(fast=1)
-            self.go_sw.tune(fast=1)
+            self.go_lw.tune(fast=fast)
+            self.go_sw.tune(fast=fast)
         self.emis = np.full(self.grid_lw.n, 0.98)
         self.albedo = np.full(self.grid_sw.n, 0.2)
         self.solar = api.create_solar_flux(self.grid_sw, self.sw_files["solar"])
