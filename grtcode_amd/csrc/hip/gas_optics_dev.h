@@ -131,24 +131,67 @@ __device__ __forceinline__ float quot(float a, float b)
     return FAST ? a*__builtin_amdgcn_rcpf(b) : a/b;
 }
 
+// Thresholds of RFM_voigt.c:111-126 for one (x, y): which formula a near-centre point takes.
+struct VoigtLimits
+{
+    float xlim1, xlim2, xlim3, xlim4;
+};
+
 template <bool FAST>
+__device__ __forceinline__ VoigtLimits voigt_limits(float y)
+{
+    VoigtLimits l;
+    // the reference takes the square roots in double and narrows; the correctly rounded sqrtf gives
+    // the same float (53 >= 2*24 + 2 bits)
+    float const r1 = 164.0f - y*(4.3f + y*1.8f);
+    l.xlim1 = (y >= 8.425f) ? 0.0f : (FAST ? sqrtf(r1) : (float)sqrt((double)r1));
+    l.xlim2 = 6.8f - y;
+    l.xlim3 = 2.4f*y;
+    l.xlim4 = 18.1f*y + 1.65f;
+    if (y <= 0.000001f)
+    {
+        // RFM_voigt.c:122-126: no Lorentz width -> regions 1 and 2 are switched off
+        float const r0 = 15100.0f + y*(40.0f - y*3.6f);
+        float const xlim0 = FAST ? sqrtf(r0) : (float)sqrt((double)r0);
+        l.xlim1 = xlim0;
+        l.xlim2 = xlim0;
+    }
+    return l;
+}
+
+// 0: regions 1-3 (one rational function of x^2), 1: region 4 inner sums (|x| <= XLIM4), 2: region 4
+// outer sums.  Same tests, same order as voigt_near below.
+template <bool FAST>
+__device__ __forceinline__ int voigt_class(float xi, float y)
+{
+    VoigtLimits const l = voigt_limits<FAST>(y);
+    float const abx = fabsf(xi);
+    if ((abx >= l.xlim1) | (abx >= l.xlim2) | (abx < l.xlim3))
+    {
+        return 0;
+    }
+    return abx <= l.xlim4 ? 1 : 2;
+}
+
+// ONLY = -1: any region; 0 / 1 / 2: the caller has sorted its points with voigt_class and only that
+// class's code is generated (no divergence inside a batch of 64 points).
+template <bool FAST, int ONLY = -1>
 __device__ __forceinline__ double voigt_near(float xi, float y)
 {
     float const yq = y*y;
     float const abx = fabsf(xi);
     float const xq = abx*abx;
-    float xlim1 = (y >= 8.425f) ? 0.0f : (float)sqrt((double)(164.0f - y*(4.3f + y*1.8f)));
-    float xlim2 = 6.8f - y;
-    float const xlim3 = 2.4f*y;
-    float const xlim4 = 18.1f*y + 1.65f;
-    if (y <= 0.000001f)
+    VoigtLimits lim = {0.f, 0.f, 0.f, 0.f};
+    if (ONLY <= 0)
     {
-        // RFM_voigt.c:122-126: no Lorentz width -> regions 1 and 2 are switched off
-        float const xlim0 = (float)sqrt((double)(15100.0f + y*(40.0f - y*3.6f)));
-        xlim1 = xlim0;
-        xlim2 = xlim0;
+        lim = voigt_limits<FAST>(y);
     }
-    if (abx >= xlim1)
+    else
+    {
+        lim.xlim4 = 18.1f*y + 1.65f;
+    }
+    float const xlim1 = lim.xlim1, xlim2 = lim.xlim2, xlim3 = lim.xlim3, xlim4 = lim.xlim4;
+    if (ONLY <= 0 && abx >= xlim1)
     {
         float const a0 = (float)((double)yq + 0.5);
         float const d0 = a0*a0;
@@ -156,7 +199,7 @@ __device__ __forceinline__ double voigt_near(float xi, float y)
         float const d = quot<FAST>(kRsqrpi, d0 + xq*(d2 + xq));
         return (double)(d*y*(a0 + xq));
     }
-    if (abx >= xlim2)
+    if (ONLY <= 0 && abx >= xlim2)
     {
         float const h0 = 0.5625f + yq*(4.5f + yq*(10.5f + yq*(6.0f + yq)));
         float const h2 = -4.5f + yq*(9.0f + yq*(6.0f + yq*4.0f));
@@ -168,7 +211,7 @@ __device__ __forceinline__ double voigt_near(float xi, float y)
         float const d = quot<FAST>(kRsqrpi, h0 + xq*(h2 + xq*(h4 + xq*(h6 + xq))));
         return (double)(d*y*(e0 + xq*(e2 + xq*(e4 + xq))));
     }
-    if (abx < xlim3)
+    if (ONLY == 0 || (ONLY < 0 && abx < xlim3))
     {
         float const z0 = 272.1014f + y*(1280.829f + y*(2802.870f + y*(3764.966f
                          + y*(3447.629f + y*(2256.981f + y*(1074.409f + y*(369.1989f
@@ -205,8 +248,12 @@ __device__ __forceinline__ double voigt_near(float xi, float y)
     float const y0 = 1.5f, y0py0 = 3.f, y0q = 2.25f;
     float const ypy0 = y + y0;
     float const ypy0q = ypy0*ypy0;
+    // (the fused form keeps the reference's operation order here: the differences xm - xp and
+    // mq*mf - y0*ym cancel, so the reference's own fp32 rounding is ~1e-6 of the result and only the
+    // same sequence of roundings reproduces it; only the divisions become hardware reciprocals and
+    // exp(-x^2) the hardware exp2 after an fp64 range reduction)
     double k = 0.0;
-    if (abx <= xlim4)
+    if (ONLY == 1 || (ONLY < 0 && abx <= xlim4))
     {
 #pragma unroll
         for (int J = 0; J < 6; ++J)
@@ -237,7 +284,7 @@ __device__ __forceinline__ double voigt_near(float xi, float y)
             k = k + (double)quot<FAST>(C[J]*(mq*mf - y0*ym) + S[J]*yf*xm, mq + y0q)
                   + (double)quot<FAST>(C[J]*(pq*pf - y0*yp) - S[J]*yf*xp, pq + y0q);
         }
-        k = (double)y*k + exp((double)(-xq));
+        k = (double)y*k + (FAST ? exp_fast((double)(-xq)) : exp((double)(-xq)));
     }
     return k;
 }

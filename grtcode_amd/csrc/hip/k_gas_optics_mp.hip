@@ -37,7 +37,8 @@ constexpr int kCellLoop = 4;    // waves whose lines span at most this many cell
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+    int const b = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(b, b, CTRL, 0xf, 0xf, false));
 }
 
 // row_ror:1 (DPP control 0x121): rotation by one lane inside each row of 16 lanes
@@ -52,7 +53,7 @@ __device__ __forceinline__ double row_pass(double v)
 template <int CTRL>
 __device__ __forceinline__ int dpp_i(int v)
 {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
 }
 
 // Wave-wide integer min / max as scalars: rotations inside the rows of 16 lanes (every lane of a row
@@ -107,13 +108,41 @@ __device__ __forceinline__ float row_sum_transposed(float const (&m)[8], bool b3
     return y + dpp_f<0xB1>(y);                          // quad_perm:[1,0,3,2]
 }
 
+// Near-centre points (Humlicek regions 1-4 inside XLIM1) wait in per-wave LDS queues, one queue per
+// class of formula (voigt_class), so that a batch of 64 points runs ONE formula with all lanes busy:
+// evaluated unsorted, a batch pays for every formula present in it (~4x the work of the usual mix).
+constexpr int kClasses = 3;
+constexpr int kMpQueue = 96;    // entries per (class, wave): batches of 64 leave at most 63 behind
+
+struct MpQueue
+{
+    float amp[kClasses][kWaves][kMpQueue];      // S(T)*N_s of the line (fp32: 6e-8 of that line's value)
+    float xi[kClasses][kWaves][kMpQueue];
+    float y[kClasses][kWaves][kMpQueue];
+    float repwid[kClasses][kWaves][kMpQueue];
+    float far[kClasses][kWaves][kMpQueue];      // the Lorentzian this point also receives, to be taken back
+    unsigned short idx[kClasses][kWaves][kMpQueue];   // accumulator index f - F0
+};
+
+template <int CLASS>
+__device__ __forceinline__ void drain_class(double *acc, MpQueue const *q, int wave, int first, int count, int lane)
+{
+    for (int i = first + lane; i < first + count; i += 64)
+    {
+        float const rep = q->repwid[CLASS][wave][i];
+        double const k = (double)(kRsqrpi*rep)*voigt_near<true, CLASS>(q->xi[CLASS][wave][i], q->y[CLASS][wave][i])
+                         - (double)q->far[CLASS][wave][i];                                  // RFM_voigt.c:278
+        GRT_ACC_ADD(&acc[q->idx[CLASS][wave][i]], (double)q->amp[CLASS][wave][i]*k);        // kernels.c:459
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs a, long long fsteps_ll, unsigned ngroups,
                                                                 unsigned perm_stride, int ncell)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int const fsteps = (int)fsteps_ll;
     double *acc = reinterpret_cast<double *>(smem);                               // [tile]
-    NearQueue *nq = reinterpret_cast<NearQueue *>(smem + sizeof(double)*a.tile);
+    MpQueue *nq = reinterpret_cast<MpQueue *>(smem + sizeof(double)*a.tile);
     long long *range = reinterpret_cast<long long *>(nq + 1);                     // [2]
     double *ms_l = reinterpret_cast<double *>(range + 2);                         // [num_slots][4]
     double *q_l = ms_l + 4*a.lay.num_slots;                                       // [num_slots][GRT_MAX_ISO]
@@ -190,13 +219,17 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
         }
     }
 
-    int qcount = 0;                      // wave-uniform
-    double *q_amp = nq->amp[wave];
-    float *q_xi = nq->xi[wave], *q_y = nq->y[wave], *q_rep = nq->repwid[wave], *q_far = nq->far[wave];
-    int *q_idx = nq->idx[wave];
-    auto drain = [&](int count)
+    int qcount[kClasses] = {0, 0, 0};    // wave-uniform
+    auto drain = [&](int cls, int first, int count)
     {
-        drain_near<true>(acc, q_amp, q_xi, q_y, q_rep, q_far, q_idx, count, lane);
+#if defined(GRT_MP_NODRAIN)
+        if (lay[0] == 12345.678)
+#endif
+        {
+            if (cls == 0) drain_class<0>(acc, nq, wave, first, count, lane);
+            else if (cls == 1) drain_class<1>(acc, nq, wave, first, count, lane);
+            else drain_class<2>(acc, nq, wave, first, count, lane);
+        }
     };
 
     for (uint64_t base = jbeg + (uint64_t)wave*64; base < jend; base += kBlock)
@@ -315,59 +348,95 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
             }
         }
 
-        // ---- pre-pass: near-centre points (regions 2-4) anywhere in the window, and region-1 points
-        // beyond the near field; each lane walks the grid points around ITS OWN line centre ----
+        // ---- pre-pass 1: near-centre points (|x| < XLIM1: Humlicek regions 2-4) go to the queue.
+        // Each lane walks the few grid points around ITS OWN line centre: the integers r with
+        // |r - delta| < XLIM1/wr (a superset is enumerated; the canonical x decides) ----
+        float const rwr = __builtin_amdgcn_rcpf(wr);
+        bool const voigt_line = valid & !lorentz;
         {
-            bool const voigt_line = valid & !lorentz;
-            float const rwr = __builtin_amdgcn_rcpf(wr);
-            int const reach1 = voigt_line ? (int)(sqrtf(xq_near)*rwr) + 1 : -1;
-            int reach0 = voigt_line ? (int)(xlim0*rwr) + 1 : -1;
-            reach0 = reach0 > R ? reach0 : -1;
-            int const reach = reach1 > reach0 ? reach1 : reach0;
+            float const delta = dc*inv_wres_f;
+            float const span = fmaf(sqrtf(fmaxf(xq_near, 0.f))*rwr, 1.000001f, 1e-6f);
+            int const r_first = (int)floorf(delta - span) + 1;      // smallest integer > delta - span
+            int const r_last = (int)ceilf(delta + span) - 1;        // largest integer < delta + span
+            int const count = voigt_line ? r_last - r_first + 1 : 0;
 #if defined(GRT_MP_NOPREPASS)
-            int const rmax = wave_max_s(reach) > 1000000 ? 1 : -1;
+            int const nmax = wave_max_s(count) > 1000000 ? 1 : 0;
 #else
-            int const rmax = wave_max_s(reach);
+            int const nmax = wave_max_s(count);
 #endif
-            for (int r = -rmax; r <= rmax; ++r)
+            for (int t = 0; t < nmax; ++t)
             {
+                int const r = r_first + t;
                 int const f = c + r;
-                bool const cand = (r >= -reach) & (r <= reach) & (f >= lo) & (f <= hi);
                 float const xi = fmaf((float)r, wr, ndcr);
-                float const xq = xi*xi;
-                bool const inner = cand & (xq < x0q);
-                bool const near = inner & (xq < xq_near);
-                bool const beyond = (r > R) | (r < -R);
-                if (inner & !near & beyond)
+                bool const near = (t < count) & (f >= lo) & (f <= hi) & (xi*xi < xq_near);
+                if (__ballot(near) != 0ull)
                 {
-                    // region 1 minus the Lorentzian the moments supply (see k_gas_optics.hip):
-                    // cl (1.5 XQ - 0.5 A0) / [(D0+XQ(D2+XQ)) (XQ+YQ)]
-                    float const den = fmaf(xq, d2r + xq, d0r)*fmaf(xi, xi, yq);
-                    float const corr = cl*fmaf(1.5f, xq, -0.5f*a0)*__builtin_amdgcn_rcpf(den);
-                    GRT_ACC_ADD(&acc[f - F0], amp*(double)corr);
+                    float const xr = voigt_x(dwno, f - s, a.wres, wnoadj, repwid);     // the reference's x
+                    int const cls = near ? voigt_class<true>(xr, y) : -1;
+#pragma unroll
+                    for (int q = 0; q < kClasses; ++q)
+                    {
+                        unsigned long long const mk = __ballot(cls == q);
+                        if (mk == 0ull)
+                        {
+                            continue;
+                        }
+                        int const npush = __popcll(mk);
+                        if (qcount[q] + npush > kMpQueue)
+                        {
+                            drain(q, 0, qcount[q]);
+                            qcount[q] = 0;
+                        }
+                        if (cls == q)
+                        {
+                            int const pos = qcount[q] + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32),
+                                            __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                            nq->amp[q][wave][pos] = (float)amp;
+                            nq->xi[q][wave][pos] = xr;
+                            nq->y[q][wave][pos] = y;
+                            nq->repwid[q][wave][pos] = repwid;
+                            // the Lorentzian this point also receives (ring: the very same instruction
+                            // sequence, so it cancels exactly; moments: to ~1e-8), to be taken back
+                            nq->far[q][wave][pos] = cl*__builtin_amdgcn_rcpf(fmaf(xi, xi, yq));
+                            nq->idx[q][wave][pos] = (unsigned short)(f - F0);
+                        }
+                        qcount[q] += npush;
+                        if (qcount[q] >= 64)
+                        {
+                            qcount[q] -= 64;
+                            drain(q, qcount[q], 64);        // a full batch off the top
+                        }
+                    }
                 }
-                unsigned long long const mk = __ballot(near);
-                if (mk != 0ull)
+            }
+        }
+
+        // ---- pre-pass 2: region-1 points beyond the near field (Doppler widths of several grid steps:
+        // fine grids, high wavenumbers), as a correction to the Lorentzian the moments supply:
+        // cl (1.5 XQ - 0.5 A0) / [(D0+XQ(D2+XQ)) (XQ+YQ)]   (see k_gas_optics.hip) ----
+        {
+            int const reach0 = voigt_line ? (int)(xlim0*rwr) + 1 : -1;
+#if defined(GRT_MP_NOPREPASS)
+            int const rmax = wave_max_s(reach0) > 1000000 ? 1 : -1;
+#else
+            int const rmax = wave_max_s(reach0);
+#endif
+            for (int rr = R + 1; rr <= rmax; ++rr)
+            {
+#pragma unroll
+                for (int sgn = -1; sgn <= 1; sgn += 2)
                 {
-                    if (qcount > kQueue - 64)
+                    int const r = sgn*rr;
+                    int const f = c + r;
+                    float const xi = fmaf((float)r, wr, ndcr);
+                    float const xq = xi*xi;
+                    if ((rr <= reach0) & (f >= lo) & (f <= hi) & (xq < x0q) & (xq >= xq_near))
                     {
-                        drain(qcount);
-                        qcount = 0;
+                        float const den = fmaf(xq, d2r + xq, d0r)*fmaf(xi, xi, yq);
+                        float const corr = cl*fmaf(1.5f, xq, -0.5f*a0)*__builtin_amdgcn_rcpf(den);
+                        GRT_ACC_ADD(&acc[f - F0], amp*(double)corr);
                     }
-                    if (near)
-                    {
-                        int const pos = qcount + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32),
-                                        __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-                        q_amp[pos] = amp;
-                        q_xi[pos] = voigt_x(dwno, f - s, a.wres, wnoadj, repwid);
-                        q_y[pos] = y;
-                        q_rep[pos] = repwid;
-                        // the Lorentzian this point also receives (ring: the very same instruction
-                        // sequence, so it cancels exactly; moments: to ~1e-8), to be taken back
-                        q_far[pos] = cl*__builtin_amdgcn_rcpf(fmaf(xi, xi, yq));
-                        q_idx[pos] = f - F0;
-                    }
-                    qcount += __popcll(mk);
                 }
             }
         }
@@ -417,7 +486,11 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
             }
         }
     }
-    drain(qcount);
+#pragma unroll
+    for (int q = 0; q < kClasses; ++q)
+    {
+        drain(q, 0, qcount[q]);
+    }
     __syncthreads();
 
     // ---- far field: every grid point of the tile gathers the moment series of the cells at
@@ -454,7 +527,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
 
 size_t mp_lds_bytes(int tile, int ncell, int fsteps, int num_slots)
 {
-    return sizeof(double)*tile + sizeof(NearQueue) + 2*sizeof(long long) + sizeof(double)*num_slots*(4 + GRT_MAX_ISO)
+    return sizeof(double)*tile + sizeof(MpQueue) + 2*sizeof(long long) + sizeof(double)*num_slots*(4 + GRT_MAX_ISO)
            + sizeof(float)*((size_t)kMom*ncell + fsteps + 1);
 }
 
