@@ -34,8 +34,9 @@ typedef struct GrtLineStore
     uint8_t const *iso;     /* 1-based isotopologue id */
     uint8_t const *slot;    /* molecule slot (order of add_molecule) */
     double dmax;            /* max |delta| over the store: bound on the pressure shift */
-    double ymax;            /* max of yair, yself over the store [cm-1 atm-1] and */
-    double nmax;            /* max |nexp|: bound on the Lorentz half-width of any line in a layer */
+    double nmax;            /* max |nexp| over the store and, per molecule slot, the largest yair / yself */
+    float yair_max[GRT_MAX_SLOTS];   /* [cm-1 atm-1]: together a bound on the Lorentz half-width of any */
+    float yself_max[GRT_MAX_SLOTS];  /* line in a layer (kernels.c:105-106), see k_gas_optics_mp.hip */
 } GrtLineStore;
 
 /* Per-column layer state prepared on the host in the reference's arithmetic

@@ -190,14 +190,19 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
 
     // ---- near-field radius R of this (tile, layer): workgroup-uniform ----
     // moment series: every line has |z| <= sqrt(1/4 + eta_max^2), eta_max from the largest half-width
-    // any line of the store can have in this layer (kernels.c:105-106); ratio |z|/(R+1) <= 0.128 keeps
+    // any line of the store can have in this layer (kernels.c:105-106: per molecule, the largest
+    // air- and self-broadening coefficients times this layer's partial pressures); ratio |z|/(R+1) <= 0.128 keeps
     // the 8-term remainder below 1e-7 of the far-wing value.  If that asks for more than the window,
     // the whole window is "near" and no moments are formed.
     int R;
     bool use_moments;
     {
-        double const gmax = a.lines.ymax*fabs(lay[0])*exp(a.lines.nmax*fabs(lay[3]));
-        double const eta = gmax*inv_wres;
+        double gmax = 0.;       // max over slots of yair_max (P - Ps) + yself_max Ps
+        for (int sl = 0; sl < a.lay.num_slots; ++sl)
+        {
+            gmax = fmax(gmax, (double)a.lines.yair_max[sl]*fabs(ms_l[sl*4 + 1]) + (double)a.lines.yself_max[sl]*fabs(ms_l[sl*4]));
+        }
+        double const eta = gmax*exp(a.lines.nmax*fabs(lay[3]))*inv_wres;
         int const r_mp = (int)ceil(7.8*sqrt(0.25 + eta*eta)) - 1;
         int const r_lo = r_mp < 3 ? 3 : r_mp;
         // Humlicek region 1 reaches XLIM0 <= 123.4 Doppler units from the centre: evaluate it inside

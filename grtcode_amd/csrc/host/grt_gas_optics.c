@@ -710,8 +710,9 @@ static int build_store(GasOptics_t *go)
     }
     im->store.n = total;
     im->store.dmax = 0.;
-    im->store.ymax = 0.;
     im->store.nmax = 0.;
+    memset(im->store.yair_max, 0, sizeof(im->store.yair_max));
+    memset(im->store.yself_max, 0, sizeof(im->store.yself_max));
     if (total == 0)
     {
         im->store_dirty = 0;
@@ -753,8 +754,8 @@ static int build_store(GasOptics_t *go)
         iso[k] = h->iso[j]; slot[k] = keys[k].slot;
         double const ad = fabs((double)h->delta[j]);
         if (ad > im->store.dmax) im->store.dmax = ad;
-        if ((double)h->yair[j] > im->store.ymax) im->store.ymax = (double)h->yair[j];
-        if ((double)h->yself[j] > im->store.ymax) im->store.ymax = (double)h->yself[j];
+        if (h->yair[j] > im->store.yair_max[keys[k].slot]) im->store.yair_max[keys[k].slot] = h->yair[j];
+        if (h->yself[j] > im->store.yself_max[keys[k].slot]) im->store.yself_max[keys[k].slot] = h->yself[j];
         if (fabs((double)h->nexp[j]) > im->store.nmax) im->store.nmax = fabs((double)h->nexp[j]);
     }
     free(keys);

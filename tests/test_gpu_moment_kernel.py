@@ -1,0 +1,100 @@
+"""The fused form's production kernel (fast=1: far wings by cell moments, k_gas_optics_mp.hip) against the oracle.
+
+Every case states which branch of the kernel it is there for.  Tolerance of the fused form: 2e-6 of each layer's
+largest optical depth (the reference's own fp32 rounding in the Humlicek core is ~1e-6 of a line peak; the moment
+series itself is cut below 1e-7 of the far-wing value), fluxes 1e-3 W m-2 (BASELINE.json) -- in practice ~1e-6.
+The ring kernel (fast=2, every window point evaluated) is compared as well: the two fused forms share everything
+but the far wings, so they must agree much more closely than either does with the reference.
+"""
+import numpy as np
+import pytest
+
+from grtcode_amd import api, synthetic as syn
+from scenario import Band
+from test_gpu_gas_optics import tau_close
+
+pytestmark = pytest.mark.gpu
+FAST_TOL = 2e-6
+
+
+def run(band, device, col, fast, tile=0, nslice=0, from_file=False):
+    V = col["p"].size
+    go, grid = band.gas_optics(device, V, from_file=from_file)
+    go.tune(tile=tile, nslice=nslice, fast=fast)
+    band.set_column(go, col)
+    opt = api.OpticsObject(V - 1, grid, device)
+    go.calculate_optical_depth(col["p"], col["t"], opt)
+    tau = opt.read()[0]
+    opt.destroy()
+    go.destroy()
+    return tau
+
+
+def check(band, device, oracle, lib, col, **kw):
+    want = band.oracle_tau(oracle, oracle, lib, col)
+    mp = run(band, device, col, 1, **kw)
+    ring = run(band, device, col, 2, **kw)
+    e_mp, e_ring, e_between = tau_close(mp, want), tau_close(ring, want), tau_close(mp, ring)
+    print(f"moment kernel vs oracle {e_mp:.2e}; ring kernel vs oracle {e_ring:.2e}; moment vs ring {e_between:.2e}")
+    assert e_mp < FAST_TOL
+    assert e_ring < FAST_TOL
+    assert e_between < 5e-7
+    return mp, want
+
+
+@pytest.mark.parametrize("tile,nslice", [(0, 0), (64, 1), (128, 3), (1024, 2)])
+def test_dense_lines_many_per_cell(tmp_path, oracle, lib, device, tile, nslice):
+    """~100 lines per grid point: waves whose 64 lines share one or two cells (register reduction of the moments),
+    tile edges every 64/128 points, line slices combined with global atomics."""
+    band = Band(str(tmp_path), 900.0, 1100.0, 1.0, 20000)
+    check(band, device, oracle, lib, syn.profile(2, 13), tile=tile, nslice=nslice)
+
+
+def test_sparse_lines_many_cells_per_wave(tmp_path, oracle, lib, device):
+    """One line every ~10 grid points: a wave's lines span hundreds of cells (per-lane LDS adds of the moments)."""
+    band = Band(str(tmp_path), 1.0, 3000.0, 1.0, 300)
+    check(band, device, oracle, lib, syn.profile(4, 11))
+
+
+def test_lines_hugging_the_grid_edges(tmp_path, oracle, lib, device):
+    """Windows clipped at index 0 and n-1, centres pushed off the grid by the pressure shift (kernels.c:433-437)."""
+    band = Band(str(tmp_path), 100.0, 400.0, 1.0, 900, mols=[syn.H2O, syn.CO2], with_cfc=False, with_cia=False,
+                with_ctm=False)
+    for m in band.lines:
+        v = band.lines[m]["v0"]
+        v[: v.size // 3] = np.round(100.0 + (v[: v.size // 3] - 100.0) * 0.004, 6)
+        v[-(v.size // 3):] = np.round(400.0 - (400.0 - v[-(v.size // 3):]) * 0.004, 6)
+        band.lines[m]["v0"] = np.sort(v)
+    check(band, device, oracle, lib, syn.profile(5, 9))
+
+
+def test_high_pressure_widens_the_near_field(tmp_path, oracle, lib, device):
+    """Three atmospheres at the surface: Lorentz widths of several tenths of a grid step, so the moment series
+    needs a wider near field (R grows with gamma/wres) in the lowest layers and the smallest in the highest."""
+    band = Band(str(tmp_path), 600.0, 800.0, 0.5, 6000)
+    col = syn.profile(7, 15)
+    col["p"] = col["p"] * 3.0
+    check(band, device, oracle, lib, col)
+
+
+def test_fine_grid_high_wavenumber_region1_beyond_near_field(tmp_path, oracle, lib, device):
+    """0.1 cm-1 at 44 000 cm-1: Doppler widths of ~0.06 cm-1, so Humlicek region 1 (|x| < XLIM0) reaches ~90 grid
+    steps from the centre -- beyond the near field, where it is applied as a correction to the moment series; the
+    near-centre queue receives tens of points per line."""
+    band = Band(str(tmp_path), 44000.0, 44200.0, 0.1, 1200, sw=True, with_cfc=False)
+    check(band, device, oracle, lib, syn.profile(8, 9))
+
+
+def test_half_wavenumber_grid_uses_moments_too(tmp_path, oracle, lib, device):
+    band = Band(str(tmp_path), 2000.0, 2400.0, 0.5, 5000)
+    check(band, device, oracle, lib, syn.profile(9, 12))
+
+
+def test_window_narrower_than_near_field_falls_back_to_all_near(tmp_path, oracle, lib, device):
+    """1.5 cm-1: 17 grid steps per half window; under a (deliberately absurd) 40 atm surface pressure R + 4 > fsteps
+    in the lowest layers, where the workgroup treats the whole window as near field (no moments) -- both branches
+    in one launch."""
+    band = Band(str(tmp_path), 500.0, 1400.0, 1.5, 6000)
+    col = syn.profile(3, 15)
+    col["p"] = col["p"] * 40.0
+    check(band, device, oracle, lib, col)
