@@ -26,6 +26,7 @@
 // token carries its slot number with it, so nothing depends on the direction of the rotation.
 // Humlicek region 1 (XLIM1 <= |x| < XLIM0) is evaluated inside the ring whenever it lies within R;
 // regions 2-4 go through the per-wave queue exactly as in the ring kernel.
+#include <type_traits>
 #include "gas_optics_dev.h"
 
 namespace {
@@ -111,8 +112,11 @@ __device__ __forceinline__ float row_sum_transposed(float const (&m)[8], bool b3
 // Near-centre points (Humlicek regions 1-4 inside XLIM1) wait in per-wave LDS queues, one queue per
 // class of formula (voigt_class), so that a batch of 64 points runs ONE formula with all lanes busy:
 // evaluated unsorted, a batch pays for every formula present in it (~4x the work of the usual mix).
+#ifndef GRT_MPQ
+#define GRT_MPQ 96
+#endif
 constexpr int kClasses = 3;
-constexpr int kMpQueue = 96;    // entries per (class, wave): batches of 64 leave at most 63 behind
+constexpr int kMpQueue = GRT_MPQ;    // entries per (class, wave): batches of 64 leave at most 63 behind
 
 struct MpQueue
 {
@@ -457,18 +461,18 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
         }
         float const mid = 0.5f*(float)(lo_n + hi_n) - (float)c;
         float const half = lo_n <= hi_n ? 0.5f*(float)(hi_n - lo_n) + 0.25f : -1.f;
-#if defined(GRT_MP_NORING)
-        if (amp == 12345.678) acc[lane] = amp + cl + wr + ndcr + d0r + d2r + a0 + mid + half + xq_near + x0q;
-        for (int fbp = fb; fbp <= fe && amp == 12345.678; fbp += 16)
-#else
-        for (int fbp = fb; fbp <= fe; fbp += 16)
-#endif
+        // One pass of the row rings over the grid points [fbp, fbp + PERIOD).  PERIOD 16: sixteen tokens
+        // per row, sixteen steps.  PERIOD 8 (the wave's near fields fit in 8 grid points -- the usual case
+        // at 1 cm-1, R = 3): slots s and s + 8 of a row stand for the same grid point and start half a row
+        // apart, so after eight steps the two tokens of a grid point have together met all 16 lines.
+        auto ring_block = [&](int fbp, auto period_tag)
         {
+            constexpr int PERIOD = decltype(period_tag)::value;
             double token = 0.;
-            float slotf = (float)(lane & 15);
+            float slotf = (float)(lane & (PERIOD - 1));
             float const base_rel = (float)(fbp - c);
 #pragma unroll 4
-            for (int t = 0; t < 16; ++t)
+            for (int t = 0; t < PERIOD; ++t)
             {
                 float const rel = base_rel + slotf;
                 float const xi = fmaf(rel, wr, ndcr);
@@ -488,6 +492,21 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
             if (f <= fe)
             {
                 GRT_ACC_ADD(&acc[f - F0], token);
+            }
+        };
+#if defined(GRT_MP_NORING)
+        if (amp == 12345.678) acc[lane] = amp + cl + wr + ndcr + d0r + d2r + a0 + mid + half + xq_near + x0q;
+        if (amp == 12345.678)
+#endif
+        for (int fbp = fb; fbp <= fe; fbp += 16)
+        {
+            if (fe - fbp < 8)
+            {
+                ring_block(fbp, std::integral_constant<int, 8>{});      // what is left fits in 8 points
+            }
+            else
+            {
+                ring_block(fbp, std::integral_constant<int, 16>{});
             }
         }
     }
