@@ -110,7 +110,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cols", type=int, default=int(os.environ.get("GRT_BENCH_COLS", 8)), help="columns per GPU per step")
     ap.add_argument("--fast", type=int, default=int(os.environ.get("GRT_BENCH_FAST", 1)),
-                    help="1: fused arithmetic form of the line kernel (production); 0: reference operation order")
+                    help="1: fused form, far wings by cell moments (production); 2: fused form, ring kernel; 0: reference operation order")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lw-lines", type=int, default=None)
     ap.add_argument("--sw-lines", type=int, default=None)
@@ -204,6 +204,7 @@ def main():
             except Exception:
                 traffic = None
         total_cols = world * args.cols * args.steps
+        line_kernel = "gas_optics_mp_kernel" if args.fast == 1 else "gas_optics_kernel"
         line = {
             "metric": "columns/sec (60-layer, 1 cm-1 LBL, LW+SW)", "value": total_cols / elapsed, "unit": "columns/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -211,15 +212,18 @@ def main():
             "config": {"workload": "SURVEY §8d grid G1: LW 1-3250 + SW 1-50000 cm-1 @1 cm-1, 60 layers, 7 absorbers, "
                                    f"{S['lw']} LW + {S['sw']} SW synthetic lines, H2O/O3 continua, 2 CFC, 3 CIA, clear sky, "
                                    "integrated fluxes",
-                       "columns_per_gpu_per_step": args.cols, "arithmetic": "fast" if args.fast else "reference-order",
+                       "columns_per_gpu_per_step": args.cols, "fast": args.fast,
+                       "arithmetic": {0: "reference operation order", 1: "fused form, far wings by cell moments",
+                                      2: "fused form, every window point in the ring"}.get(args.fast, str(args.fast)),
                        "parallelism": f"columns sharded over {world} GPU(s), RCCL gather of 12 fluxes/column"},
-            "roofline": {"kernel": "gas_optics_kernel (line-by-line tau), SW-band launch", "bound": "hbm",
+            "roofline": {"kernel": f"{line_kernel} (line-by-line tau), SW-band launch", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "avg_launch_ms": dom_ms, "launches": ms[2][1],
-                         "note": "this kernel is FP32/FP64-VALU bound by construction (L*S*F Voigt evaluations), see roofline_valu"},
-            "roofline_valu": {"kernel": "gas_optics_kernel, SW-band launch", "bound": "valu_fp32",
+                         "note": "this kernel is FP32/FP64-VALU bound by construction, see roofline_valu"},
+            "roofline_valu": {"kernel": f"{line_kernel}, SW-band launch", "bound": "valu_fp32",
                               "achieved": valu_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0,
-                              "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s (12 flop per Voigt point, SURVEY §8d)",
+                              "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s (algorithmic: 12 flop x L*S*F line-shape points, SURVEY §8d; the moment kernel "
+                                      "delivers the far-wing points without evaluating them one by one)",
                               "frac": (valu_flop / (dom_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS) if dom_ms > 0 else 0.0,
                               "voigt_points_per_launch": points(S["sw"]),
                               "gpoints_per_s": points(S["sw"]) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0},

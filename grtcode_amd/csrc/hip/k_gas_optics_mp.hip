@@ -191,6 +191,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
     float const wres_f = (float)a.wres;
     double const inv_wres = 1./a.wres;
     float const inv_wres_f = (float)inv_wres;
+    int const nw_i = (int)nw;
 
     // ---- near-field radius R of this (tile, layer): workgroup-uniform ----
     // moment series: every line has |z| <= sqrt(1/4 + eta_max^2), eta_max from the largest half-width
@@ -249,46 +250,80 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
         {
             ln = load_line(a.lines, j);
         }
+        // kernels.c:34-131 for this (layer, line) in the fused form's arithmetic: shifted centre, centre
+        // index and Doppler width in fp64 exactly as the reference-order kernels (prepare_line); S(T) in
+        // fp64 with hardware exp2.
         int s = 1, lo = 1, hi = 0, c = 0;
         bool valid = false;
-        double dwno = 0., wnoadj = 0., amp = 0.;
+        double wnoadj = 0., amp = 0.;
         float repwid = 1.f, y = 0.f;
         if (j < jend)
         {
             double const *ms = ms_l + ln.slot*4;
-            double const *q = q_l + ln.slot*GRT_MAX_ISO;
-            Prepared const p = prepare_line<true>(ln, lay, ms, q, a.w0, a.wres, inv_wres, fsteps_ll, nw);
-            if (p.s <= p.e && p.s < F1l && p.e >= F0l)
+            double const vnn = ln.v0 + (double)ln.delta*lay[0];                        // kernels.c:44
+            // kernels.c:431-432: fcenterid = floor((2*((vnn - w0)/wres) + 1)/2), bit-exact (see prepare_line)
+            double const dv = vnn - a.w0;
+            double u = (2*(dv*inv_wres) + 1)/2;
+            if (fabs(u - rint(u)) <= 4e-15*fmax(1., fabs(u)))
             {
-                valid = true;
-                s = (int)p.s;
-                lo = s > F0 ? s : F0;
-                hi = (int)p.e < F1 - 1 ? (int)p.e : F1 - 1;
-                c = p.c_minus_fsteps + fsteps;
-                // RFM_voigt.c:94, rounded as the reference's REPWID (see k_gas_optics.hip)
-                double const r0 = (double)__builtin_amdgcn_rcpf((float)p.alpha);
-                repwid = (float)((double)kSqrln2*(r0*fma(-p.alpha, r0, 2.0)));
-                y = (float)((double)repwid*p.gamma);                                  // RFM_voigt.c:95
-                dwno = (double)p.s*a.wres + a.w0;                                     // kernels.c:438
-                wnoadj = p.vnn;
-                amp = p.snn*ms[2];                                                    // snn*n (kernels.c:459)
+                u = (2*(dv/a.wres) + 1)/2;
+            }
+            double const fc = floor(u);
+            if (fc >= 0. && fc < (double)nw_i)
+            {
+                int const ci = (int)fc;
+                int const s_i = ci - fsteps < 0 ? 0 : ci - fsteps;                     // kernels.c:435
+                int const e_i = ci + fsteps >= nw_i ? nw_i - 1 : ci + fsteps;          // kernels.c:436-437
+                if (s_i < F1 && e_i >= F0)
+                {
+                    valid = true;
+                    c = ci;
+                    s = s_i;
+                    lo = s_i > F0 ? s_i : F0;
+                    hi = e_i < F1 - 1 ? e_i : F1 - 1;
+                    wnoadj = vnn;
+                }
             }
         }
         if (__ballot(valid) == 0ull)
         {
             continue;
         }
+        if (valid)
+        {
+            double const *ms = ms_l + ln.slot*4;
+            double const c2 = -1.4387686f;                                             // kernels.c:75
+            double const invT = lay[2];
+            // stimulated emission 1 - exp(c2 v0/T): below exp(-20) = 2e-9 the factor is 1 to fp32 and beyond
+            double const x2 = (c2*ln.v0)*invT;
+            double stim = 1.0;
+            if (__ballot(x2 > -20.) != 0ull)
+            {
+                stim = 1.0 - exp_fast(x2);
+            }
+            double const snn = ln.s0*exp_fast((c2*(double)ln.en)*invT)*stim*q_l[ln.slot*GRT_MAX_ISO + ln.iso - 1];   // :83-85
+            amp = snn*ms[2];                                                          // snn*n (kernels.c:459)
+            double const gamma = exp_fast((double)ln.nexp*lay[3])
+                                 *fma((double)ln.yair, ms[1], (double)ln.yself*ms[0]);   // kernels.c:105-106
+            double const alpha = ((double)0.83255461115f*wnoadj)*ms[3];                       // kernels.c:127
+            // RFM_voigt.c:94, rounded as the reference's REPWID (see k_gas_optics.hip)
+            double const r0 = (double)__builtin_amdgcn_rcpf((float)alpha);
+            repwid = (float)((double)kSqrln2*(r0*fma(-alpha, r0, 2.0)));
+            y = (float)((double)repwid*gamma);                                        // RFM_voigt.c:95
+        }
         bool const lorentz = (y >= 70.55f);                                           // RFM_voigt.c:97
         float const yq = y*y;
-        float const xlim0 = sqrtf(15100.0f + y*(40.0f - y*3.6f));                     // :109
-        float xlim1 = (y >= 8.425f) ? 0.0f : sqrtf(164.0f - y*(4.3f + y*1.8f));       // :111-118
+        // thresholds: hardware square roots (1 ulp) -- they only decide which formula a point within
+        // an ulp of a region boundary takes
+        float const xlim0 = __builtin_amdgcn_sqrtf(15100.0f + y*(40.0f - y*3.6f));    // :109
+        float xlim1 = (y >= 8.425f) ? 0.0f : __builtin_amdgcn_sqrtf(164.0f - y*(4.3f + y*1.8f));   // :111-118
         if (y <= 0.000001f)
         {
             xlim1 = xlim0;                                                            // :122-126
         }
-        float const a0 = (float)((double)yq + 0.5);                                   // :177
+        float const a0 = yq + 0.5f;                                                   // :177
         float const d0r = a0*a0;
-        float const d2r = (float)((double)(yq + yq) - 1.0);                           // :179
+        float const d2r = (yq + yq) - 1.0f;                                           // :179
         float const xq_near = lorentz ? -1.f : xlim1*xlim1;   // |x| < XLIM1 of a Voigt line -> queue
         float const x0q = lorentz ? 0.f : xlim0*xlim0;
         // canonical fp32 x: x(f) = fma(float(f - c), wr, ndcr), a function of the integer offset to the
@@ -381,6 +416,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
                 bool const near = (t < count) & (f >= lo) & (f <= hi) & (xi*xi < xq_near);
                 if (__ballot(near) != 0ull)
                 {
+                    double const dwno = (double)s*a.wres + a.w0;                       // kernels.c:438
                     float const xr = voigt_x(dwno, f - s, a.wres, wnoadj, repwid);     // the reference's x
                     int const cls = near ? voigt_class<true>(xr, y) : -1;
 #pragma unroll

@@ -27,7 +27,7 @@ def newest(pattern):
 
 
 def short(name):
-    for k in ("gas_optics_kernel", "sw_kernel", "lw_kernel", "clear_sky_kernel", "integrate_rows_kernel",
+    for k in ("gas_optics_mp_kernel", "gas_optics_kernel", "sw_kernel", "lw_kernel", "clear_sky_kernel", "integrate_rows_kernel",
               "fillBufferAligned", "copyBuffer"):
         if k in name:
             return k
@@ -80,12 +80,12 @@ for key in sorted(set(fetch) | set(write)):
 json.dump(summary, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
 
 # what bench.py reads back into roofline.traffic (dominant kernel = SW-band launch = largest grid)
-gas = {k: v for k, v in summary["kernels"].items() if k.startswith("gas_optics_kernel")}
+gas = {k: v for k, v in summary["kernels"].items() if k.startswith("gas_optics")}
 if gas:
     sw_key = max(gas, key=lambda k: gas[k]["grid_threads"])
     lw_key = min(gas, key=lambda k: gas[k]["grid_threads"])
     cfg = bench["config"]
-    json.dump({"tag": tag, "cols": cfg["columns_per_gpu_per_step"], "fast": 1 if cfg["arithmetic"] == "fast" else 0,
+    json.dump({"tag": tag, "cols": cfg["columns_per_gpu_per_step"], "fast": cfg["fast"],
                "gas_optics_sw": gas[sw_key], "gas_optics_lw": gas[lw_key]},
               open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1)[:1800])
