@@ -40,7 +40,11 @@ EXTERN int grt_add_molecule_lines(GasOptics_t *gas_optics, int molecule_id, uint
                                   double const *yair, double const *yself, double const *en,
                                   double const *nexp, double const *delta);
 
-/* ---- launch tuning for the line kernel (0 keeps the current/automatic value) ------ */
+/* ---- launch tuning for the line kernel (tile, nslice: 0 keeps the automatic value) --
+ * fast: 0 = reference operation order (default of a new object: tau within 1e-11 of the
+ *          reference's), 1 = fused arithmetic with the far wings summed by cell moments
+ *          (production form of the batched pipeline: tau within 2e-6 of each layer's maximum,
+ *          fluxes ~1e-6 W m-2), 2 = fused arithmetic, every window point evaluated. */
 EXTERN int grt_gas_optics_tune(GasOptics_t *gas_optics, int tile, int nslice, int fast);
 
 /* ---- batched columns ------------------------------------------------------------- */
