@@ -1,0 +1,165 @@
+"""BASELINE.json's remaining configurations as parity-test cases (SURVEY.md §8d "Mapping of configs"):
+
+(2) CIRC cases 1-7, clear-sky LW+SW at 1 cm-1: the reference tree holds case 1 only (circ/src/circ1.h); cases 2-7
+    need circ-case{2..7}.nc + netCDF, so they are case 1 plus six deterministic perturbations (temperature offsets,
+    moisture and ozone scalings, a colder/drier and a warmer/wetter column, a different sun), run as ONE batch.
+(4) 1 800 columns = 100 columns x 18 replicas, sharded: on one GPU the property is that every replica of a column
+    returns the same fluxes wherever it sits in a chunk, and that rank shards tile the set (the N-rank gather itself
+    is covered on CPU by tests/test_multi_rank_gloo.py).
+(5) ERA5-like: longwave at 0.1 cm-1, shortwave at 10 cm-1 (GRTworkflow/run-era5.sh), all 21 CFC species of
+    cfcs.h:32-56 active.
+
+Tolerances: production arithmetic (fast=1); optical depths 2e-6 of each layer's maximum, integrated fluxes
+1e-3 W m-2 (BASELINE.json north star) -- asserted at 1e-4.
+"""
+import copy
+
+import numpy as np
+import pytest
+
+from grtcode_amd import api, multi, synthetic as syn
+from scenario import Band, MOL_ORDER
+from test_gpu_circ_rfmip import circ1_column
+from test_gpu_gas_optics import tau_close
+from test_gpu_pipeline import oracle_column
+
+pytestmark = pytest.mark.gpu
+FLUX_TOL = 1e-4
+
+
+def circ_like_columns():
+    base, v = circ1_column()
+    cols = [base]
+    k = np.linspace(0.0, 1.0, base["p"].size)
+
+    def variant(dt=0.0, h2o=1.0, o3=1.0, co2=1.0, sza=None, tsurf=0.0):
+        c = copy.deepcopy(base)
+        c["t"] = c["t"] + dt * k
+        c["t_layer"] = c["t_layer"] + dt * 0.5 * (k[:-1] + k[1:])
+        c["t_surf"] = c["t_surf"] + dt + tsurf
+        c["ppmv"][syn.H2O] = c["ppmv"][syn.H2O] * h2o
+        c["ppmv"][syn.O3] = c["ppmv"][syn.O3] * o3
+        c["ppmv"][syn.CO2] = c["ppmv"][syn.CO2] * co2
+        if sza is not None:
+            c["mu0"] = float(np.cos(np.deg2rad(sza)))
+            c["tsi"] = v["toa_solar_irradiance"] / float(np.cos(np.deg2rad(v["solar_zenith_angle_deg"])))
+        return c
+    cols += [variant(dt=-25.0, h2o=0.2), variant(dt=8.0, h2o=1.6, tsurf=3.0), variant(o3=1.5, sza=30.0),
+             variant(co2=2.0), variant(dt=-10.0, h2o=0.5, o3=0.7, sza=75.0), variant(h2o=3.0, co2=0.7, sza=0.0)]
+    return cols
+
+
+def test_circ_cases_1_to_7_lw_sw_one_batch(tmp_path, oracle, lib, device):
+    cols = circ_like_columns()
+    V = cols[0]["p"].size
+    lwb = Band(str(tmp_path / "lw"), 1.0, 3250.0, 1.0, 12000)
+    swb = Band(str(tmp_path / "sw"), 1.0, 50000.0, 1.0, 12000, sw=True)
+    go_lw, grid_lw = lwb.gas_optics(device, V, from_file=False)
+    go_sw, grid_sw = swb.gas_optics(device, V, from_file=False)
+    go_lw.tune(fast=1)
+    go_sw.tune(fast=1)
+    emis, alb = np.full(lwb.nw, 1.0 - 0.196), np.full(swb.nw, 0.196)
+    solar = api.create_solar_flux(grid_sw, swb.files["solar"])
+    pipe = api.Pipeline(go_lw, go_sw, len(cols), 20, emis, alb, solar)
+    gcols, keep = api.make_columns(cols, MOL_ORDER, cfc_order=(0, 1))
+    pipe.run(gcols)
+    got = pipe.fluxes(len(cols))
+    worst = 0.0
+    for ci, col in enumerate(cols):
+        for bi, (band, lw) in enumerate(((lwb, True), (swb, False))):
+            w = oracle_column(oracle, lib, band, col, lw, emis, alb, solar, 20)
+            worst = max(worst, np.max(np.abs(got[ci, bi * 6: bi * 6 + 6] - w["integ"])))
+    print(f"CIRC-like batch of 7: worst integrated-flux difference {worst:.2e} W m-2")
+    assert worst < FLUX_TOL
+    assert len({round(x, 4) for x in got[:, 0]}) == len(cols)       # seven different atmospheres, seven OLRs
+    pipe.destroy()
+    go_lw.destroy()
+    go_sw.destroy()
+
+
+def test_1800_replicated_columns_in_shards(tmp_path, device):
+    base_n, replicas, chunk, V = 100, 18, 64, 21
+    band = Band(str(tmp_path), 600.0, 760.0, 1.0, 3000)
+    go, grid = band.gas_optics(device, V, from_file=False)
+    go.tune(fast=1)
+    emis = np.full(band.nw, 0.98)
+    pipe = api.Pipeline(go, None, chunk, -1, emis, None, None)
+    base = [syn.profile(c, V) for c in range(base_n)]
+    order = [(r, c) for r in range(replicas) for c in range(base_n)]           # replica-major, as run-rfmip would
+    total = len(order)
+    assert total == 1800
+    # the 8-rank sharding of the set tiles it exactly (multi.shard is what bench.py and a driver use)
+    parts = [multi.shard(total, rank, 8) for rank in range(8)]
+    parts = [(first, first + count) for first, count in parts]
+    assert parts[0][0] == 0 and parts[-1][1] == total and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+    got = np.zeros((total, api.GRT_FLUXES_PER_COLUMN))
+    for lo, hi in parts:                                                       # each "rank" runs its shard in chunks
+        for first in range(lo, hi, chunk):
+            ids = order[first: min(first + chunk, hi)]
+            gcols, keep = api.make_columns([base[c] for _, c in ids], MOL_ORDER, cfc_order=(0, 1))
+            pipe.run(gcols)
+            got[first: first + len(ids)] = pipe.fluxes(len(ids))
+    per_col = got.reshape(replicas, base_n, -1)
+    # a column's fluxes do not depend on which shard / chunk slot / neighbours it had -- up to the order in which
+    # waves add their partial sums (fp32 moments, fp64 tiles): ~1e-8 W m-2 on fluxes of a few hundred
+    spread = np.max(np.abs(per_col - per_col[0:1]), axis=0)[:, :6]
+    assert np.max(spread) < 1e-6
+    assert np.all(per_col[0, :, 0] > 0) and len({round(x, 6) for x in per_col[0, :, 0]}) == base_n
+    pipe.destroy()
+    go.destroy()
+
+
+def test_era5_like_fine_longwave_coarse_shortwave_all_cfcs(tmp_path, oracle, lib, device):
+    V, ncfc = 17, 21
+    lwb = Band(str(tmp_path / "lw"), 700.0, 1300.0, 0.1, 5000)
+    swb = Band(str(tmp_path / "sw"), 1.0, 20000.0, 10.0, 5000, sw=True)
+    cols = [syn.profile(c, V) for c in (11, 12)]
+    for c in cols:                                                             # 21 species, distinct abundances
+        c["cfc_ppmv"] = {k: np.full(V, 1.0e-4 * (1 + k)) for k in range(ncfc)}
+
+    def build(band):
+        grid = api.create_spectral_grid(band.w0, band.wn, band.dw)
+        go = api.GasOpticsObject(V, grid, device, band.par, band.h2o_dir, band.files["o3_ctm"])
+        for m in band.mols:
+            go.add_molecule_lines(m, band.lines[m])
+        for k in range(ncfc):
+            go.add_cfc(k, band.files["cfc11" if k % 2 == 0 else "cfc12"])
+        for a, b, name in ((0, 0, "cia_n2n2"), (1, 0, "cia_o2n2"), (1, 1, "cia_o2o2")):
+            go.add_cia(a, b, band.files[name])
+        go.tune(fast=1)
+        return go, grid
+
+    def oracle_band(band, col, lw, emis=None, alb=None, solar=None):
+        kw = band.oracle_inputs(oracle, lib, col)
+        kw["cfcs"] = [(col["cfc_ppmv"][k] * 1e-6, band.table_on_grid(oracle, "cfc11" if k % 2 == 0 else "cfc12"))
+                      for k in range(ncfc)]
+        tau_gas = oracle.gas_optics(col["p"], col["t"], band.w0, band.dw, band.nw, **kw)
+        L = V - 1
+        tr, om_r, g_r = oracle.rayleigh(L, col["p"], band.w0, band.dw, band.nw)
+        z = np.zeros_like(tau_gas)
+        tau, omega, g = oracle.add_optics([tau_gas, tr], [z, om_r], [z, g_r])
+        if lw:
+            up, dn = oracle.lw_fluxes(band.w0, band.dw, col["t_surf"], col["t_layer"], col["t"], tau, omega, emis)
+        else:
+            up, dn = oracle.sw_fluxes(omega, g, tau, col["mu0"], 0.5, alb, alb, col["tsi"], solar)
+        integ = np.array([oracle.integrate_row(r, band.dw) for r in (up[0], up[-1], dn[0], dn[-1])])
+        return tau_gas, integ
+
+    go_lw, grid_lw = build(lwb)
+    go_sw, grid_sw = build(swb)
+    emis, alb = np.full(lwb.nw, 0.98), np.full(swb.nw, 0.2)
+    solar = api.create_solar_flux(grid_sw, swb.files["solar"])
+    pipe = api.Pipeline(go_lw, go_sw, len(cols), -1, emis, alb, solar)
+    gcols, keep = api.make_columns(cols, MOL_ORDER, cfc_order=tuple(range(ncfc)))
+    pipe.run(gcols)
+    got = pipe.fluxes(len(cols))
+    for bi, (band, lw) in enumerate(((lwb, True), (swb, False))):
+        tau_dev = api.device_to_host(device, pipe.views(bi)["tau_gas"], (len(cols), V - 1, band.nw))
+        for ci, col in enumerate(cols):
+            tau_gas, integ = oracle_band(band, col, lw, emis, alb, solar)
+            assert tau_close(tau_dev[ci], tau_gas) < 2e-6
+            mine = got[ci, bi * 6: bi * 6 + 6][[0, 1, 3, 4]]
+            assert np.max(np.abs(mine - integ)) < FLUX_TOL
+    pipe.destroy()
+    go_lw.destroy()
+    go_sw.destroy()
