@@ -106,9 +106,10 @@ class Oracle:
         return tau
 
     def gas_optics(self, p_mb, t, w0, wres, nw, mols, h2o_coefs=None, o3_xs=None,
-                   cfcs=(), cias=()):
+                   cfcs=(), cias=(), method=2):
         """mols: list of dict(id,num_iso,mass,lines,x,q,h2o_ctm,o3_ctm);
-        cfcs: list of (x_level, xs_grid); cias: list of (x1_level, x2_level, xs_grid)."""
+        cfcs: list of (x_level, xs_grid); cias: list of (x1_level, x2_level, xs_grid);
+        method: 0 wavenumber_sweep, 1 line_sweep, 2 line_sample (gas_optics.h:89-94)."""
         p_mb, t = _f64(p_mb), _f64(t)
         V = p_mb.size
         keep = []
@@ -141,11 +142,17 @@ class Oracle:
         cia_x2 = ptr_array([c[1] for c in cias])
         cia_xs = ptr_array([c[2] for c in cias])
         tau = np.zeros((V - 1, nw))
-        self.lib.orc_gas_optics(C.c_int(V), _dp(p_mb), _dp(t), C.c_double(w0), C.c_double(wres),
-                                C.c_uint64(nw), C.c_int(len(mols)), arr, h2o, _dp(o3),
-                                C.c_int(len(cfcs)), cfc_x, cfc_xs,
-                                C.c_int(len(cias)), cia_x1, cia_x2, cia_xs, _dp(tau))
+        self.lib.orc_gas_optics_method(C.c_int(method), C.c_int(V), _dp(p_mb), _dp(t), C.c_double(w0),
+                                       C.c_double(wres), C.c_uint64(nw), C.c_int(len(mols)), arr, h2o, _dp(o3),
+                                       C.c_int(len(cfcs)), cfc_x, cfc_xs,
+                                       C.c_int(len(cias)), cia_x1, cia_x2, cia_xs, _dp(tau))
         return tau
+
+    def bracket(self, array, val):
+        array = _f64(array)
+        l, r = C.c_uint64(0), C.c_uint64(0)
+        rc = self.lib.orc_bracket(C.c_uint64(array.size), _dp(array), C.c_double(val), C.byref(l), C.byref(r))
+        return rc, l.value, r.value
 
     def rayleigh(self, num_layers, p_mb, w0, dw, nw):
         p_mb = _f64(p_mb)
@@ -357,18 +364,80 @@ class Ref:
                                         _dp(_f64(x2)), _dp(_f64(xs)), _dp(tau))
         return tau
 
-    def gas_optics(self, p_mb, t, w0, wres, nw, mols, h2o_coefs=None, o3_xs=None, cfcs=(), cias=()):
+    def sweep_bins(self, L, w0, wres, nw, bin_width=1.0):
+        """spectral_bin.c:30-99 restated on numpy arrays we own (one spare bin of zero padding: the reference's
+        line_sweep indexes bin `n` for lines near the top of the grid, kernels.c:345-353,387-403)."""
+        b = RefSpectralBins()
+        b.num_layers, b.w0, b.wres, b.num_wpoints, b.width = L, w0, wres, nw, bin_width
+        b.ppb = int(np.floor(bin_width / wres) + 1)
+        b.do_interp = 1 if b.ppb > 3 else 0
+        last = nw % b.ppb
+        b.last_ppb = b.ppb if last == 0 else last
+        b.do_last_interp = 1 if b.last_ppb > 3 else 0
+        b.n = nw // b.ppb + (1 if b.ppb != b.last_ppb else 0)
+        b.isize = 3 * b.n
+        n = b.n
+        l = np.zeros(n + 1, dtype=np.uint64)
+        r = np.zeros(n + 1, dtype=np.uint64)
+        w = np.zeros(3 * (n + 1))
+        for i in range(n):
+            l[i] = i * b.ppb
+            s = b.ppb if i < n - 1 else b.last_ppb
+            r[i] = l[i] + s - 1
+            w[3 * i] = w0 + b.ppb * i * wres
+            w[3 * i + 2] = w[3 * i] + (s - 1) * wres
+            w[3 * i + 1] = np.float64(np.float32(0.5)) * (w[3 * i] + w[3 * i + 2])
+        taub = np.zeros(L * 3 * n + 64)                     # (layer, n, 3) + padding after the last layer
+        b.l = l.ctypes.data_as(C.POINTER(C.c_uint64))
+        b.r = r.ctypes.data_as(C.POINTER(C.c_uint64))
+        b.w = _dp(w)
+        b.tau = _dp(taub)
+        b.device = HOST_ONLY
+        b._keep = (l, r, w, taub)
+        return b
+
+    def sweep(self, method, bins, vnn, snn, gamma, alpha, ns, tau):
+        """sort_lines + calc_optical_depth_bin_sweep (method 0) or calc_optical_depth_line_sweep (1)."""
+        vnn, snn, gamma, alpha, ns = (_f64(a).copy() for a in (vnn, snn, gamma, alpha, ns))
+        L, N = vnn.shape
+        if method == 0:
+            self._check(self.lib.sort_lines(C.c_uint64(N), C.c_int(L), _dp(vnn), _dp(snn), _dp(gamma), _dp(alpha)),
+                        "sort_lines")
+        f = self.lib.calc_optical_depth_bin_sweep if method == 0 else self.lib.calc_optical_depth_line_sweep
+        f.argtypes = [C.c_uint64, C.c_int, c_double_p, c_double_p, c_double_p, c_double_p,
+                      c_double_p, RefSpectralBins, c_double_p]
+        self._check(f(N, L, _dp(vnn), _dp(snn), _dp(gamma), _dp(alpha), _dp(ns), bins, _dp(tau)), "sweep")
+        return tau
+
+    def interpolate(self, bins, tau):
+        for name in ("interpolate", "interpolate_last_bin"):
+            f = getattr(self.lib, name)
+            f.argtypes = [RefSpectralBins, c_double_p]
+            self._check(f(bins, _dp(tau)), name)
+        return tau
+
+    def bracket(self, array, val):
+        array = _f64(array)
+        l, r = C.c_uint64(0), C.c_uint64(0)
+        rc = self.lib.bracket(C.c_uint64(array.size), _dp(array), C.c_double(val), C.byref(l), C.byref(r))
+        return rc, l.value, r.value
+
+    def gas_optics(self, p_mb, t, w0, wres, nw, mols, h2o_coefs=None, o3_xs=None, cfcs=(), cias=(), method=2):
         """launch.c:40-226 sequencing, executed with the reference's own kernels."""
         p_mb, t = _f64(p_mb), _f64(t)
         p = p_mb * np.float64(np.float32(0.000986923))
         L = p.size - 1
         n, pavg, tavg = self.layer_means(p, t)
         tau = np.zeros((L, nw))
+        bins = self.sweep_bins(L, w0, wres, nw) if method != 2 else None
         for m in mols:
             ps, ns = self.species_means(p, m["x"], n)
             if m["lines"]["v0"].size:
                 vnn, snn, gamma, alpha = self.line_prep(m["lines"], m["mass"], m["num_iso"], pavg, tavg, ps, m["q"])
-                self.line_sample(vnn, snn, gamma, alpha, ns, w0, wres, nw, tau=tau)
+                if method == 2:
+                    self.line_sample(vnn, snn, gamma, alpha, ns, w0, wres, nw, tau=tau)
+                else:
+                    self.sweep(method, bins, vnn, snn, gamma, alpha, ns, tau)
             if m.get("h2o_ctm"):
                 self.h2o_ctm(tau, h2o_coefs[1], tavg, ps, ns, h2o_coefs[3], h2o_coefs[0], pavg, h2o_coefs[2])
             elif m.get("o3_ctm"):
@@ -377,6 +446,8 @@ class Ref:
             self.cfc(tau, n, x, xs)
         for x1, x2, xs in cias:
             self.cia(tau, p, tavg, x1, x2, xs)
+        if method != 2:
+            self.interpolate(bins, tau)
         return tau
 
     # -- optics / solvers through the reference's public API ----------------- #

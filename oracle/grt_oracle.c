@@ -282,6 +282,346 @@ void orc_line_sample(uint64_t num_lines, int num_layers, double const *vnn,
 }
 
 /* ------------------------------------------------------------------------- */
+/* The RFM sweep methods -- gas-optics/src/spectral_bin.c:30-99,                */
+/* kernel_utils.c:26-117, kernels.c:135-406,514-581                            */
+/* ------------------------------------------------------------------------- */
+#define ORC_NIP 3                                                   /* spectral_bin-internal.h:30 */
+
+void orc_bins_create(OrcBins *b, int num_layers, double w0, uint64_t n, double wres, double bin_width)
+{
+    b->num_layers = num_layers;
+    b->w0 = w0;
+    b->wres = wres;
+    b->num_wpoints = n;
+    b->width = bin_width;
+    b->ppb = floor(b->width/wres) + 1;                              /* spectral_bin.c:52 */
+    b->do_interp = b->ppb > 3 ? 1 : 0;
+    b->last_ppb = n % b->ppb;                                       /* :57-58 */
+    b->last_ppb = b->last_ppb == 0 ? b->ppb : b->last_ppb;
+    b->do_last_interp = b->last_ppb > 3 ? 1 : 0;
+    b->n = n/b->ppb;                                                /* :64-68 */
+    if (b->ppb != b->last_ppb)
+    {
+        (b->n)++;
+    }
+    b->isize = ORC_NIP*b->n;
+    /* one spare bin of padding at the end: kernels.c:345-353,387-403 index bin `n` for lines near the
+       top of the grid (see orc_line_sweep) */
+    b->l = calloc(b->n + 1, sizeof(*b->l));
+    b->r = calloc(b->n + 1, sizeof(*b->r));
+    b->w = calloc(b->isize + ORC_NIP, sizeof(*b->w));
+    b->tau = calloc((size_t)(b->isize + ORC_NIP)*num_layers, sizeof(*b->tau));
+    for (uint64_t i = 0; i < b->n; ++i)                             /* :79-88 */
+    {
+        b->l[i] = i*b->ppb;
+        int const s = i < (b->n - 1) ? b->ppb : b->last_ppb;
+        b->r[i] = b->l[i] + s - 1;
+        uint64_t const o = i*ORC_NIP;
+        b->w[o] = w0 + b->ppb*i*wres;
+        b->w[o + (ORC_NIP - 1)] = b->w[o] + (s - 1)*wres;
+        b->w[o + 1] = 0.5f*(b->w[o] + b->w[o + (ORC_NIP - 1)]);
+    }
+}
+
+void orc_bins_destroy(OrcBins *b)
+{
+    free(b->l); free(b->r); free(b->w); free(b->tau);
+    b->l = b->r = NULL; b->w = b->tau = NULL;
+}
+
+/* kernels.c:135-172: per layer, ascending by line centre; an insertion sort that only moves strictly
+   greater elements, i.e. a STABLE sort -- restated as a stable merge sort of indices (same result,
+   O(N log N)). */
+static void stable_order(uint64_t n, double const *key, uint64_t *idx, uint64_t *tmp)
+{
+    for (uint64_t i = 0; i < n; ++i) idx[i] = i;
+    for (uint64_t width = 1; width < n; width *= 2)
+    {
+        for (uint64_t lo = 0; lo < n; lo += 2*width)
+        {
+            uint64_t const mid = lo + width < n ? lo + width : n, hi = lo + 2*width < n ? lo + 2*width : n;
+            uint64_t a = lo, b = mid, k = lo;
+            while (a < mid && b < hi)
+            {
+                tmp[k++] = key[idx[b]] < key[idx[a]] ? idx[b++] : idx[a++];
+            }
+            while (a < mid) tmp[k++] = idx[a++];
+            while (b < hi) tmp[k++] = idx[b++];
+        }
+        memcpy(idx, tmp, sizeof(*idx)*n);
+    }
+}
+
+void orc_sort_lines(uint64_t num_lines, int num_layers, double *vnn, double *snn, double *gamma, double *alpha)
+{
+    uint64_t *idx = malloc(sizeof(*idx)*2*num_lines);
+    double *buf = malloc(sizeof(*buf)*num_lines);
+    double *arr[4] = {vnn, snn, gamma, alpha};
+    for (int k = 0; k < num_layers; ++k)
+    {
+        stable_order(num_lines, vnn + (uint64_t)k*num_lines, idx, idx + num_lines);
+        for (int a = 0; a < 4; ++a)
+        {
+            double *x = arr[a] + (uint64_t)k*num_lines;
+            for (uint64_t i = 0; i < num_lines; ++i) buf[i] = x[idx[i]];
+            memcpy(x, buf, sizeof(*x)*num_lines);
+        }
+    }
+    free(idx);
+    free(buf);
+}
+
+/* kernel_utils.c:26-77.  Returns 0, or -1 where the reference returns an error code (which its callers
+   ignore): value outside the array (left/right still set to the ends) or an empty array (nothing set). */
+int orc_bracket(uint64_t array_size, double const *array, double val, uint64_t *left, uint64_t *right)
+{
+    if (array_size < 1)
+    {
+        return -1;
+    }
+    uint64_t l = 0, r = array_size - 1;
+    if (val < array[l] || val > array[r])
+    {
+        *left = l;
+        *right = r;
+        return -1;
+    }
+    if (array[l] == val)
+    {
+        r = l;
+    }
+    else if (array[r] == val)
+    {
+        l = r;
+    }
+    else
+    {
+        while (r - l > 1)
+        {
+            uint64_t const mid = l + (r - l)/2;
+            if (array[mid] == val)
+            {
+                l = mid;
+                r = mid;
+                break;
+            }
+            else if (val > array[mid])
+            {
+                l = mid;
+            }
+            else
+            {
+                r = mid;
+            }
+        }
+    }
+    *left = l;
+    *right = r;
+    return 0;
+}
+
+/* kernels.c:176-307 */
+void orc_bin_sweep(uint64_t num_lines, int num_layers, double const *vnn, double const *snn,
+                   double const *gamma, double const *alpha, double const *n, OrcBins const *bins,
+                   double *tau)
+{
+    double *t = malloc(sizeof(*t)*(bins->ppb + 1));
+    for (int i = 0; i < num_layers; ++i)
+    {
+        for (uint64_t j = 0; j < bins->n; ++j)
+        {
+            double const *v = &vnn[(uint64_t)i*num_lines];
+            double const *s = &snn[(uint64_t)i*num_lines];
+            double const *g = &gamma[(uint64_t)i*num_lines];
+            double const *a = &alpha[(uint64_t)i*num_lines];
+            uint64_t const nbin_local = 1, nbin_remote = 25;
+            uint64_t nbin = nbin_local;
+            double const leftw = j > nbin ? bins->w[ORC_NIP*(j - nbin)] : bins->w[0];
+            double const rightw = j >= (bins->n - 1) - nbin ? bins->w[ORC_NIP*bins->n - 1]
+                                  : bins->w[ORC_NIP*(j + nbin + 1) - 1];
+            uint64_t left = 0, right = 0, tmp;
+            if (leftw <= v[num_lines - 1] && rightw >= v[0])
+            {
+                orc_bracket(num_lines, v, leftw, &left, &tmp);
+                orc_bracket(num_lines - left, &v[left], rightw, &tmp, &right);
+                right += left;
+                double const w = bins->w0 + bins->l[j]*bins->wres;
+                uint64_t const np = bins->r[j] - bins->l[j] + 1;
+                for (uint64_t k = left; k <= right; ++k)
+                {
+                    orc_voigt(w, np, bins->wres, v[k], g[k], a[k], t);
+                    for (uint64_t l = bins->l[j]; l <= bins->r[j]; ++l)
+                    {
+                        tau[(uint64_t)i*bins->num_wpoints + l] += s[k]*n[i]*t[l - bins->l[j]];
+                    }
+                }
+            }
+            else if (leftw > v[num_lines - 1])
+            {
+                left = num_lines;
+            }
+            else
+            {
+                right = (uint64_t)(-1);
+            }
+            nbin = nbin_remote;
+            double const leftw_r = j > nbin ? bins->w[ORC_NIP*(j - nbin)] : bins->w[0];
+            if (leftw >= v[0] && leftw_r <= v[num_lines - 1])
+            {
+                uint64_t left_r = 0;
+                /* (an empty range, left == 0, makes the reference's bracket fail before it sets left_r;
+                   with nothing below `left` there is nothing to add either way) */
+                if (orc_bracket(left, v, leftw_r, &left_r, &tmp) != 0 && left == 0)
+                {
+                    left_r = left;
+                }
+                double const w = bins->w[j*ORC_NIP], wr = bins->w[j*ORC_NIP + 1] - w;
+                double tr[ORC_NIP];
+                for (uint64_t k = left_r; k < left; ++k)
+                {
+                    orc_voigt(w, ORC_NIP, wr, v[k], g[k], a[k], tr);
+                    for (uint64_t l = 0; l < ORC_NIP; ++l)
+                    {
+                        bins->tau[(uint64_t)i*bins->n*ORC_NIP + j*ORC_NIP + l] += s[k]*n[i]*tr[l];
+                    }
+                }
+            }
+            double const rightw_r = j >= (bins->n - 1) - nbin ? bins->w[ORC_NIP*bins->n - 1]
+                                    : bins->w[ORC_NIP*(j + nbin + 1) - 1];
+            if (rightw <= v[num_lines - 1] && rightw_r >= v[0])
+            {
+                uint64_t const f = right == (uint64_t)(-1) ? 1 : 0;
+                uint64_t right_r = 0;
+                orc_bracket(num_lines - (right + f), &v[right + f], rightw_r, &tmp, &right_r);
+                right_r += right + f;
+                double const w = bins->w[j*ORC_NIP], wr = bins->w[j*ORC_NIP + 1] - w;
+                double tr[ORC_NIP];
+                for (uint64_t k = right + 1; k <= right_r; ++k)
+                {
+                    orc_voigt(w, ORC_NIP, wr, v[k], g[k], a[k], tr);
+                    for (uint64_t l = 0; l < ORC_NIP; ++l)
+                    {
+                        bins->tau[(uint64_t)i*bins->n*ORC_NIP + j*ORC_NIP + l] += s[k]*n[i]*tr[l];
+                    }
+                }
+            }
+        }
+    }
+    free(t);
+}
+
+/* kernels.c:311-406.  For lines within 25 cm-1 (remote) or 1.5 cm-1 (local) of the top of the grid the
+   reference computes bin index `n` -- one past its arrays (maxw lies one grid step beyond the last point).
+   Bins beyond the last one are skipped here; the reference reads and writes out of bounds for them. */
+void orc_line_sweep(uint64_t num_lines, int num_layers, double const *vnn, double const *snn,
+                    double const *gamma, double const *alpha, double const *n, OrcBins const *bins,
+                    double *tau)
+{
+    double const bin_width = bins->wres*bins->ppb;
+    double *t = malloc(sizeof(*t)*(bins->ppb + 1));
+    for (int i = 0; i < num_layers; ++i)
+    {
+        for (uint64_t j = 0; j < num_lines; ++j)
+        {
+            uint64_t const o = (uint64_t)i*num_lines + j;
+            double wcutoff = 1.5f;
+            double leftw = vnn[o] - wcutoff;
+            if (leftw < bins->w0)
+            {
+                leftw = bins->w0;
+            }
+            uint64_t const left = floor((leftw - bins->w0)/bin_width);
+            double rightw = vnn[o] + wcutoff;
+            double const maxw = bins->w0 + bins->num_wpoints*bins->wres;
+            if (rightw > maxw)
+            {
+                rightw = maxw;
+            }
+            uint64_t const right = floor((rightw - bins->w0)/bin_width);
+            for (uint64_t k = left; k <= right && k < bins->n; ++k)
+            {
+                double const w = bins->w0 + bins->l[k]*bins->wres;
+                uint64_t const np = bins->r[k] - bins->l[k] + 1;
+                orc_voigt(w, np, bins->wres, vnn[o], gamma[o], alpha[o], t);
+                for (uint64_t l = bins->l[k]; l <= bins->r[k]; ++l)
+                {
+                    tau[(uint64_t)i*bins->num_wpoints + l] += snn[o]*n[i]*t[l - bins->l[k]];
+                }
+            }
+            wcutoff = 25.f;
+            leftw = vnn[o] - wcutoff;
+            if (leftw < bins->w0)
+            {
+                leftw = bins->w0;
+            }
+            uint64_t const left_r = floor((leftw - bins->w0)/bin_width);
+            double tr[ORC_NIP];
+            for (uint64_t k = left_r; k < left && k < bins->n; ++k)
+            {
+                double const w = bins->w[k*ORC_NIP], wr = bins->w[k*ORC_NIP + 1] - w;
+                orc_voigt(w, ORC_NIP, wr, vnn[o], gamma[o], alpha[o], tr);
+                for (uint64_t l = 0; l < ORC_NIP; ++l)
+                {
+                    bins->tau[(uint64_t)i*bins->n*ORC_NIP + k*ORC_NIP + l] += snn[o]*n[i]*tr[l];
+                }
+            }
+            rightw = vnn[o] + wcutoff;
+            if (rightw > maxw)
+            {
+                rightw = maxw;
+            }
+            uint64_t const right_r = floor((rightw - bins->w0)/bin_width);
+            for (uint64_t k = right + 1; k <= right_r && k < bins->n; ++k)
+            {
+                double const w = bins->w[k*ORC_NIP], wr = bins->w[k*ORC_NIP + 1] - w;
+                orc_voigt(w, ORC_NIP, wr, vnn[o], gamma[o], alpha[o], tr);
+                for (uint64_t l = 0; l < ORC_NIP; ++l)
+                {
+                    bins->tau[(uint64_t)i*bins->n*ORC_NIP + k*ORC_NIP + l] += snn[o]*n[i]*tr[l];
+                }
+            }
+        }
+    }
+    free(t);
+}
+
+/* kernel_utils.c:81-117 + kernels.c:514-581: add the bins' line-wing values to the fine grid, by a
+   quadratic through the three interpolation points (negative values clamped to zero) or, for bins of at
+   most three points, point by point. */
+void orc_interpolate(OrcBins const *bins, double *tau)
+{
+    for (int i = 0; i < bins->num_layers; ++i)
+    {
+        for (uint64_t j = 0; j < bins->n; ++j)
+        {
+            int const interp = j < bins->n - 1 ? bins->do_interp : bins->do_last_interp;
+            double *t = &tau[(uint64_t)i*bins->num_wpoints];
+            double const *x = &bins->w[j*ORC_NIP];
+            double const *y = &bins->tau[(uint64_t)i*bins->isize + j*ORC_NIP];
+            for (uint64_t k = bins->l[j]; k <= bins->r[j]; ++k)
+            {
+                if (interp)
+                {
+                    double const w = bins->w0 + k*bins->wres;
+                    double v = (w - x[1])*(w - x[2])*y[0]/((x[0] - x[1])*(x[0] - x[2])) +
+                               (w - x[0])*(w - x[2])*y[1]/((x[1] - x[0])*(x[1] - x[2])) +
+                               (w - x[0])*(w - x[1])*y[2]/((x[2] - x[0])*(x[2] - x[1]));
+                    if (v < 0.f)
+                    {
+                        v = 0.f;
+                    }
+                    t[k] += v;
+                }
+                else
+                {
+                    t[k] += y[k - bins->l[j]];
+                }
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
 /* Continua, CFCs, CIA -- gas-optics/src/kernels.c:469-510, 585-630           */
 /* ------------------------------------------------------------------------- */
 void orc_h2o_ctm(uint64_t nw, int num_layers, double *tau, double const *CS,
@@ -356,7 +696,22 @@ void orc_gas_optics(int num_levels, double const *p_mb, double const *t,
                     double const *const *cia_xs,
                     double *tau)
 {
+    orc_gas_optics_method(2, num_levels, p_mb, t, w0, wres, nw, num_molecules, mols, h2o_coefs, o3_xs, num_cfcs,
+                          cfc_x, cfc_xs, num_cias, cia_x1, cia_x2, cia_xs, tau);
+}
+
+void orc_gas_optics_method(int method, int num_levels, double const *p_mb, double const *t,
+                           double w0, double wres, uint64_t nw,
+                           int num_molecules, OrcMolecule const *mols,
+                           double const *const *h2o_coefs, double const *o3_xs,
+                           int num_cfcs, double const *const *cfc_x, double const *const *cfc_xs,
+                           int num_cias, double const *const *cia_x1, double const *const *cia_x2,
+                           double const *const *cia_xs,
+                           double *tau)
+{
     int const L = num_levels - 1;
+    OrcBins bins;
+    orc_bins_create(&bins, L, w0, nw, wres, 1.);                     /* gas_optics.c:73-76 */
     double const mbtoatm = 0.000986923f;                             /* gas_optics.c:445 */
     double p[ORC_MAX_LEVELS];
     double n[ORC_MAX_LEVELS], pavg[ORC_MAX_LEVELS], tavg[ORC_MAX_LEVELS];
@@ -380,7 +735,19 @@ void orc_gas_optics(int num_levels, double const *p_mb, double const *t,
             orc_line_prep(N, L, mol->num_iso, mol->mass, mol->v0, mol->delta, mol->s0,
                           mol->en, mol->iso, mol->nexp, mol->yair, mol->yself,
                           pavg, tavg, ps, mol->q, vnn, snn, gamma, alpha);       /* launch.c:107-131 */
-            orc_line_sample(N, L, vnn, snn, gamma, alpha, ns, w0, wres, nw, tau, NULL, NULL); /* :153 */
+            switch (method)                                          /* launch.c:131-159 */
+            {
+                case 0:
+                    orc_sort_lines(N, L, vnn, snn, gamma, alpha);
+                    orc_bin_sweep(N, L, vnn, snn, gamma, alpha, ns, &bins, tau);
+                    break;
+                case 1:
+                    orc_line_sweep(N, L, vnn, snn, gamma, alpha, ns, &bins, tau);
+                    break;
+                default:
+                    orc_line_sample(N, L, vnn, snn, gamma, alpha, ns, w0, wres, nw, tau, NULL, NULL);
+                    break;
+            }
             free(buf);
         }
         if (mol->h2o_ctm)
@@ -403,6 +770,11 @@ void orc_gas_optics(int num_levels, double const *p_mb, double const *t,
         /* launch.c:206-208: LEVEL pressures [atm], LAYER temperatures */
         orc_cia(nw, L, p, tavg, cia_x1[m], cia_x2[m], cia_xs[m], tau);
     }
+    if (method != 2)
+    {
+        orc_interpolate(&bins, tau);                                 /* launch.c:212-219 */
+    }
+    orc_bins_destroy(&bins);
 }
 
 /* ------------------------------------------------------------------------- */

@@ -90,6 +90,36 @@ void orc_gas_optics(int num_levels, double const *p_mb, double const *t,
                     double const *const *cia_xs,
                     double *tau);
 
+/* The RFM sweep methods (optical_depth_method wavenumber_sweep = 0, line_sweep = 1; line_sample = 2):
+ * spectral_bin.c:30-99, kernel_utils.c:26-117, kernels.c:135-406,514-581. */
+typedef struct OrcBins
+{
+    int num_layers;
+    double w0, wres, width;
+    uint64_t num_wpoints, n, isize;
+    int ppb, do_interp, last_ppb, do_last_interp;
+    double *w;        /* (n, 3) interpolation wavenumbers */
+    double *tau;      /* (layer, n, 3) line-wing optical depths */
+    uint64_t *l, *r;  /* first / last grid index of each bin */
+} OrcBins;
+void orc_bins_create(OrcBins *bins, int num_layers, double w0, uint64_t n, double wres, double bin_width);
+void orc_bins_destroy(OrcBins *bins);
+void orc_sort_lines(uint64_t num_lines, int num_layers, double *vnn, double *snn, double *gamma, double *alpha);
+int orc_bracket(uint64_t array_size, double const *array, double val, uint64_t *left, uint64_t *right);
+void orc_bin_sweep(uint64_t num_lines, int num_layers, double const *vnn, double const *snn,
+                   double const *gamma, double const *alpha, double const *n, OrcBins const *bins, double *tau);
+void orc_line_sweep(uint64_t num_lines, int num_layers, double const *vnn, double const *snn,
+                    double const *gamma, double const *alpha, double const *n, OrcBins const *bins, double *tau);
+void orc_interpolate(OrcBins const *bins, double *tau);
+void orc_gas_optics_method(int method, int num_levels, double const *p_mb, double const *t,
+                           double w0, double wres, uint64_t nw,
+                           int num_molecules, OrcMolecule const *mols,
+                           double const *const *h2o_coefs, double const *o3_xs,
+                           int num_cfcs, double const *const *cfc_x, double const *const *cfc_xs,
+                           int num_cias, double const *const *cia_x1, double const *const *cia_x2,
+                           double const *const *cia_xs,
+                           double *tau);
+
 /* rayleigh.c:29-144 */
 void orc_rayleigh(int num_layers, double const *p_mb, double w0, double dw, uint64_t nw,
                   double *tau, double *omega, double *g);

@@ -115,8 +115,10 @@ class Band:
             kw["cias"] = [(x[a], x[b], self.table_on_grid(orc, name)) for a, b, name in CIA_PAIRS]
         return kw
 
-    def oracle_tau(self, checker, orc, lib, col):
+    def oracle_tau(self, checker, orc, lib, col, method=None):
         kw = self.oracle_inputs(orc, lib, col)
+        if method is not None:
+            kw["method"] = method
         return checker.gas_optics(col["p"], col["t"], self.w0, self.dw, self.nw, **kw)
 
 

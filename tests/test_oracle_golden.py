@@ -163,6 +163,38 @@ def test_column_bit_exact_vs_live_reference(oracle, ref, lib, seed, dw, tmp_path
     assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("method", [0, 1])
+@pytest.mark.parametrize("seed,dw,span", [(21, 1.0, 140.0), (22, 0.1, 60.0), (23, 0.25, 80.0), (24, 0.02, 40.0)])
+def test_sweep_methods_bit_exact_vs_live_reference(oracle, ref, lib, seed, dw, span, method, tmp_path):
+    """wavenumber_sweep (0) and line_sweep (1): sort_lines, bracket, the local/remote split, the three
+    interpolation points per bin and the final quadratic interpolation (kernels.c:135-406,514-581,
+    kernel_utils.c:26-117, spectral_bin.c:30-99).  The reference holds no expected values for them (its
+    own tests return early, test_kernels.c:322-362), so the live build is the only pin.  Lines stay
+    26.5 cm-1 below the top of the grid: for nearer ones the reference's line_sweep indexes one bin past
+    its arrays (maxw = w0 + n*wres is a grid step beyond the last point) and lands in the next layer's first
+    bin -- undefined behaviour the restatement does not copy."""
+    from scenario import Band
+    w0 = 300.0
+    band = Band(str(tmp_path), w0, w0 + span, dw, 500, mols=[syn.H2O, syn.CO2, syn.O3], seed=seed,
+                line_range=(w0, w0 + span - 26.5))
+    col = syn.profile(seed, 8)
+    a = band.oracle_tau(oracle, oracle, lib, col, method=method)
+    b = band.oracle_tau(ref, oracle, lib, col, method=method)
+    assert np.array_equal(a, b)
+    sample = band.oracle_tau(oracle, oracle, lib, col)
+    # the sweeps approximate the far wings by a quadratic per 1 cm-1 bin: close to, not equal to, line_sample
+    scale = np.abs(sample).max(axis=1, keepdims=True)
+    assert 0.0 < np.max(np.abs(a - sample) / scale) < 0.05
+
+
+def test_bracket_vs_live_reference(oracle, ref):
+    arr = np.array([1.0, 2.0, 2.0, 3.5, 7.0, 7.0, 7.0, 9.25])
+    for val in (0.5, 1.0, 1.5, 2.0, 3.0, 3.5, 7.0, 8.0, 9.25, 10.0):
+        ra, rb = oracle.bracket(arr, val), ref.bracket(arr, val)
+        assert (ra[0] == 0) == (rb[0] == 0)
+        assert ra[1:] == rb[1:]
+
+
 def test_solvers_bit_exact_vs_live_reference(oracle, ref):
     rng = np.random.default_rng(5)
     L = 17
