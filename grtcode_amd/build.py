@@ -20,12 +20,12 @@ SO = os.path.join(LIB, "libgrtcode_hip.so")
 
 HOST_SRC = ["grt_error.c", "grt_util.c", "grt_grid.c", "grt_device.c", "grt_optics.c", "grt_tips.c",
             "grt_gas_optics.c", "grt_solvers.c", "grt_pipeline.c"]
-HIP_SRC = ["k_gas_optics.hip", "k_gas_optics_mp.hip", "k_optics.hip", "k_longwave.hip", "k_shortwave.hip"]
+HIP_SRC = ["k_gas_optics.hip", "k_gas_optics_mp.hip", "k_gas_optics_sweep.hip", "k_optics.hip", "k_longwave.hip", "k_shortwave.hip"]
 
 # the reference's archive names (*/src/Makefile.am): which objects go where
 ARCHIVES = {
     "libgrtcode_utilities.a": ["grt_error", "grt_util", "grt_grid", "grt_device", "grt_optics", "k_optics"],
-    "libgas_optics.a": ["grt_tips", "grt_gas_optics", "k_gas_optics", "k_gas_optics_mp"],
+    "libgas_optics.a": ["grt_tips", "grt_gas_optics", "k_gas_optics", "k_gas_optics_mp", "k_gas_optics_sweep"],
     "liblongwave.a": ["k_longwave"],
     "libshortwave.a": ["k_shortwave"],
     # solvers' host entry points and the batched pipeline reference both bands

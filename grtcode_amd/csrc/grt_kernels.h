@@ -81,6 +81,25 @@ int grt_launch_gas_optics(void *stream, GrtGasOpticsArgs const *a);
 int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a);
 int grt_gas_optics_mp_applicable(GrtGasOpticsArgs const *a);
 
+/* The RFM sweep methods (k_gas_optics_sweep.hip; kernels.c:135-406,514-581).  Per molecule: `prep` holds
+   vnn, snn, gamma, alpha as [4][L][n] (grt_launch_line_prep); grt_launch_sweep_sort writes them sorted by
+   shifted centre per layer (sort_lines); grt_launch_sweep adds the molecule to tau / bins.tau by method 0
+   (wavenumber_sweep, needs sorted input) or 1 (line_sweep); grt_launch_sweep_interpolate finishes. */
+typedef struct GrtSweepBins
+{
+    double w0, wres;
+    uint64_t num_wpoints, n;
+    int ppb, do_interp, do_last_interp;
+    double const *w;        /* device (n, 3) */
+    double *tau;            /* device (layer, n, 3) */
+    uint64_t const *l, *r;  /* device (n) */
+} GrtSweepBins;
+int grt_launch_sweep_sort(void *stream, uint64_t n, int num_layers, double const *v0, double shift_max,
+                          double const *lay, double const *prep, double *sorted);
+int grt_launch_sweep(void *stream, int method, uint64_t n, int num_layers, double const *lines,
+                     double const *ns, GrtSweepBins const *bins, double *tau);
+int grt_launch_sweep_interpolate(void *stream, int num_layers, GrtSweepBins const *bins, double *tau);
+
 /* Debug/parity hook: per-(layer,line) preparation only (kernels.c:34-131) and the
    integer window [s,e] of kernels.c:431-437 (s=1,e=0 when the line is skipped). */
 int grt_launch_line_prep(void *stream, GrtGasOpticsArgs const *a, int col,

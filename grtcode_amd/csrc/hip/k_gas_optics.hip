@@ -406,8 +406,8 @@ __global__ __launch_bounds__(kBlock) void line_prep_kernel(GrtGasOpticsArgs a, l
     snn[o] = p.snn;
     gamma[o] = p.gamma;
     alpha[o] = p.alpha;
-    ws[o] = p.s;
-    we[o] = p.e;
+    if (ws != nullptr) ws[o] = p.s;
+    if (we != nullptr) we[o] = p.e;
 }
 
 size_t gas_optics_lds_bytes(int tile)

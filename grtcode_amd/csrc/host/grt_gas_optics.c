@@ -307,11 +307,6 @@ EXTERN int create_gas_optics(GasOptics_t * const gas_optics, int const num_level
     {
         go->optical_depth_method = wavenumber_sweep;   /* gas_optics.c:110-113 */
     }
-    if (go->optical_depth_method != line_sample)
-    {
-        GRT_FAIL(GRTCODE_COMPILER_ERR, "optical_depth_method %d: only line_sample (the method the"
-                 " drivers use, driver.c:618-624) is built in this library.", go->optical_depth_method);
-    }
     if (h2o_ctm_dir != NULL && strcmp(h2o_ctm_dir, "none") != 0)
     {
         go->use_h2o_ctm = 1;
@@ -346,6 +341,14 @@ static int free_store(GasOptics_t *go)
     GRT_TRY(grt_dev_free(go->device, im->store_block));
     im->store_block = NULL;
     memset(&im->store, 0, sizeof(im->store));
+    for (int sl = 0; sl < NUM_MOLS; ++sl)
+    {
+        GRT_TRY(grt_dev_free(go->device, im->mstore_block[sl]));
+        im->mstore_block[sl] = NULL;
+        memset(&im->mstore[sl], 0, sizeof(im->mstore[sl]));
+    }
+    GRT_TRY(grt_dev_free(go->device, im->sweep_scratch));
+    im->sweep_scratch = NULL;
     return GRTCODE_SUCCESS;
 }
 
@@ -360,6 +363,7 @@ EXTERN int destroy_gas_optics(GasOptics_t * const gas_optics)
             grt_free_host_lines(&im->host[i]);
         }
         GRT_TRY(free_store(gas_optics));
+        GRT_TRY(grt_dev_free(gas_optics->device, im->bins_block));
         GRT_TRY(grt_dev_free(gas_optics->device, im->h2o_tables));
         GRT_TRY(grt_dev_free(gas_optics->device, im->lin_tables));
         GRT_TRY(grt_dev_free(gas_optics->device, im->colstate_d));
@@ -699,6 +703,64 @@ static size_t align256(size_t x)
     return (x + 255) & ~(size_t)255;
 }
 
+/* Upload the lines named by `keys` (already in the wanted order) as one structure of arrays. */
+static int upload_lines(GasOptics_t *go, SortKey const *keys, uint64_t total, GrtLineStore *st, void **block,
+                        size_t *bytes_out)
+{
+    GrtGasOpticsImpl *im = impl_of(go);
+    size_t off[10];
+    size_t bytes = 0;
+    size_t const sizes[9] = {8, 8, 4, 4, 4, 4, 4, 1, 1};
+    for (int a = 0; a < 9; ++a)
+    {
+        off[a] = bytes;
+        bytes = align256(bytes + sizes[a]*total);
+    }
+    off[9] = bytes;
+    unsigned char *host = malloc(bytes);
+    double *v0 = (double *)(host + off[0]), *s0 = (double *)(host + off[1]);
+    float *yair = (float *)(host + off[2]), *yself = (float *)(host + off[3]);
+    float *en = (float *)(host + off[4]), *nexp = (float *)(host + off[5]), *delta = (float *)(host + off[6]);
+    uint8_t *iso = host + off[7], *slot = host + off[8];
+    st->n = total;
+    st->dmax = 0.;
+    st->nmax = 0.;
+    memset(st->yair_max, 0, sizeof(st->yair_max));
+    memset(st->yself_max, 0, sizeof(st->yself_max));
+    for (uint64_t k = 0; k < total; ++k)
+    {
+        GrtHostLines const *h = &im->host[keys[k].slot];
+        uint32_t const j = keys[k].idx;
+        v0[k] = h->v0[j]; s0[k] = h->s0[j];
+        yair[k] = h->yair[j]; yself[k] = h->yself[j]; en[k] = h->en[j]; nexp[k] = h->nexp[j];
+        delta[k] = h->delta[j];
+        iso[k] = h->iso[j]; slot[k] = keys[k].slot;
+        double const ad = fabs((double)h->delta[j]);
+        if (ad > st->dmax) st->dmax = ad;
+        if (h->yair[j] > st->yair_max[keys[k].slot]) st->yair_max[keys[k].slot] = h->yair[j];
+        if (h->yself[j] > st->yself_max[keys[k].slot]) st->yself_max[keys[k].slot] = h->yself[j];
+        if (fabs((double)h->nexp[j]) > st->nmax) st->nmax = fabs((double)h->nexp[j]);
+    }
+    int rc = grt_dev_alloc(go->device, block, bytes);
+    void *s = grt_dev_stream(go->device);
+    if (rc == GRTCODE_SUCCESS) rc = grt_dev_upload(go->device, *block, host, bytes, s);
+    if (rc == GRTCODE_SUCCESS) rc = grt_dev_sync(go->device, s);
+    free(host);
+    GRT_TRY(rc);
+    unsigned char *d = *block;
+    st->v0 = (double const *)(d + off[0]);
+    st->s0 = (double const *)(d + off[1]);
+    st->yair = (float const *)(d + off[2]);
+    st->yself = (float const *)(d + off[3]);
+    st->en = (float const *)(d + off[4]);
+    st->nexp = (float const *)(d + off[5]);
+    st->delta = (float const *)(d + off[6]);
+    st->iso = d + off[7];
+    st->slot = d + off[8];
+    if (bytes_out != NULL) *bytes_out = bytes;
+    return GRTCODE_SUCCESS;
+}
+
 static int build_store(GasOptics_t *go)
 {
     GrtGasOpticsImpl *im = impl_of(go);
@@ -709,10 +771,6 @@ static int build_store(GasOptics_t *go)
         total += im->host[s].n;
     }
     im->store.n = total;
-    im->store.dmax = 0.;
-    im->store.nmax = 0.;
-    memset(im->store.yair_max, 0, sizeof(im->store.yair_max));
-    memset(im->store.yself_max, 0, sizeof(im->store.yself_max));
     if (total == 0)
     {
         im->store_dirty = 0;
@@ -730,55 +788,68 @@ static int build_store(GasOptics_t *go)
         }
     }
     qsort(keys, total, sizeof(SortKey), sort_key_cmp);
-    size_t off[10];
     size_t bytes = 0;
-    size_t const sizes[9] = {8, 8, 4, 4, 4, 4, 4, 1, 1};
-    for (int a = 0; a < 9; ++a)
+    int rc = upload_lines(go, keys, total, &im->store, &im->store_block, &bytes);
+    if (rc == GRTCODE_SUCCESS && go->optical_depth_method != line_sample)
     {
-        off[a] = bytes;
-        bytes = align256(bytes + sizes[a]*total);
-    }
-    off[9] = bytes;
-    unsigned char *host = malloc(bytes);
-    double *v0 = (double *)(host + off[0]), *s0 = (double *)(host + off[1]);
-    float *yair = (float *)(host + off[2]), *yself = (float *)(host + off[3]);
-    float *en = (float *)(host + off[4]), *nexp = (float *)(host + off[5]), *delta = (float *)(host + off[6]);
-    uint8_t *iso = host + off[7], *slot = host + off[8];
-    for (k = 0; k < total; ++k)
-    {
-        GrtHostLines const *h = &im->host[keys[k].slot];
-        uint32_t const j = keys[k].idx;
-        v0[k] = h->v0[j]; s0[k] = h->s0[j];
-        yair[k] = h->yair[j]; yself[k] = h->yself[j]; en[k] = h->en[j]; nexp[k] = h->nexp[j];
-        delta[k] = h->delta[j];
-        iso[k] = h->iso[j]; slot[k] = keys[k].slot;
-        double const ad = fabs((double)h->delta[j]);
-        if (ad > im->store.dmax) im->store.dmax = ad;
-        if (h->yair[j] > im->store.yair_max[keys[k].slot]) im->store.yair_max[keys[k].slot] = h->yair[j];
-        if (h->yself[j] > im->store.yself_max[keys[k].slot]) im->store.yself_max[keys[k].slot] = h->yself[j];
-        if (fabs((double)h->nexp[j]) > im->store.nmax) im->store.nmax = fabs((double)h->nexp[j]);
+        /* the sweep methods work molecule by molecule (launch.c:78-159): one store each, sorted by centre */
+        SortKey *mk = malloc(sizeof(SortKey)*total);
+        for (int sl = 0; sl < go->num_molecules && rc == GRTCODE_SUCCESS; ++sl)
+        {
+            uint64_t n = 0;
+            for (uint64_t k = 0; k < total; ++k)
+            {
+                if (keys[k].slot == sl) mk[n++] = keys[k];
+            }
+            if (n > 0)
+            {
+                rc = upload_lines(go, mk, n, &im->mstore[sl], &im->mstore_block[sl], NULL);
+            }
+        }
+        free(mk);
     }
     free(keys);
-    int rc = grt_dev_alloc(go->device, &im->store_block, bytes);
-    void *s = grt_dev_stream(go->device);
-    if (rc == GRTCODE_SUCCESS) rc = grt_dev_upload(go->device, im->store_block, host, bytes, s);
-    if (rc == GRTCODE_SUCCESS) rc = grt_dev_sync(go->device, s);
-    free(host);
     GRT_TRY(rc);
-    unsigned char *d = im->store_block;
-    im->store.v0 = (double const *)(d + off[0]);
-    im->store.s0 = (double const *)(d + off[1]);
-    im->store.yair = (float const *)(d + off[2]);
-    im->store.yself = (float const *)(d + off[3]);
-    im->store.en = (float const *)(d + off[4]);
-    im->store.nexp = (float const *)(d + off[5]);
-    im->store.delta = (float const *)(d + off[6]);
-    im->store.iso = d + off[7];
-    im->store.slot = d + off[8];
     /* expose the device arrays through the public struct of the FIRST molecule only as
        documentation of where they live; per-molecule views do not exist in a merged store */
     im->store_dirty = 0;
     GRT_INFO("Line store: %zu lines, %zu bytes on device %d.", (size_t)total, bytes, go->device);
+    return GRTCODE_SUCCESS;
+}
+
+/* spectral_bin.c:66-98: first/last grid index and the three interpolation wavenumbers of every bin,
+   plus the (layer, bin, 3) line-wing accumulator, on the device (the sweep methods only). */
+static int create_bin_arrays(GasOptics_t *go)
+{
+    GrtGasOpticsImpl *im = impl_of(go);
+    SpectralBins_t *b = &go->bins;
+    uint64_t const n = b->n;
+    size_t const bytes_l = align256(sizeof(uint64_t)*n), bytes_w = align256(sizeof(fp_t)*b->isize);
+    size_t const bytes_tau = align256(sizeof(fp_t)*b->isize*(size_t)b->num_layers);
+    unsigned char *host = calloc(1, 2*bytes_l + bytes_w);
+    uint64_t *l = (uint64_t *)host, *r = (uint64_t *)(host + bytes_l);
+    fp_t *w = (fp_t *)(host + 2*bytes_l);
+    for (uint64_t i = 0; i < n; ++i)
+    {
+        l[i] = i*(uint64_t)b->ppb;
+        int const s = i < (n - 1) ? b->ppb : b->last_ppb;
+        r[i] = l[i] + (uint64_t)s - 1;
+        uint64_t const o = i*3;
+        w[o] = b->w0 + b->ppb*i*b->wres;
+        w[o + 2] = w[o] + (s - 1)*b->wres;
+        w[o + 1] = 0.5f*(w[o] + w[o + 2]);
+    }
+    void *s = grt_dev_stream(go->device);
+    int rc = grt_dev_alloc(go->device, &im->bins_block, 2*bytes_l + bytes_w + bytes_tau);
+    if (rc == GRTCODE_SUCCESS) rc = grt_dev_upload(go->device, im->bins_block, host, 2*bytes_l + bytes_w, s);
+    if (rc == GRTCODE_SUCCESS) rc = grt_dev_sync(go->device, s);
+    free(host);
+    GRT_TRY(rc);
+    unsigned char *d = im->bins_block;
+    b->l = (uint64_t *)d;
+    b->r = (uint64_t *)(d + bytes_l);
+    b->w = (fp_t *)(d + 2*bytes_l);
+    b->tau = (fp_t *)(d + 2*bytes_l + bytes_w);
     return GRTCODE_SUCCESS;
 }
 
@@ -790,6 +861,10 @@ int grt_gas_optics_prepare(GasOptics_t *go, int ncol)
     if (im->store_dirty)
     {
         GRT_TRY(build_store(go));
+    }
+    if (go->optical_depth_method != line_sample && im->bins_block == NULL)
+    {
+        GRT_TRY(create_bin_arrays(go));
     }
     int const L = go->num_layers;
     int const S = go->num_molecules > 0 ? go->num_molecules : 1;
@@ -977,9 +1052,75 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
     return GRTCODE_SUCCESS;
 }
 
+/* launch.c:40-226 with optical_depth_method wavenumber_sweep / line_sweep, one column at a time: continua,
+   CFCs and CIA first (the line kernel with an empty line list writes exactly those), then molecule by
+   molecule the per-(layer, line) preparation, the per-layer sort (wavenumber_sweep) and the sweep, then the
+   interpolation of the bins' line-wing values onto the grid. */
+static int launch_sweep_columns(GasOptics_t *go, int ncol, double *tau_dev, uint64_t tau_col_stride)
+{
+    GrtGasOpticsImpl *im = impl_of(go);
+    void *s = grt_dev_stream(go->device);
+    int const L = go->num_layers;
+    uint64_t nmax = 0;
+    for (int sl = 0; sl < go->num_molecules; ++sl)
+    {
+        if (im->mstore[sl].n > nmax) nmax = im->mstore[sl].n;
+    }
+    if (nmax > 0 && im->sweep_scratch == NULL)
+    {
+        GRT_TRY(grt_dev_alloc(go->device, (void **)&im->sweep_scratch, sizeof(double)*8*(size_t)L*nmax));
+    }
+    GRT_TRY(grt_dev_upload(go->device, im->colstate_d, im->colstate_h, sizeof(double)*im->layout.stride*ncol, s));
+    GrtSweepBins bins = {go->bins.w0, go->bins.wres, go->bins.num_wpoints, go->bins.n, go->bins.ppb,
+                         go->bins.do_interp, go->bins.do_last_interp, go->bins.w, go->bins.tau, go->bins.l, go->bins.r};
+    int const method = go->optical_depth_method == wavenumber_sweep ? 0 : 1;
+    for (int c = 0; c < ncol; ++c)
+    {
+        double const *cs = im->colstate_d + (size_t)c*im->layout.stride;
+        double *tau = tau_dev + (size_t)c*tau_col_stride;
+        GrtGasOpticsArgs args;
+        GRT_TRY(grt_fill_gas_args(go, 1, tau, tau_col_stride, &args));
+        args.colstate = cs;
+        args.fast = 0;
+        args.nslice = 1;
+        GrtLineStore const all = args.lines;
+        args.lines.n = 0;
+        GRT_TRY(grt_dev_check(grt_launch_gas_optics(s, &args), "continuum pass"));
+        GRT_TRY(grt_dev_zero(go->device, go->bins.tau, sizeof(fp_t)*go->bins.isize*(size_t)L, s));
+        for (int sl = 0; sl < go->num_molecules; ++sl)
+        {
+            uint64_t const n = im->mstore[sl].n;
+            if (n == 0)
+            {
+                continue;
+            }
+            double *prep = im->sweep_scratch, *sorted = im->sweep_scratch + 4*(size_t)L*nmax;
+            args.lines = im->mstore[sl];
+            GRT_TRY(grt_dev_check(grt_launch_line_prep(s, &args, 0, prep, prep + (size_t)L*n, prep + 2*(size_t)L*n,
+                                                       prep + 3*(size_t)L*n, NULL, NULL), "line prep kernel"));
+            double const *lines = prep;
+            if (method == 0)
+            {
+                GRT_TRY(grt_dev_check(grt_launch_sweep_sort(s, n, L, im->mstore[sl].v0, im->mstore[sl].dmax,
+                                                            cs + im->layout.off_lay, prep, sorted), "sweep sort kernel"));
+                lines = sorted;
+            }
+            double const *ns = cs + im->layout.off_ms + ((size_t)sl*L)*4 + 2;
+            GRT_TRY(grt_dev_check(grt_launch_sweep(s, method, n, L, lines, ns, &bins, tau), "sweep kernel"));
+        }
+        args.lines = all;
+        GRT_TRY(grt_dev_check(grt_launch_sweep_interpolate(s, L, &bins, tau), "sweep interpolation kernel"));
+    }
+    return GRTCODE_SUCCESS;
+}
+
 static int launch_columns(GasOptics_t *go, int ncol, double *tau_dev, uint64_t tau_col_stride)
 {
     GrtGasOpticsImpl *im = impl_of(go);
+    if (go->optical_depth_method != line_sample)
+    {
+        return launch_sweep_columns(go, ncol, tau_dev, tau_col_stride);
+    }
     void *s = grt_dev_stream(go->device);
     GrtGasOpticsArgs args;
     GRT_TRY(grt_fill_gas_args(go, ncol, tau_dev, tau_col_stride, &args));

@@ -72,6 +72,11 @@ typedef struct GrtGasOpticsImpl
     int store_dirty;               /* merged device store must be (re)built */
     GrtLineStore store;            /* device SoA, sorted by centre */
     void *store_block;             /* single device allocation backing `store` */
+    /* sweep methods only: one store per molecule (each sorted by centre), prep/sort scratch, bin arrays */
+    GrtLineStore mstore[NUM_MOLS];
+    void *mstore_block[NUM_MOLS];
+    double *sweep_scratch;         /* device [2][4][L][max lines of a molecule] */
+    void *bins_block;              /* device allocation backing bins.w / bins.l / bins.r / bins.tau */
     /* spectral tables on device, each [n]: */
     double *h2o_tables;            /* [4][n] F296,S296,CKDF,CKDS or NULL */
     double *lin_tables;            /* [GRT_MAX_TABLES][n]; row k used when k < num_lin */

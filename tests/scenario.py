@@ -58,11 +58,11 @@ class Band:
         return orc.interp_to_grid(self.w0, self.dw, self.nw, w, y, constant_extrap)
 
     # -- the product ------------------------------------------------------------------- #
-    def gas_optics(self, device, num_levels, from_file=True):
+    def gas_optics(self, device, num_levels, from_file=True, method=api.LINE_SAMPLE):
         grid = api.create_spectral_grid(self.w0, self.wn, self.dw)
         go = api.GasOpticsObject(num_levels, grid, device, self.par,
                                  self.h2o_dir if self.with_ctm else None,
-                                 self.files["o3_ctm"] if self.with_ctm else None)
+                                 self.files["o3_ctm"] if self.with_ctm else None, method=method)
         for m in self.mols:
             if from_file:
                 go.add_molecule(m)
