@@ -324,6 +324,15 @@ EXTERN int create_gas_optics(GasOptics_t * const gas_optics, int const num_level
         GRT_FAIL(GRTCODE_NULL_ERR, "out of host memory for the gas-optics state.%s", "");
     }
     go->impl = im;
+    {
+        /* arithmetic form of the line kernel for callers that cannot call grt_gas_optics_tune (an unchanged
+           reference driver): GRT_GAS_OPTICS_FAST=0|1|2 in the environment; default 0 (reference order) */
+        char const *env = getenv("GRT_GAS_OPTICS_FAST");
+        if (env != NULL && env[0] >= '0' && env[0] <= '2' && env[1] == '\0')
+        {
+            im->fast = env[0] - '0';
+        }
+    }
     size_t const V = (size_t)num_levels;
     go->x = calloc(NUM_MOLS*V, sizeof(fp_t));
     go->x_cfc = calloc(NUM_CFCS*V, sizeof(fp_t));

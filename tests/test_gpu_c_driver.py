@@ -62,12 +62,18 @@ def test_c_driver_on_static_archives_matches_oracle(tmp_path, oracle, lib):
             "-N2-N2", swb.files["cia_n2n2"], "-O2-N2", swb.files["cia_o2n2"], "-O2-O2", swb.files["cia_o2o2"],
             "-a", repr(albedo), "-flux-at-level", str(user_level),
             "-w-lw", "1", "-W-lw", "3250", "-r-lw", "0.5", "-w-sw", "1", "-W-sw", "20000", "-r-sw", "2"]
-    r = subprocess.run(args, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = [s for s in r.stdout.splitlines() if s.startswith("fluxes:")]
-    assert len(line) == 1
-    got = np.array([float(x) for x in line[0].split()[1:]])
-    assert got.size == 12
+    def fluxes(env_extra):
+        r = subprocess.run(args, capture_output=True, text=True, timeout=600, env=dict(os.environ, **env_extra))
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [s for s in r.stdout.splitlines() if s.startswith("fluxes:")]
+        assert len(line) == 1
+        out = np.array([float(x) for x in line[0].split()[1:]])
+        assert out.size == 12
+        return out
+    got = fluxes({})
+    # the same unchanged binary with the production arithmetic selected from the environment
+    fast = fluxes({"GRT_GAS_OPTICS_FAST": "1"})
+    assert 0.0 < np.max(np.abs(fast - got)) < 1e-4
     from grtcode_amd import api
     grid_sw = api.create_spectral_grid(swb.w0, swb.wn, swb.dw)
     solar = api.create_solar_flux(grid_sw, swb.files["solar"])
