@@ -443,7 +443,11 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
                             nq->repwid[q][wave][pos] = repwid;
                             // the Lorentzian this point also receives (ring: the very same instruction
                             // sequence, so it cancels exactly; moments: to ~1e-8), to be taken back
+#if defined(GRT_MP_NORING)
+                            nq->far[q][wave][pos] = 0.f*cl*__builtin_amdgcn_rcpf(fmaf(xi, xi, yq));
+#else
                             nq->far[q][wave][pos] = cl*__builtin_amdgcn_rcpf(fmaf(xi, xi, yq));
+#endif
                             nq->idx[q][wave][pos] = (unsigned short)(f - F0);
                         }
                         qcount[q] += npush;

@@ -40,9 +40,9 @@ def band_lines(total, grid, seed):
     return {m: lists[m] for m in MOL_ORDER}
 
 
-def build_band(device, grid_spec, lines, files, num_levels=NUM_LEVELS):
+def build_band(device, grid_spec, lines, files, num_levels=NUM_LEVELS, method=api.LINE_SAMPLE):
     grid = api.create_spectral_grid(*grid_spec)
-    go = api.GasOpticsObject(num_levels, grid, device, "", files["h2o_dir"], files["o3_ctm"])
+    go = api.GasOpticsObject(num_levels, grid, device, "", files["h2o_dir"], files["o3_ctm"], method=method)
     for m in MOL_ORDER:
         go.add_molecule_lines(m, lines[m])
     go.add_cfc(0, files["cfc11"])
