@@ -346,15 +346,27 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
             float const amp_f = valid ? (float)(amp*(double)((cl*rwr)*rwr)) : 0.f;
             float m[kMom];
             {
-                float u = 1.f, pk = 0.f;                    // Re z^k, Im z^k / eta
+                float u = amp_f, pk = 0.f;                  // A Re z^k, A Im z^k / eta
 #pragma unroll
                 for (int k = 0; k < kMom; ++k)
                 {
                     float const un = fmaf(delta, u, -eta2*pk);
                     pk = fmaf(delta, pk, u);
                     u = un;
-                    m[k] = amp_f*pk;
+                    m[k] = pk;
                 }
+            }
+            // lines are sorted by centre: most waves sit in one cell (longwave: ~300 lines per cell)
+            unsigned long long const vmask = __ballot(valid);
+            int const c_ref = __builtin_amdgcn_readlane(c, __builtin_ctzll(vmask));
+            if (__ballot(valid & (c != c_ref)) == 0ull)
+            {
+                float const t = row_sum_transposed(m, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0);
+                if ((lane & 1) == 0)
+                {
+                    unsafeAtomicAdd(&mom[((lane >> 1) & 7)*ncell + (c_ref - cell0)], t);
+                }
+                goto moments_done;
             }
             int const cmin = wave_min_s(valid ? c : 0x7fffffff);
             int const cmax = wave_max_s(valid ? c : (int)0x80000000);
@@ -391,6 +403,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
                 }
             }
         }
+        moments_done:
 
         // ---- pre-pass 1: near-centre points (|x| < XLIM1: Humlicek regions 2-4) go to the queue.
         // Each lane walks the few grid points around ITS OWN line centre: the integers r with
@@ -399,7 +412,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
         bool const voigt_line = valid & !lorentz;
         {
             float const delta = dc*inv_wres_f;
-            float const span = fmaf(sqrtf(fmaxf(xq_near, 0.f))*rwr, 1.000001f, 1e-6f);
+            float const span = fmaf(xlim1*rwr, 1.000001f, 1e-6f);
             int const r_first = (int)floorf(delta - span) + 1;      // smallest integer > delta - span
             int const r_last = (int)ceilf(delta + span) - 1;        // largest integer < delta + span
             int const count = voigt_line ? r_last - r_first + 1 : 0;
