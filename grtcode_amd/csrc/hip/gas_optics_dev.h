@@ -141,10 +141,11 @@ template <bool FAST>
 __device__ __forceinline__ VoigtLimits voigt_limits(float y)
 {
     VoigtLimits l;
-    // the reference takes the square roots in double and narrows; the correctly rounded sqrtf gives
-    // the same float (53 >= 2*24 + 2 bits)
+    // the reference takes the square roots in double and narrows (the correctly rounded sqrtf would give
+    // the same float: 53 >= 2*24 + 2 bits); the fused form takes the hardware square root (1 ulp): the
+    // limits only decide which formula a point within an ulp of a region boundary takes
     float const r1 = 164.0f - y*(4.3f + y*1.8f);
-    l.xlim1 = (y >= 8.425f) ? 0.0f : (FAST ? sqrtf(r1) : (float)sqrt((double)r1));
+    l.xlim1 = (y >= 8.425f) ? 0.0f : (FAST ? __builtin_amdgcn_sqrtf(r1) : (float)sqrt((double)r1));
     l.xlim2 = 6.8f - y;
     l.xlim3 = 2.4f*y;
     l.xlim4 = 18.1f*y + 1.65f;
@@ -152,7 +153,7 @@ __device__ __forceinline__ VoigtLimits voigt_limits(float y)
     {
         // RFM_voigt.c:122-126: no Lorentz width -> regions 1 and 2 are switched off
         float const r0 = 15100.0f + y*(40.0f - y*3.6f);
-        float const xlim0 = FAST ? sqrtf(r0) : (float)sqrt((double)r0);
+        float const xlim0 = FAST ? __builtin_amdgcn_sqrtf(r0) : (float)sqrt((double)r0);
         l.xlim1 = xlim0;
         l.xlim2 = xlim0;
     }
