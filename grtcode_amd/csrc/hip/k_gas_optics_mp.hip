@@ -33,7 +33,7 @@ namespace {
 
 constexpr int kMom = 8;         // moments per cell
 constexpr int kRcap = 12;       // widest near field taken for the sake of region 1 (the moment bound may ask for more)
-constexpr int kCellLoop = 4;    // waves whose lines span at most this many cells reduce in registers first
+constexpr int kCellLoop = 3;    // passes of the in-register moment reduction before falling back to per-lane adds
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v)
@@ -368,33 +368,32 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
                 }
                 goto moments_done;
             }
-            int const cmin = wave_min_s(valid ? c : 0x7fffffff);
-            int const cmax = wave_max_s(valid ? c : (int)0x80000000);
-            if (cmax - cmin < kCellLoop)
+            // Several cells in the wave: every row of 16 lanes works on ITS lowest pending cell, so one pass
+            // serves four cells at once; sorted lines rarely put more than two cells in a row.  Whatever is
+            // still pending after kCellLoop passes (sparse spectra: a cell per line) is added lane by lane.
+            bool pending = valid;
+            for (int pass = 0; pass < kCellLoop && __ballot(pending) != 0ull; ++pass)
             {
-                // the usual case: the wave's 64 lines (sorted by centre) share one or two cells.  Reduce
-                // in registers, then one LDS add per (row, moment): 32 lanes, 4 per address.
-                for (int cc = cmin; cc <= cmax; ++cc)
-                {
-                    bool const mine = valid & (c == cc);
-                    if (__ballot(mine) == 0ull)
-                    {
-                        continue;
-                    }
-                    float mm[kMom];
+                int cr = pending ? c : 0x7fffffff;
+                cr = min(cr, dpp_i<0x121>(cr));
+                cr = min(cr, dpp_i<0x122>(cr));
+                cr = min(cr, dpp_i<0x124>(cr));
+                cr = min(cr, dpp_i<0x128>(cr));                      // the row's lowest pending cell, in every lane
+                bool const mine = pending & (c == cr);
+                float mm[kMom];
 #pragma unroll
-                    for (int k = 0; k < kMom; ++k)
-                    {
-                        mm[k] = mine ? m[k] : 0.f;
-                    }
-                    float const t = row_sum_transposed(mm, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0);
-                    if ((lane & 1) == 0)
-                    {
-                        unsafeAtomicAdd(&mom[((lane >> 1) & 7)*ncell + (cc - cell0)], t);
-                    }
+                for (int k = 0; k < kMom; ++k)
+                {
+                    mm[k] = mine ? m[k] : 0.f;
                 }
+                float const t = row_sum_transposed(mm, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0);
+                if (((lane & 1) == 0) & (cr != 0x7fffffff))
+                {
+                    unsafeAtomicAdd(&mom[((lane >> 1) & 7)*ncell + (cr - cell0)], t);
+                }
+                pending = pending & !mine;
             }
-            else if (valid)
+            if (pending)
             {
 #pragma unroll
                 for (int k = 0; k < kMom; ++k)
