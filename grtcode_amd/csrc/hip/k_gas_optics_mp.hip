@@ -219,7 +219,9 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
         }
         double const w_hi = a.w0 + (double)(F1l + fsteps)*a.wres;
         double const alpha_max = 0.83255461115*w_hi*dop;
-        double const reach = 123.4*alpha_max/(0.832554611*a.wres) + 2.;
+        // (a performance choice, not a bound the results depend on: region-1 points beyond R are picked up
+        // line by line in pre-pass 2; shrinking R below this estimate was measured slower)
+        double const reach = 123.4*alpha_max/(0.832554611*a.wres) + 0.51;
         int const r_reg1 = reach < (double)kRcap ? (int)reach : kRcap;
         R = r_lo > r_reg1 ? r_lo : r_reg1;
         use_moments = (R + 4 <= fsteps);
