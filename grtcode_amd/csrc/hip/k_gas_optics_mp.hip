@@ -304,7 +304,11 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
                 stim = 1.0 - exp_fast(x2);
             }
             double const snn = ln.s0*exp_fast((c2*(double)ln.en)*invT)*stim*q_l[ln.slot*GRT_MAX_ISO + ln.iso - 1];   // :83-85
-            amp = snn*ms[2];                                                          // snn*n (kernels.c:459)
+            // snn*n (kernels.c:459), rounded to fp32 ONCE and used in that form everywhere (ring, queue,
+            // moments): the near-centre queue takes back amp*K_lorentz that the ring added, and at a grid
+            // point that happens to sit on a narrow line's centre K_lorentz is hundreds of times the true
+            // value -- the two products must be of the very same amp to cancel
+            amp = (double)(float)(snn*ms[2]);
             double const gamma = exp_fast((double)ln.nexp*lay[3])
                                  *fma((double)ln.yair, ms[1], (double)ln.yself*ms[0]);   // kernels.c:105-106
             double const alpha = ((double)0.83255461115f*wnoadj)*ms[3];                       // kernels.c:127
