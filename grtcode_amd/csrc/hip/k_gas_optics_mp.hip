@@ -246,77 +246,57 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
 
     for (uint64_t base = jbeg + (uint64_t)wave*64; base < jend; base += kBlock)
     {
+        // Lanes past the end of the range prepare the last line again and are masked at the end: straight
+        // line code for the whole wave instead of nested divergent regions.
         uint64_t const j = base + lane;
-        RawLine ln = {};
-        if (j < jend)
-        {
-            ln = load_line(a.lines, j);
-        }
+        bool const have = j < jend;
+        RawLine const ln = load_line(a.lines, have ? j : jend - 1);
         // kernels.c:34-131 for this (layer, line) in the fused form's arithmetic: shifted centre, centre
         // index and Doppler width in fp64 exactly as the reference-order kernels (prepare_line); S(T) in
         // fp64 with hardware exp2.
-        int s = 1, lo = 1, hi = 0, c = 0;
-        bool valid = false;
-        double wnoadj = 0., amp = 0.;
-        float repwid = 1.f, y = 0.f;
-        if (j < jend)
+        double const *ms = ms_l + ln.slot*4;
+        double const wnoadj = ln.v0 + (double)ln.delta*lay[0];                         // kernels.c:44
+        // kernels.c:431-432: fcenterid = floor((2*((vnn - w0)/wres) + 1)/2), bit-exact (see prepare_line)
+        double const dv = wnoadj - a.w0;
+        double u = (2*(dv*inv_wres) + 1)/2;
+        if (fabs(u - rint(u)) <= 4e-15*fmax(1., fabs(u)))
         {
-            double const *ms = ms_l + ln.slot*4;
-            double const vnn = ln.v0 + (double)ln.delta*lay[0];                        // kernels.c:44
-            // kernels.c:431-432: fcenterid = floor((2*((vnn - w0)/wres) + 1)/2), bit-exact (see prepare_line)
-            double const dv = vnn - a.w0;
-            double u = (2*(dv*inv_wres) + 1)/2;
-            if (fabs(u - rint(u)) <= 4e-15*fmax(1., fabs(u)))
-            {
-                u = (2*(dv/a.wres) + 1)/2;
-            }
-            double const fc = floor(u);
-            if (fc >= 0. && fc < (double)nw_i)
-            {
-                int const ci = (int)fc;
-                int const s_i = ci - fsteps < 0 ? 0 : ci - fsteps;                     // kernels.c:435
-                int const e_i = ci + fsteps >= nw_i ? nw_i - 1 : ci + fsteps;          // kernels.c:436-437
-                if (s_i < F1 && e_i >= F0)
-                {
-                    valid = true;
-                    c = ci;
-                    s = s_i;
-                    lo = s_i > F0 ? s_i : F0;
-                    hi = e_i < F1 - 1 ? e_i : F1 - 1;
-                    wnoadj = vnn;
-                }
-            }
+            u = (2*(dv/a.wres) + 1)/2;
         }
+        double const fc = floor(u);
+        bool valid = have & (fc >= 0.) & (fc < (double)nw_i);
+        int const c = valid ? (int)fc : 0;
+        int const s = c - fsteps < 0 ? 0 : c - fsteps;                                 // kernels.c:435
+        int const e_i = c + fsteps >= nw_i ? nw_i - 1 : c + fsteps;                    // kernels.c:436-437
+        valid = valid & (s < F1) & (e_i >= F0);
         if (__ballot(valid) == 0ull)
         {
             continue;
         }
-        if (valid)
+        int const lo = valid ? (s > F0 ? s : F0) : 1;
+        int const hi = valid ? (e_i < F1 - 1 ? e_i : F1 - 1) : 0;
+        double const c2 = -1.4387686f;                                                 // kernels.c:75
+        double const invT = lay[2];
+        // stimulated emission 1 - exp(c2 v0/T): below exp(-20) = 2e-9 the factor is 1 to fp32 and beyond
+        double const x2 = (c2*ln.v0)*invT;
+        double stim = 1.0;
+        if (__ballot(valid & (x2 > -20.)) != 0ull)
         {
-            double const *ms = ms_l + ln.slot*4;
-            double const c2 = -1.4387686f;                                             // kernels.c:75
-            double const invT = lay[2];
-            // stimulated emission 1 - exp(c2 v0/T): below exp(-20) = 2e-9 the factor is 1 to fp32 and beyond
-            double const x2 = (c2*ln.v0)*invT;
-            double stim = 1.0;
-            if (__ballot(x2 > -20.) != 0ull)
-            {
-                stim = 1.0 - exp_fast(x2);
-            }
-            double const snn = ln.s0*exp_fast((c2*(double)ln.en)*invT)*stim*q_l[ln.slot*GRT_MAX_ISO + ln.iso - 1];   // :83-85
-            // snn*n (kernels.c:459), rounded to fp32 ONCE and used in that form everywhere (ring, queue,
-            // moments): the near-centre queue takes back amp*K_lorentz that the ring added, and at a grid
-            // point that happens to sit on a narrow line's centre K_lorentz is hundreds of times the true
-            // value -- the two products must be of the very same amp to cancel
-            amp = (double)(float)(snn*ms[2]);
-            double const gamma = exp_fast((double)ln.nexp*lay[3])
-                                 *fma((double)ln.yair, ms[1], (double)ln.yself*ms[0]);   // kernels.c:105-106
-            double const alpha = ((double)0.83255461115f*wnoadj)*ms[3];                       // kernels.c:127
-            // RFM_voigt.c:94, rounded as the reference's REPWID (see k_gas_optics.hip)
-            double const r0 = (double)__builtin_amdgcn_rcpf((float)alpha);
-            repwid = (float)((double)kSqrln2*(r0*fma(-alpha, r0, 2.0)));
-            y = (float)((double)repwid*gamma);                                        // RFM_voigt.c:95
+            stim = 1.0 - exp_fast(x2);
         }
+        double const snn = ln.s0*exp_fast((c2*(double)ln.en)*invT)*stim*q_l[ln.slot*GRT_MAX_ISO + ln.iso - 1];   // :83-85
+        // snn*n (kernels.c:459), rounded to fp32 ONCE and used in that form everywhere (ring, queue,
+        // moments): the near-centre queue takes back amp*K_lorentz that the ring added, and at a grid
+        // point that happens to sit on a narrow line's centre K_lorentz is hundreds of times the true
+        // value -- the two products must be of the very same amp to cancel
+        double const amp = valid ? (double)(float)(snn*ms[2]) : 0.;
+        double const gamma = exp_fast((double)ln.nexp*lay[3])
+                             *fma((double)ln.yair, ms[1], (double)ln.yself*ms[0]);       // kernels.c:105-106
+        double const alpha = ((double)0.83255461115f*wnoadj)*ms[3];                    // kernels.c:127
+        // RFM_voigt.c:94, rounded as the reference's REPWID (see k_gas_optics.hip)
+        double const r0 = (double)__builtin_amdgcn_rcpf((float)alpha);
+        float const repwid = (float)((double)kSqrln2*(r0*fma(-alpha, r0, 2.0)));
+        float const y = (float)((double)repwid*gamma);                                 // RFM_voigt.c:95
         bool const lorentz = (y >= 70.55f);                                           // RFM_voigt.c:97
         float const yq = y*y;
         // thresholds: hardware square roots (1 ulp) -- they only decide which formula a point within
