@@ -11,10 +11,11 @@
 // -ffp-contract=off), one molecule at a time, as gas-optics/src/launch.c:78-159 does.
 //
 // Mapping: the reference's "one thread per (layer, bin)" (wavenumber_sweep) and "one thread per
-// (layer, line)" (line_sweep) become one workgroup per (layer, bin) -- lines strided over the lanes,
-// three register partial sums per lane for the remote lines, LDS accumulators for the bin's own points
-// -- and one lane per (layer, line) with global atomics.  Neither is the headline path (the drivers use
-// line_sample, driver.c:618-624); they are kept simple.
+// (layer, line)" with atomics (line_sweep) both become one workgroup per (layer, bin) -- lines strided
+// over the lanes, three register partial sums per lane for the remote lines, LDS accumulators for the
+// bin's own points, no global atomics.  For line_sweep that works because the bins a line is local or
+// remote to are monotone functions of its centre, so a bin's lines are index ranges of the sorted
+// centres.  Neither is the headline path (the drivers use line_sample, driver.c:618-624).
 #include "gas_optics_dev.h"
 
 namespace {
@@ -154,14 +155,44 @@ __global__ __launch_bounds__(256) void sweep_sort_kernel(uint64_t n, double cons
     alpha_s[o + rank] = alpha[o + k];
 }
 
-// calc_optical_depth_bin_sweep (kernels.c:176-307): workgroup = (bin j, layer i).
+// line_sweep's bin ranges (kernels.c:329-390) as functions of the line centre: all four are monotone
+// non-decreasing in v, so "the lines that are local / remote to bin k" are contiguous index ranges of the
+// per-layer sorted centres, found by binary search with these very expressions.
+struct LineSweepBins
+{
+    double w0, bin_width, maxw;
+    __device__ uint64_t left(double v) const { double w = v - (double)1.5f; if (w < w0) w = w0; return (uint64_t)floor((w - w0)/bin_width); }
+    __device__ uint64_t right(double v) const { double w = v + (double)1.5f; if (w > maxw) w = maxw; return (uint64_t)floor((w - w0)/bin_width); }
+    __device__ uint64_t left_r(double v) const { double w = v - (double)25.f; if (w < w0) w = w0; return (uint64_t)floor((w - w0)/bin_width); }
+    __device__ uint64_t right_r(double v) const { double w = v + (double)25.f; if (w > maxw) w = maxw; return (uint64_t)floor((w - w0)/bin_width); }
+};
+
+// first index in [0, n) whose value f(v[idx]) >= k (n if none): f monotone non-decreasing
+template <typename F>
+__device__ uint64_t first_at_least(uint64_t n, double const *v, uint64_t k, F f)
+{
+    uint64_t lo = 0, hi = n;
+    while (lo < hi)
+    {
+        uint64_t const mid = lo + (hi - lo)/2;
+        if (f(v[mid]) >= k) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+// calc_optical_depth_bin_sweep (kernels.c:176-307), METHOD 0, and calc_optical_depth_line_sweep
+// (kernels.c:311-406) turned bin-parallel, METHOD 1: workgroup = (bin j, layer i); the lines are sorted by
+// shifted centre per layer.  For METHOD 1 bins past the last one (the reference indexes bin `n` for lines near
+// the top of the grid: its maxw lies a grid step beyond the last point) never come up here; the reference reads
+// and writes out of bounds for them.
+template <int METHOD>
 __global__ __launch_bounds__(256) void bin_sweep_kernel(uint64_t num_lines, double const *vnn, double const *snn,
                                                         double const *gamma, double const *alpha,
                                                         double const *ns /* ms[slot][.][2], stride 4 */,
                                                         SweepBins bins, double *tau)
 {
     extern __shared__ double tloc[];            // [ppb] the bin's own grid points
-    __shared__ uint64_t range[6];               // left, right, has_local, left_r, right_r, flags
+    __shared__ uint64_t range[7];               // local [0,1] + flag [2]; remote ranges [3,6) and [4,5]
     __shared__ double red[3][4];
     uint64_t const j = blockIdx.x;
     int const i = blockIdx.y;
@@ -176,7 +207,20 @@ __global__ __launch_bounds__(256) void bin_sweep_kernel(uint64_t num_lines, doub
     {
         tloc[p] = 0.;
     }
-    if (tid == 0)
+    if (tid == 0 && METHOD == 1)
+    {
+        LineSweepBins const b = {bins.w0, bins.wres*bins.ppb, bins.w0 + bins.num_wpoints*bins.wres};
+        // local: left(v) <= j <= right(v); remote left of the line: left_r(v) <= j < left(v); right: right(v) < j <= right_r(v)
+        uint64_t const loc_b = first_at_least(num_lines, v, j, [&](double x) { return b.right(x); });
+        uint64_t const loc_e = first_at_least(num_lines, v, j + 1, [&](double x) { return b.left(x); });      // left(v) > j
+        uint64_t const rl_e = first_at_least(num_lines, v, j + 1, [&](double x) { return b.left_r(x); });     // left_r(v) > j
+        uint64_t const rr_b = first_at_least(num_lines, v, j, [&](double x) { return b.right_r(x); });
+        // as seen from the BIN: lines to its right have the bin on their remote-left side and vice versa
+        range[0] = loc_b; range[1] = loc_e - 1; range[2] = loc_e > loc_b ? 1 : 0;
+        range[3] = rr_b; range[6] = loc_b;              // [rr_b, loc_b): right(v) < j <= right_r(v)
+        range[4] = loc_e; range[5] = rl_e - 1;          // [loc_e, rl_e): left_r(v) <= j < left(v)
+    }
+    if (tid == 0 && METHOD == 0)
     {
         uint64_t const nbin_local = 1, nbin_remote = 25;
         uint64_t nbin = nbin_local;
@@ -220,9 +264,11 @@ __global__ __launch_bounds__(256) void bin_sweep_kernel(uint64_t num_lines, doub
             first_r = right + 1;
         }
         range[0] = left; range[1] = right; range[2] = has_local; range[3] = left_r; range[4] = first_r; range[5] = right_r;
+        range[6] = left;
     }
     __syncthreads();
     uint64_t const left = range[0], right = range[1], left_r = range[3], first_r = range[4], right_r = range[5];
+    uint64_t const left_end = range[6];
     // "local" lines on the bin's own grid points (kernels.c:213-231)
     if (range[2] != 0)
     {
@@ -242,7 +288,7 @@ __global__ __launch_bounds__(256) void bin_sweep_kernel(uint64_t num_lines, doub
     for (int side = 0; side < 2; ++side)
     {
         uint64_t const kb = side == 0 ? left_r : first_r;
-        uint64_t const ke = side == 0 ? left : right_r + 1;         // [kb, ke)
+        uint64_t const ke = side == 0 ? left_end : right_r + 1;     // [kb, ke)
         for (uint64_t k = kb + tid; k < ke; k += 256)
         {
             LineShape const sh = make_shape(v[k], g[k], a[k]);
@@ -274,75 +320,6 @@ __global__ __launch_bounds__(256) void bin_sweep_kernel(uint64_t num_lines, doub
     for (uint64_t p = tid; p < np; p += 256)
     {
         tau[(uint64_t)i*bins.num_wpoints + bins.l[j] + p] += tloc[p];
-    }
-}
-
-// calc_optical_depth_line_sweep (kernels.c:311-406): one lane per (layer, line), global atomics.  Bins past
-// the last one (the reference indexes bin `n` for lines near the top of the grid: maxw lies a grid step
-// beyond the last point) are skipped; the reference reads and writes out of bounds for them.
-__global__ __launch_bounds__(256) void line_sweep_kernel(uint64_t num_lines, double const *vnn, double const *snn,
-                                                         double const *gamma, double const *alpha, double const *ns,
-                                                         SweepBins bins, double *tau)
-{
-    uint64_t const j = (uint64_t)blockIdx.x*256 + threadIdx.x;
-    int const i = blockIdx.y;
-    if (j >= num_lines)
-    {
-        return;
-    }
-    uint64_t const o = (uint64_t)i*num_lines + j;
-    double const bin_width = bins.wres*bins.ppb;
-    double const n_i = ns[4*i];
-    LineShape const sh = make_shape(vnn[o], gamma[o], alpha[o]);
-    double const amp = snn[o]*n_i;
-    double wcutoff = 1.5f;
-    double leftw = vnn[o] - wcutoff;
-    if (leftw < bins.w0)
-    {
-        leftw = bins.w0;
-    }
-    uint64_t const left = (uint64_t)floor((leftw - bins.w0)/bin_width);
-    double rightw = vnn[o] + wcutoff;
-    double const maxw = bins.w0 + bins.num_wpoints*bins.wres;
-    if (rightw > maxw)
-    {
-        rightw = maxw;
-    }
-    uint64_t const right = (uint64_t)floor((rightw - bins.w0)/bin_width);
-    for (uint64_t k = left; k <= right && k < bins.n; ++k)
-    {
-        double const w = bins.w0 + bins.l[k]*bins.wres;
-        for (uint64_t l = bins.l[k]; l <= bins.r[k]; ++l)
-        {
-            unsafeAtomicAdd(&tau[(uint64_t)i*bins.num_wpoints + l], amp*shape_value(sh, w, (int)(l - bins.l[k]), bins.wres));
-        }
-    }
-    wcutoff = 25.f;
-    leftw = vnn[o] - wcutoff;
-    if (leftw < bins.w0)
-    {
-        leftw = bins.w0;
-    }
-    uint64_t const left_r = (uint64_t)floor((leftw - bins.w0)/bin_width);
-    rightw = vnn[o] + wcutoff;
-    if (rightw > maxw)
-    {
-        rightw = maxw;
-    }
-    uint64_t const right_r = (uint64_t)floor((rightw - bins.w0)/bin_width);
-    for (int side = 0; side < 2; ++side)
-    {
-        uint64_t const kb = side == 0 ? left_r : right + 1;
-        uint64_t const ke = side == 0 ? left : right_r + 1;
-        for (uint64_t k = kb; k < ke && k < bins.n; ++k)
-        {
-            double const w = bins.w[k*kNip], wr = bins.w[k*kNip + 1] - w;
-#pragma unroll
-            for (int p = 0; p < kNip; ++p)
-            {
-                unsafeAtomicAdd(&bins.tau[((uint64_t)i*bins.n + k)*kNip + p], amp*shape_value(sh, w, p, wr));
-            }
-        }
     }
 }
 
@@ -411,12 +388,16 @@ extern "C" int grt_launch_sweep(void *stream, int method, uint64_t n, int num_la
         {
             return (int)hipErrorInvalidValue;
         }
-        hipLaunchKernelGGL(bin_sweep_kernel, dim3((unsigned)b->n, num_layers), dim3(256), sizeof(double)*(size_t)b->ppb, s,
+        hipLaunchKernelGGL(bin_sweep_kernel<0>, dim3((unsigned)b->n, num_layers), dim3(256), sizeof(double)*(size_t)b->ppb, s,
                            n, lines, lines + ln, lines + 2*ln, lines + 3*ln, ns, bins, tau);
     }
-    else
+    else if (method == 1)
     {
-        hipLaunchKernelGGL(line_sweep_kernel, dim3((unsigned)((n + 255)/256), num_layers), dim3(256), 0, s,
+        if (b->n > 0x7fffffffull)
+        {
+            return (int)hipErrorInvalidValue;
+        }
+        hipLaunchKernelGGL(bin_sweep_kernel<1>, dim3((unsigned)b->n, num_layers), dim3(256), sizeof(double)*(size_t)b->ppb, s,
                            n, lines, lines + ln, lines + 2*ln, lines + 3*ln, ns, bins, tau);
     }
     return (int)hipGetLastError();

@@ -1108,7 +1108,8 @@ static int launch_sweep_columns(GasOptics_t *go, int ncol, double *tau_dev, uint
             GRT_TRY(grt_dev_check(grt_launch_line_prep(s, &args, 0, prep, prep + (size_t)L*n, prep + 2*(size_t)L*n,
                                                        prep + 3*(size_t)L*n, NULL, NULL), "line prep kernel"));
             double const *lines = prep;
-            if (method == 0)
+            /* wavenumber_sweep needs the reference's per-layer sort_lines; line_sweep runs bin-parallel here,
+               which needs the same order */
             {
                 GRT_TRY(grt_dev_check(grt_launch_sweep_sort(s, n, L, im->mstore[sl].v0, im->mstore[sl].dmax,
                                                             cs + im->layout.off_lay, prep, sorted), "sweep sort kernel"));
