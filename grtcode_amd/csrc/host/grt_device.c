@@ -162,6 +162,43 @@ int grt_dev_sync(Device_t device, void *stream)
     return GRTCODE_SUCCESS;
 }
 
+/* Events: "the uploads of this batch have left the staging buffer", so the host may refill it while the
+   batch's kernels still run.  *ev is created on first use; waiting on an event that was never recorded
+   returns at once. */
+int grt_dev_event_record(Device_t device, void **ev, void *stream)
+{
+    GRT_TRY(grt_dev_require(device));
+    if (*ev == NULL)
+    {
+        hipEvent_t e;
+        GRT_TRY(grt_dev_check((int)hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"));
+        *ev = (void *)e;
+    }
+    GRT_TRY(grt_dev_check((int)hipEventRecord((hipEvent_t)*ev, (hipStream_t)stream), "hipEventRecord"));
+    return GRTCODE_SUCCESS;
+}
+
+int grt_dev_event_wait(Device_t device, void *ev)
+{
+    if (ev != NULL)
+    {
+        GRT_TRY(grt_dev_require(device));
+        GRT_TRY(grt_dev_check((int)hipEventSynchronize((hipEvent_t)ev), "hipEventSynchronize"));
+    }
+    return GRTCODE_SUCCESS;
+}
+
+int grt_dev_event_destroy(Device_t device, void **ev)
+{
+    if (*ev != NULL)
+    {
+        GRT_TRY(grt_dev_require(device));
+        GRT_TRY(grt_dev_check((int)hipEventDestroy((hipEvent_t)*ev), "hipEventDestroy"));
+        *ev = NULL;
+    }
+    return GRTCODE_SUCCESS;
+}
+
 int grt_host_alloc_pinned(void **p, size_t bytes)
 {
     GRT_REQUIRE_PTR(p);

@@ -377,6 +377,7 @@ EXTERN int destroy_gas_optics(GasOptics_t * const gas_optics)
         GRT_TRY(grt_dev_free(gas_optics->device, im->lin_tables));
         GRT_TRY(grt_dev_free(gas_optics->device, im->colstate_d));
         GRT_TRY(grt_host_free_pinned(im->colstate_h));
+        GRT_TRY(grt_dev_event_destroy(gas_optics->device, &im->colstate_uploaded));
         free(im);
     }
     free(gas_optics->h2o_cc.coefs);
@@ -1080,6 +1081,7 @@ static int launch_sweep_columns(GasOptics_t *go, int ncol, double *tau_dev, uint
         GRT_TRY(grt_dev_alloc(go->device, (void **)&im->sweep_scratch, sizeof(double)*8*(size_t)L*nmax));
     }
     GRT_TRY(grt_dev_upload(go->device, im->colstate_d, im->colstate_h, sizeof(double)*im->layout.stride*ncol, s));
+    GRT_TRY(grt_dev_event_record(go->device, &im->colstate_uploaded, s));
     GrtSweepBins bins = {go->bins.w0, go->bins.wres, go->bins.num_wpoints, go->bins.n, go->bins.ppb,
                          go->bins.do_interp, go->bins.do_last_interp, go->bins.w, go->bins.tau, go->bins.l, go->bins.r};
     int const method = go->optical_depth_method == wavenumber_sweep ? 0 : 1;
@@ -1136,6 +1138,7 @@ static int launch_columns(GasOptics_t *go, int ncol, double *tau_dev, uint64_t t
     GRT_TRY(grt_fill_gas_args(go, ncol, tau_dev, tau_col_stride, &args));
     GRT_TRY(grt_dev_upload(go->device, im->colstate_d, im->colstate_h,
                            sizeof(double)*im->layout.stride*ncol, s));
+    GRT_TRY(grt_dev_event_record(go->device, &im->colstate_uploaded, s));
     if (args.nslice > 1)
     {
         /* slices accumulate with atomics (launch.c:61 zeroes tau in every case) */
@@ -1205,6 +1208,14 @@ static int batch_column_states(GasOptics_t *go, GrtColumns_t const *cols)
     return GRTCODE_SUCCESS;
 }
 
+int grt_gas_optics_wait_staging(GasOptics_t *go)
+{
+    GRT_REQUIRE_PTR(go);
+    GRT_REQUIRE_PTR(go->impl);
+    GRT_TRY(grt_dev_event_wait(go->device, impl_of(go)->colstate_uploaded));
+    return GRTCODE_SUCCESS;
+}
+
 EXTERN int grt_optical_depth_batch(GasOptics_t *gas_optics, GrtColumns_t const *columns, fp_t *tau_dev)
 {
     GRT_REQUIRE_PTR(gas_optics);
@@ -1215,6 +1226,9 @@ EXTERN int grt_optical_depth_batch(GasOptics_t *gas_optics, GrtColumns_t const *
     GRT_REQUIRE_PTR(columns->temperature);
     GRT_REQUIRE_RANGE(columns->ncol, 1, 65535);
     GRT_TRY(grt_gas_optics_prepare(gas_optics, columns->ncol));
+    /* the pinned column-state buffer is refilled every call: the previous batch's copy of it must have
+       left (its kernels may still be running) */
+    GRT_TRY(grt_gas_optics_wait_staging(gas_optics));
     GRT_TRY(batch_column_states(gas_optics, columns));
     uint64_t const per_col = (uint64_t)gas_optics->num_layers*gas_optics->grid.n;
     GRT_TRY(launch_columns(gas_optics, columns->ncol, tau_dev, per_col));

@@ -50,6 +50,9 @@ int grt_dev_upload(Device_t device, void *dst, void const *src, size_t bytes, vo
 int grt_dev_download(Device_t device, void *dst, void const *src, size_t bytes, void *stream);
 int grt_dev_copy(Device_t device, void *dst, void const *src, size_t bytes, void *stream);
 int grt_dev_sync(Device_t device, void *stream);
+int grt_dev_event_record(Device_t device, void **ev, void *stream);
+int grt_dev_event_wait(Device_t device, void *ev);
+int grt_dev_event_destroy(Device_t device, void **ev);
 int grt_dev_check(int hip_error, char const *what);     /* maps any HIP error to GRTCODE_GPU_ERR */
 void *grt_dev_stream(Device_t device);                  /* library stream of a device (created lazily) */
 int grt_profile_begin(void *stream, int tag);           /* -1 when profiling is off */
@@ -87,12 +90,14 @@ typedef struct GrtGasOpticsImpl
     GrtColumnLayout layout;
     int layout_cols;               /* capacity (columns) of the buffers below */
     double *colstate_h;            /* pinned host */
+    void *colstate_uploaded;       /* event: colstate_h has been copied out and may be refilled */
     double *colstate_d;
     int tile, nslice, fast;        /* launch tuning (grt_gas_optics_tune) */
     int profile_tag;               /* 0: by grid size; the pipeline sets 1 (longwave) / 2 (shortwave) */
 } GrtGasOpticsImpl;
 
 int grt_gas_optics_prepare(GasOptics_t *go, int ncol);   /* build store/tables/layout if stale */
+int grt_gas_optics_wait_staging(GasOptics_t *go);        /* until the last batch's column state has been uploaded */
 /* Host prologue for one column (curtis_godson.c + partition sums), written at dst. */
 int grt_column_state(GasOptics_t const *go, fp_t const *p_mb, fp_t const *t,
                      fp_t const *x_mol /* [NUM_MOLS][V] by id-1 */, fp_t const *x_cfc /* [NUM_CFCS][V] */,

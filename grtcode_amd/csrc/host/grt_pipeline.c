@@ -35,6 +35,7 @@ struct GrtPipeline
     GrtBand band[2];       /* 0: longwave, 1: shortwave */
     /* per-batch small inputs: pinned host staging + device copies */
     double *small_h, *small_d;
+    void *small_uploaded;  /* event: small_h has been copied out and may be refilled */
     size_t off_n, off_tl, off_tv, off_ts, off_mu, off_tsi, small_doubles;
     double *emis_d, *albedo_d, *solar_d;
 };
@@ -158,6 +159,7 @@ EXTERN int grt_pipeline_destroy(GrtPipeline_t **pipeline)
     }
     GRT_TRY(grt_dev_free(p->device, p->small_d));
     GRT_TRY(grt_host_free_pinned(p->small_h));
+    GRT_TRY(grt_dev_event_destroy(p->device, &p->small_uploaded));
     GRT_TRY(grt_dev_free(p->device, p->emis_d));
     GRT_TRY(grt_dev_free(p->device, p->albedo_d));
     GRT_TRY(grt_dev_free(p->device, p->solar_d));
@@ -204,9 +206,9 @@ EXTERN int grt_pipeline_run(GrtPipeline_t *p, GrtColumns_t const *cols, fp_t *fl
     GRT_REQUIRE_PTR(cols->temperature);
     int const V = p->num_levels, L = V - 1, C = cols->ncol;
     void *s = grt_dev_stream(p->device);
-    /* the pinned staging buffers are reused every call: wait for the previous batch's
-       uploads (and, with them, its kernels) before overwriting them */
-    GRT_TRY(grt_dev_sync(p->device, s));
+    /* the pinned staging buffer is reused every call: wait until the previous batch's copy of it has
+       left -- not for its kernels, so that this batch is prepared on the host while that one runs */
+    GRT_TRY(grt_dev_event_wait(p->device, p->small_uploaded));
 
     /* small per-column inputs: air column amounts for Rayleigh (rayleigh.c:104-128 via
        curtis_godson.c:25-40), temperatures, sun geometry */
@@ -254,6 +256,7 @@ EXTERN int grt_pipeline_run(GrtPipeline_t *p, GrtColumns_t const *cols, fp_t *fl
         memcpy(p->small_h + p->off_tsi, cols->total_solar_irradiance, sizeof(double)*(size_t)C);
     }
     GRT_TRY(grt_dev_upload(p->device, p->small_d, p->small_h, sizeof(double)*p->small_doubles, s));
+    GRT_TRY(grt_dev_event_record(p->device, &p->small_uploaded, s));
 
     for (int bi = 0; bi < 2; ++bi)
     {
