@@ -204,7 +204,7 @@ def main():
             except Exception:
                 traffic = None
         total_cols = world * args.cols * args.steps
-        line_kernel = "gas_optics_mp_kernel" if args.fast == 1 else "gas_optics_kernel"
+        line_kernel = "gas_optics_mp_kernel" if args.fast in (1, 3) else "gas_optics_kernel"
         line = {
             "metric": "columns/sec (60-layer, 1 cm-1 LBL, LW+SW)", "value": total_cols / elapsed, "unit": "columns/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -214,7 +214,8 @@ def main():
                                    "integrated fluxes",
                        "columns_per_gpu_per_step": args.cols, "fast": args.fast,
                        "arithmetic": {0: "reference operation order", 1: "fused form, far wings by cell moments",
-                                      2: "fused form, every window point in the ring"}.get(args.fast, str(args.fast)),
+                                      2: "fused form, every window point in the ring",
+                                      3: "fused form, far wings by cell moments, two passes"}.get(args.fast, str(args.fast)),
                        "parallelism": f"columns sharded over {world} GPU(s), RCCL gather of 12 fluxes/column"},
             "roofline": {"kernel": f"{line_kernel} (line-by-line tau), SW-band launch", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

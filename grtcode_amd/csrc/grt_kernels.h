@@ -73,7 +73,9 @@ typedef struct GrtGasOpticsArgs
     int tile;                 /* wavenumbers per workgroup (multiple of 64) */
     int nslice;               /* line slices per tile (>=1); >1 uses global atomics */
     int fast;                 /* 0: reference operation order; 1: fused form, far wings by cell moments
-                                 where the window is wide enough; 2: fused form, every point in the ring */
+                                 where the window is wide enough; 2: fused form, every point in the ring;
+                                 3: as 1 in two passes (cell moments through gmom) */
+    float *gmom;              /* two-pass form only: [ncol][L][8][nw] cell moments */
 } GrtGasOpticsArgs;
 
 int grt_launch_gas_optics(void *stream, GrtGasOpticsArgs const *a);

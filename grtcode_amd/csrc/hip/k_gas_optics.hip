@@ -439,7 +439,7 @@ extern "C" int grt_launch_gas_optics(void *stream, GrtGasOpticsArgs const *a)
     unsigned const stride = golden_stride(ngroups);
     size_t const lds = gas_optics_lds_bytes(a->tile);
     hipStream_t const s = (hipStream_t)stream;
-    if (a->fast == 1)
+    if (a->fast == 1 || a->fast == 3)
     {
         return grt_launch_gas_optics_mp(stream, a);
     }

@@ -128,6 +128,37 @@ struct MpQueue
     unsigned short idx[kClasses][kWaves][kMpQueue];   // accumulator index f - F0
 };
 
+// Near-field radius R of a (cell tile, layer), the same for every line of the tile.
+// moment series: every line has |z| <= sqrt(1/4 + eta_max^2), eta_max from the largest half-width any
+// line of the store can have in this layer (kernels.c:105-106: per molecule, the largest air- and
+// self-broadening coefficients times this layer's partial pressures); ratio |z|/(R+1) <= 0.128 keeps the
+// 8-term remainder below 1e-7 of the far-wing value.  If that asks for more than the window, the whole
+// window is "near" (R = fsteps) and no moments are formed.  ms_l: this layer's [slot][4] block in LDS.
+__device__ int near_radius(GrtGasOpticsArgs const &a, double const *lay, double const *ms_l, long long F1l, int fsteps,
+                           bool *use_moments)
+{
+    double gmax = 0., dop = 0.;         // max over slots of yair_max (P - Ps) + yself_max Ps; of the Doppler factor
+    for (int sl = 0; sl < a.lay.num_slots; ++sl)
+    {
+        gmax = fmax(gmax, (double)a.lines.yair_max[sl]*fabs(ms_l[sl*4 + 1]) + (double)a.lines.yself_max[sl]*fabs(ms_l[sl*4]));
+        dop = fmax(dop, ms_l[sl*4 + 3]);
+    }
+    double const eta = gmax*exp(a.lines.nmax*fabs(lay[3]))/a.wres;
+    int const r_mp = (int)ceil(7.8*sqrt(0.25 + eta*eta)) - 1;
+    int const r_lo = r_mp < 3 ? 3 : r_mp;
+    // Humlicek region 1 reaches XLIM0 <= 123.4 Doppler units from the centre: evaluate it inside the ring
+    // where that is within kRcap grid steps for every line of the tile (a performance choice, not a bound
+    // the results depend on: region-1 points beyond R are picked up line by line in pre-pass 2; shrinking R
+    // below this estimate was measured slower)
+    double const w_hi = a.w0 + (double)(F1l + fsteps)*a.wres;
+    double const alpha_max = 0.83255461115*w_hi*dop;
+    double const reach = 123.4*alpha_max/(0.832554611*a.wres) + 0.51;
+    int const r_reg1 = reach < (double)kRcap ? (int)reach : kRcap;
+    int R = r_lo > r_reg1 ? r_lo : r_reg1;
+    *use_moments = (R + 4 <= fsteps);
+    return *use_moments ? R : fsteps;
+}
+
 template <int CLASS>
 __device__ __forceinline__ void drain_class(double *acc, MpQueue const *q, int wave, int first, int count, int lane)
 {
@@ -140,13 +171,22 @@ __device__ __forceinline__ void drain_class(double *acc, MpQueue const *q, int w
     }
 }
 
+// TWO_PASS = false: a workgroup owns a tile of grid POINTS: it prepares every line whose window reaches the
+// tile (its own cells and a halo of fsteps cells on either side), keeps the moments of all those cells in
+// LDS, gathers the far field itself and writes tau once.
+// TWO_PASS = true: a workgroup owns a tile of CELLS: it prepares only the lines whose centre index falls in
+// the tile -- every line exactly once per (layer, column) -- adds their near fields to tau with atomics
+// (the accumulator spans the tile and fsteps points either side) and leaves the cells' moments in global
+// memory; gas_optics_far_kernel then gathers the far field and folds in the continua.  This is what fine
+// grids want: a tile is 512 points, so at 0.1 cm-1 the one-pass form prepares every line twice.
+template <bool TWO_PASS>
 __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs a, long long fsteps_ll, unsigned ngroups,
-                                                                unsigned perm_stride, int ncell)
+                                                                unsigned perm_stride, int ncell, int nacc)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int const fsteps = (int)fsteps_ll;
-    double *acc = reinterpret_cast<double *>(smem);                               // [tile]
-    MpQueue *nq = reinterpret_cast<MpQueue *>(smem + sizeof(double)*a.tile);
+    double *acc = reinterpret_cast<double *>(smem);                               // [nacc]
+    MpQueue *nq = reinterpret_cast<MpQueue *>(smem + sizeof(double)*nacc);
     long long *range = reinterpret_cast<long long *>(nq + 1);                     // [2]
     double *ms_l = reinterpret_cast<double *>(range + 2);                         // [num_slots][4]
     double *q_l = ms_l + 4*a.lay.num_slots;                                       // [num_slots][GRT_MAX_ISO]
@@ -162,12 +202,13 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
     long long const F0l = (long long)tile_idx*a.tile;
     long long const F1l = (F0l + a.tile < nw) ? F0l + a.tile : nw;                // [F0,F1)
     int const F0 = (int)F0l, F1 = (int)F1l;
-    int const cell0 = F0 - fsteps;                                                // cell of mom[.][0]
+    int const cell0 = TWO_PASS ? F0 : F0 - fsteps;                                // cell of mom[.][0]
+    int const A0 = TWO_PASS ? F0 - fsteps : F0;                                   // grid index of acc[0]
 
     double const *cs = a.colstate + (uint64_t)col*a.lay.stride;
     double const *lay = cs + a.lay.off_lay + (uint64_t)layer*4;
 
-    for (int i = tid; i < a.tile; i += kBlock)
+    for (int i = tid; i < nacc; i += kBlock)
     {
         acc[i] = 0.0;
     }
@@ -175,14 +216,14 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
     {
         mom[i] = 0.f;
     }
-    for (int i = tid; i <= fsteps; i += kBlock)
+    for (int i = tid; i <= fsteps && !TWO_PASS; i += kBlock)
     {
         invr[i] = i > 0 ? 1.0f/(float)i : 0.f;
     }
     stage_column_state(a, cs, layer, ms_l, q_l, tid);
     if (tid == 0)
     {
-        candidate_range(a, lay, F0l, F1l, fsteps_ll, slice, range);
+        candidate_range(a, lay, F0l, F1l, TWO_PASS ? 0 : fsteps_ll, slice, range);
     }
     __syncthreads();
     uint64_t const jbeg = (uint64_t)range[0];
@@ -193,43 +234,8 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
     float const inv_wres_f = (float)inv_wres;
     int const nw_i = (int)nw;
 
-    // ---- near-field radius R of this (tile, layer): workgroup-uniform ----
-    // moment series: every line has |z| <= sqrt(1/4 + eta_max^2), eta_max from the largest half-width
-    // any line of the store can have in this layer (kernels.c:105-106: per molecule, the largest
-    // air- and self-broadening coefficients times this layer's partial pressures); ratio |z|/(R+1) <= 0.128 keeps
-    // the 8-term remainder below 1e-7 of the far-wing value.  If that asks for more than the window,
-    // the whole window is "near" and no moments are formed.
-    int R;
     bool use_moments;
-    {
-        double gmax = 0.;       // max over slots of yair_max (P - Ps) + yself_max Ps
-        for (int sl = 0; sl < a.lay.num_slots; ++sl)
-        {
-            gmax = fmax(gmax, (double)a.lines.yair_max[sl]*fabs(ms_l[sl*4 + 1]) + (double)a.lines.yself_max[sl]*fabs(ms_l[sl*4]));
-        }
-        double const eta = gmax*exp(a.lines.nmax*fabs(lay[3]))*inv_wres;
-        int const r_mp = (int)ceil(7.8*sqrt(0.25 + eta*eta)) - 1;
-        int const r_lo = r_mp < 3 ? 3 : r_mp;
-        // Humlicek region 1 reaches XLIM0 <= 123.4 Doppler units from the centre: evaluate it inside
-        // the ring where that is within kRcap grid steps for every line of the tile
-        double dop = 0.;
-        for (int sl = 0; sl < a.lay.num_slots; ++sl)
-        {
-            dop = fmax(dop, ms_l[sl*4 + 3]);
-        }
-        double const w_hi = a.w0 + (double)(F1l + fsteps)*a.wres;
-        double const alpha_max = 0.83255461115*w_hi*dop;
-        // (a performance choice, not a bound the results depend on: region-1 points beyond R are picked up
-        // line by line in pre-pass 2; shrinking R below this estimate was measured slower)
-        double const reach = 123.4*alpha_max/(0.832554611*a.wres) + 0.51;
-        int const r_reg1 = reach < (double)kRcap ? (int)reach : kRcap;
-        R = r_lo > r_reg1 ? r_lo : r_reg1;
-        use_moments = (R + 4 <= fsteps);
-        if (!use_moments)
-        {
-            R = fsteps;
-        }
-    }
+    int const R = near_radius(a, lay, ms_l, F1l, fsteps, &use_moments);
 
     int qcount[kClasses] = {0, 0, 0};    // wave-uniform
     auto drain = [&](int cls, int first, int count)
@@ -268,13 +274,14 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
         int const c = valid ? (int)fc : 0;
         int const s = c - fsteps < 0 ? 0 : c - fsteps;                                 // kernels.c:435
         int const e_i = c + fsteps >= nw_i ? nw_i - 1 : c + fsteps;                    // kernels.c:436-437
-        valid = valid & (s < F1) & (e_i >= F0);
+        valid = TWO_PASS ? valid & (c >= F0) & (c < F1) : valid & (s < F1) & (e_i >= F0);
         if (__ballot(valid) == 0ull)
         {
             continue;
         }
-        int const lo = valid ? (s > F0 ? s : F0) : 1;
-        int const hi = valid ? (e_i < F1 - 1 ? e_i : F1 - 1) : 0;
+        // the line's window, clipped to what the accumulator spans (in the two-pass form that is the whole window)
+        int const lo = valid ? (TWO_PASS || s > F0 ? s : F0) : 1;
+        int const hi = valid ? (TWO_PASS || e_i < F1 - 1 ? e_i : F1 - 1) : 0;
         double const c2 = -1.4387686f;                                                 // kernels.c:75
         double const invT = lay[2];
         // stimulated emission 1 - exp(c2 v0/T): below exp(-20) = 2e-9 the factor is 1 to fp32 and beyond
@@ -446,7 +453,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
 #else
                             nq->far[q][wave][pos] = cl*__builtin_amdgcn_rcpf(fmaf(xi, xi, yq));
 #endif
-                            nq->idx[q][wave][pos] = (unsigned short)(f - F0);
+                            nq->idx[q][wave][pos] = (unsigned short)(f - A0);
                         }
                         qcount[q] += npush;
                         if (qcount[q] >= 64)
@@ -482,7 +489,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
                     {
                         float const den = fmaf(xq, d2r + xq, d0r)*fmaf(xi, xi, yq);
                         float const corr = cl*fmaf(1.5f, xq, -0.5f*a0)*__builtin_amdgcn_rcpf(den);
-                        GRT_ACC_ADD(&acc[f - F0], amp*(double)corr);
+                        GRT_ACC_ADD(&acc[f - A0], amp*(double)corr);
                     }
                 }
             }
@@ -529,7 +536,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
             int const f = fbp + (int)slotf;
             if (f <= fe)
             {
-                GRT_ACC_ADD(&acc[f - F0], token);
+                GRT_ACC_ADD(&acc[f - A0], token);
             }
         };
 #if defined(GRT_MP_NORING)
@@ -555,6 +562,34 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
     }
     __syncthreads();
 
+    if (TWO_PASS)
+    {
+        // near fields -> tau (zeroed by the launcher; neighbouring tiles add to the same points), the tile's
+        // cell moments -> global memory for the gather kernel
+        double *out = a.tau + (uint64_t)col*a.tau_col_stride + (uint64_t)layer*a.nw;
+        for (int i = tid; i < nacc; i += kBlock)
+        {
+            long long const f = (long long)A0 + i;
+            if (f >= 0 && f < nw && acc[i] != 0.)
+            {
+                unsafeAtomicAdd(&out[f], acc[i]);
+            }
+        }
+        float *gm = a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*kMom*a.nw;
+        for (int i = tid; i < kMom*(F1 - F0); i += kBlock)
+        {
+            int const k = i/(F1 - F0), cidx = i - k*(F1 - F0);
+            if (a.nslice == 1)
+            {
+                gm[(uint64_t)k*a.nw + F0 + cidx] = mom[k*ncell + cidx];
+            }
+            else
+            {
+                unsafeAtomicAdd(&gm[(uint64_t)k*a.nw + F0 + cidx], mom[k*ncell + cidx]);
+            }
+        }
+        return;
+    }
     // ---- far field: every grid point of the tile gathers the moment series of the cells at
     // distance R < |f - c| <= fsteps (the cells' windows, kernels.c:435-437) ----
 #if defined(GRT_MP_NOFAR)
@@ -587,21 +622,129 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
     write_tile(a, acc, cs, col, layer, slice, F0l, F1l, tid);
 }
 
-size_t mp_lds_bytes(int tile, int ncell, int fsteps, int num_slots)
+// Second pass of the two-pass form: workgroup = (tile of grid points, layer, column).  Stages the moments
+// of the cells within fsteps of the tile, gathers for every point the series of the cells at distance
+// R(cell's tile) < |f - c| <= fsteps, adds the near fields the first pass left in tau and the continua, and
+// writes tau.  cell_shift: log2 of the first pass's cell-tile size.
+__global__ __launch_bounds__(kBlock) void gas_optics_far_kernel(GrtGasOpticsArgs a, long long fsteps_ll, int cell_shift, int ncell)
 {
-    return sizeof(double)*tile + sizeof(MpQueue) + 2*sizeof(long long) + sizeof(double)*num_slots*(4 + GRT_MAX_ISO)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int const fsteps = (int)fsteps_ll;
+    double *acc = reinterpret_cast<double *>(smem);                               // [tile]
+    double *ms_l = acc + a.tile;                                                  // [num_slots][4]
+    double *q_l = ms_l + 4*a.lay.num_slots;                                       // [num_slots][GRT_MAX_ISO] (unused here)
+    float *mom = reinterpret_cast<float *>(q_l + GRT_MAX_ISO*a.lay.num_slots);    // [kMom][ncell]
+    float *invr = mom + (size_t)kMom*ncell;                                       // [fsteps + 1]
+    int *rtab = reinterpret_cast<int *>(invr + fsteps + 1);                       // [cell tiles touched]
+    int const tid = threadIdx.x;
+    int const layer = blockIdx.y, col = blockIdx.z;
+    long long const nw = (long long)a.nw;
+    long long const F0l = (long long)blockIdx.x*a.tile;
+    long long const F1l = (F0l + a.tile < nw) ? F0l + a.tile : nw;
+    int const F0 = (int)F0l, F1 = (int)F1l;
+    double const *cs = a.colstate + (uint64_t)col*a.lay.stride;
+    double const *lay = cs + a.lay.off_lay + (uint64_t)layer*4;
+    double *out = a.tau + (uint64_t)col*a.tau_col_stride + (uint64_t)layer*a.nw;
+    stage_column_state(a, cs, layer, ms_l, q_l, tid);
+    for (int i = tid; i <= fsteps; i += kBlock)
+    {
+        invr[i] = i > 0 ? 1.0f/(float)i : 0.f;
+    }
+    int const cell0 = F0 - fsteps;
+    float const *gm = a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*kMom*a.nw;
+    for (int i = tid; i < kMom*ncell; i += kBlock)
+    {
+        int const k = i/ncell, ci = i - k*ncell;
+        long long const c = (long long)cell0 + ci;
+        mom[i] = (c >= 0 && c < nw) ? gm[(uint64_t)k*a.nw + c] : 0.f;
+    }
+    for (int i = tid; i < F1 - F0; i += kBlock)
+    {
+        acc[i] = out[F0 + i];
+    }
+    __syncthreads();
+    int const t0 = (cell0 > 0 ? cell0 : 0) >> cell_shift;
+    int const t1 = (int)((F1l - 1 + fsteps < nw - 1 ? F1l - 1 + fsteps : nw - 1) >> cell_shift);
+    if (tid <= t1 - t0)
+    {
+        long long const c1 = ((long long)(t0 + tid + 1) << cell_shift);
+        bool um;
+        rtab[tid] = near_radius(a, lay, ms_l, c1 < nw ? c1 : nw, fsteps, &um);
+    }
+    __syncthreads();
+    int rmin = fsteps, rmax = 0;
+    for (int t = 0; t <= t1 - t0; ++t)
+    {
+        rmin = rtab[t] < rmin ? rtab[t] : rmin;
+        rmax = rtab[t] > rmax ? rtab[t] : rmax;
+    }
+    for (int i = tid; i < F1 - F0; i += kBlock)
+    {
+        int const f = F0 + i;
+        double sum = 0.;
+        for (int r = rmin + 1; r <= fsteps; ++r)
+        {
+            float const u = invr[r];
+            float const *ma = mom + (i + fsteps - r);           // cell f - r: offset +r
+            float const *mb = mom + (i + fsteps + r);           // cell f + r: offset -r
+            float pa = ma[(kMom - 1)*ncell], pb = mb[(kMom - 1)*ncell];
+#pragma unroll
+            for (int k = kMom - 2; k >= 0; --k)
+            {
+                pa = fmaf(pa, u, ma[k*ncell]);
+                pb = fmaf(pb, -u, mb[k*ncell]);
+            }
+            if (r <= rmax)
+            {
+                // inside some tile's near field: each cell decides with its own tile's radius
+                int const ca = f - r, cb = f + r;
+                if (ca < 0 || r <= rtab[(ca >> cell_shift) - t0]) pa = 0.f;
+                if (cb >= nw || r <= rtab[(cb >> cell_shift) - t0]) pb = 0.f;
+            }
+            sum += (double)((pa + pb)*(u*u));
+        }
+        acc[i] += sum;
+    }
+    __syncthreads();
+    write_tile(a, acc, cs, col, layer, 0, F0l, F1l, tid);
+}
+
+size_t mp_lds_bytes(int nacc, int ncell, int fsteps, int num_slots)
+{
+    return sizeof(double)*nacc + sizeof(MpQueue) + 2*sizeof(long long) + sizeof(double)*num_slots*(4 + GRT_MAX_ISO)
            + sizeof(float)*((size_t)kMom*ncell + fsteps + 1);
+}
+
+size_t far_lds_bytes(int tile, int ncell, int fsteps, int num_slots, int cell_shift)
+{
+    return sizeof(double)*tile + sizeof(double)*num_slots*(4 + GRT_MAX_ISO) + sizeof(float)*((size_t)kMom*ncell + fsteps + 1)
+           + sizeof(int)*((size_t)(ncell >> cell_shift) + 3);
+}
+
+int log2_exact(int v)
+{
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return (1 << s) == v ? s : -1;
 }
 
 } // namespace
 
 // 0 when the moment kernel does not apply to this grid (narrow windows, or a window that does not fit LDS).
+// a->fast == 3 asks about the two-pass form (cell tiles must be a power of two).
 extern "C" int grt_gas_optics_mp_applicable(GrtGasOpticsArgs const *a)
 {
     long long const fsteps = (long long)ceil((double)25.f/a->wres);   // kernels.c:417
     if (fsteps < 16 || fsteps > 4096)
     {
         return 0;
+    }
+    if (a->fast == 3)
+    {
+        int const shift = log2_exact(a->tile);
+        return shift >= 6 && a->gmom != NULL
+               && mp_lds_bytes(a->tile + 2*(int)fsteps, a->tile, 0, a->lay.num_slots) <= 64*1024
+               && far_lds_bytes(a->tile, a->tile + 2*(int)fsteps, (int)fsteps, a->lay.num_slots, shift) <= 64*1024;
     }
     return mp_lds_bytes(a->tile, a->tile + 2*(int)fsteps, (int)fsteps, a->lay.num_slots) <= 64*1024;
 }
@@ -624,9 +767,36 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
     {
         return (int)hipErrorInvalidValue;
     }
+    hipStream_t const s = (hipStream_t)stream;
+    if (a->fast == 3)
+    {
+        // two passes: near fields and cell moments (every line prepared once), then the far-field gather
+        int const nacc = a->tile + 2*(int)fsteps, shift = log2_exact(a->tile);
+        if (a->ncol > 65535 || a->lay.num_layers > 65535)
+        {
+            return (int)hipErrorInvalidValue;
+        }
+        hipError_t e = hipMemsetAsync(a->tau, 0, sizeof(double)*a->tau_col_stride*(size_t)a->ncol, s);
+        if (e == hipSuccess && a->nslice > 1)
+        {
+            e = hipMemsetAsync(a->gmom, 0, sizeof(float)*(size_t)kMom*a->nw*a->lay.num_layers*a->ncol, s);
+        }
+        if (e != hipSuccess)
+        {
+            return (int)e;
+        }
+        hipLaunchKernelGGL(gas_optics_mp_kernel<true>, dim3((unsigned)blocks), dim3(kBlock),
+                           mp_lds_bytes(nacc, a->tile, 0, a->lay.num_slots), s, *a, fsteps, (unsigned)ngroups,
+                           golden_stride(ngroups), a->tile, nacc);
+        GrtGasOpticsArgs b = *a;
+        b.nslice = 1;
+        hipLaunchKernelGGL(gas_optics_far_kernel, dim3((unsigned)tiles, a->lay.num_layers, a->ncol), dim3(kBlock),
+                           far_lds_bytes(a->tile, nacc, (int)fsteps, a->lay.num_slots, shift), s, b, fsteps, shift, nacc);
+        return (int)hipGetLastError();
+    }
     int const ncell = a->tile + 2*(int)fsteps;
     size_t const lds = mp_lds_bytes(a->tile, ncell, (int)fsteps, a->lay.num_slots);
-    hipLaunchKernelGGL(gas_optics_mp_kernel, dim3((unsigned)blocks), dim3(kBlock), lds, (hipStream_t)stream, *a, fsteps,
-                       (unsigned)ngroups, golden_stride(ngroups), ncell);
+    hipLaunchKernelGGL(gas_optics_mp_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), lds, s, *a, fsteps,
+                       (unsigned)ngroups, golden_stride(ngroups), ncell, a->tile);
     return (int)hipGetLastError();
 }

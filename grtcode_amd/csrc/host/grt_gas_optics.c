@@ -328,7 +328,7 @@ EXTERN int create_gas_optics(GasOptics_t * const gas_optics, int const num_level
         /* arithmetic form of the line kernel for callers that cannot call grt_gas_optics_tune (an unchanged
            reference driver): GRT_GAS_OPTICS_FAST=0|1|2 in the environment; default 0 (reference order) */
         char const *env = getenv("GRT_GAS_OPTICS_FAST");
-        if (env != NULL && env[0] >= '0' && env[0] <= '2' && env[1] == '\0')
+        if (env != NULL && env[0] >= '0' && env[0] <= '3' && env[1] == '\0')
         {
             im->fast = env[0] - '0';
         }
@@ -373,6 +373,7 @@ EXTERN int destroy_gas_optics(GasOptics_t * const gas_optics)
         }
         GRT_TRY(free_store(gas_optics));
         GRT_TRY(grt_dev_free(gas_optics->device, im->bins_block));
+        GRT_TRY(grt_dev_free(gas_optics->device, im->gmom));
         GRT_TRY(grt_dev_free(gas_optics->device, im->h2o_tables));
         GRT_TRY(grt_dev_free(gas_optics->device, im->lin_tables));
         GRT_TRY(grt_dev_free(gas_optics->device, im->colstate_d));
@@ -689,7 +690,7 @@ EXTERN int grt_gas_optics_tune(GasOptics_t *gas_optics, int tile, int nslice, in
         GRT_REQUIRE_RANGE(nslice, 1, 64);
         im->nslice = nslice;
     }
-    GRT_REQUIRE_RANGE(fast, 0, 2);
+    GRT_REQUIRE_RANGE(fast, 0, 3);
     im->fast = fast;
     return GRTCODE_SUCCESS;
 }
@@ -1046,16 +1047,34 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
     a->tau = tau;
     a->tau_col_stride = tau_col_stride;
     a->fast = im->fast;
-    if (im->fast == 1)
+    if (im->fast == 1 || im->fast == 3)
     {
         /* fused form: far wings by cell moments where the grid's windows are wide enough for that */
         auto_tune(go, ncol, 1, &a->tile, &a->nslice);
+        if (im->fast == 3)
+        {
+            /* two passes: the cells' moments travel through global memory */
+            size_t const need = sizeof(float)*8*(size_t)a->nw*(size_t)go->num_layers*(size_t)ncol;
+            if (need > im->gmom_bytes)
+            {
+                GRT_TRY(grt_dev_free(go->device, im->gmom));
+                im->gmom = NULL;
+                im->gmom_bytes = 0;
+                GRT_TRY(grt_dev_alloc(go->device, (void **)&im->gmom, need));
+                im->gmom_bytes = need;
+            }
+            a->gmom = im->gmom;
+        }
         if (!grt_gas_optics_mp_applicable(a))
         {
-            a->fast = 2;
+            a->fast = im->fast == 3 ? 1 : 2;
+            if (a->fast == 1 && !grt_gas_optics_mp_applicable(a))
+            {
+                a->fast = 2;
+            }
         }
     }
-    if (a->fast != 1)
+    if (a->fast != 1 && a->fast != 3)
     {
         auto_tune(go, ncol, 0, &a->tile, &a->nslice);
     }

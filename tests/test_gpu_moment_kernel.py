@@ -34,11 +34,16 @@ def check(band, device, oracle, lib, col, **kw):
     want = band.oracle_tau(oracle, oracle, lib, col)
     mp = run(band, device, col, 1, **kw)
     ring = run(band, device, col, 2, **kw)
+    two = run(band, device, col, 3, **kw)               # two-pass form: cell moments through global memory
     e_mp, e_ring, e_between = tau_close(mp, want), tau_close(ring, want), tau_close(mp, ring)
-    print(f"moment kernel vs oracle {e_mp:.2e}; ring kernel vs oracle {e_ring:.2e}; moment vs ring {e_between:.2e}")
+    e_two, e_forms = tau_close(two, want), tau_close(two, mp)
+    print(f"moment kernel vs oracle {e_mp:.2e}; ring kernel vs oracle {e_ring:.2e}; moment vs ring {e_between:.2e}; "
+          f"two-pass vs oracle {e_two:.2e}, vs one-pass {e_forms:.2e}")
     assert e_mp < FAST_TOL
     assert e_ring < FAST_TOL
+    assert e_two < FAST_TOL
     assert e_between < 5e-7
+    assert e_forms < 1e-7                               # same arithmetic, different order of additions
     return mp, want
 
 
