@@ -1012,9 +1012,18 @@ static void auto_tune(GasOptics_t const *go, int ncol, int moments, int *tile, i
     int t = im->tile;
     if (t == 0)
     {
-        /* the moment kernel keeps tile + 2*fsteps cells of 8 moments in LDS next to the tile */
-        int const want = moments ? 512 : 1024;
+        /* the one-pass moment kernel keeps tile + 2*fsteps cells of 8 moments in LDS next to the tile; the
+           two-pass one only the tile's own cells, and its tiles are powers of two (256 measured best at
+           1 cm-1: four workgroups per CU) */
+        int const want = moments == 2 ? 256 : (moments ? 512 : 1024);
         t = nw >= (uint64_t)want ? want : (int)(((nw + 63)/64)*64);
+        if (moments == 2)
+        {
+            while (t & (t - 1))
+            {
+                t += 64;                /* next power of two */
+            }
+        }
     }
     int ns = im->nslice;
     if (ns == 0)
@@ -1050,7 +1059,7 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
     if (im->fast == 1 || im->fast == 3)
     {
         /* fused form: far wings by cell moments where the grid's windows are wide enough for that */
-        auto_tune(go, ncol, 1, &a->tile, &a->nslice);
+        auto_tune(go, ncol, im->fast == 3 ? 2 : 1, &a->tile, &a->nslice);
         if (im->fast == 3)
         {
             /* two passes: the cells' moments travel through global memory */
@@ -1068,9 +1077,13 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
         if (!grt_gas_optics_mp_applicable(a))
         {
             a->fast = im->fast == 3 ? 1 : 2;
-            if (a->fast == 1 && !grt_gas_optics_mp_applicable(a))
+            if (a->fast == 1)
             {
-                a->fast = 2;
+                auto_tune(go, ncol, 1, &a->tile, &a->nslice);
+                if (!grt_gas_optics_mp_applicable(a))
+                {
+                    a->fast = 2;
+                }
             }
         }
     }
