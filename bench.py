@@ -183,7 +183,7 @@ def main():
     if rank == 0:
         fluxes = out.cpu().numpy()
         assert np.all(np.isfinite(fluxes)), "non-finite integrated fluxes"
-        ms = {tag: api.profile_read(tag) for tag in (1, 2, 3, 4, 5)}
+        ms = {tag: api.profile_read(tag) for tag in (1, 2, 3, 4, 5, 6, 7)}
         L, V = W.NUM_LEVELS - 1, W.NUM_LEVELS
         n_lw, n_sw = wl.grid_lw.n, wl.grid_sw.n
         S = wl.total_lines
@@ -231,6 +231,7 @@ def main():
                               "voigt_points_per_launch": points(S["sw"]),
                               "gpoints_per_s": points(S["sw"]) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0},
             "kernel_ms_per_step": {"gas_optics_lw": ms[1][0] / args.steps, "gas_optics_sw": ms[2][0] / args.steps,
+                                   "far_field_lw": ms[6][0] / args.steps, "far_field_sw": ms[7][0] / args.steps,
                                    "lw_solver": ms[3][0] / args.steps, "sw_solver": ms[4][0] / args.steps,
                                    "clear_sky_optics": ms[5][0] / args.steps},
             "sample_fluxes_col0": {"rlut": fluxes[0, 0], "rlus": fluxes[0, 1], "rlds": fluxes[0, 4],

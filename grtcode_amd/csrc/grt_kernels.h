@@ -76,9 +76,13 @@ typedef struct GrtGasOpticsArgs
                                  where the window is wide enough; 2: fused form, every point in the ring;
                                  3: as 1 in two passes (cell moments through gmom) */
     float *gmom;              /* two-pass form only: [ncol][L][8][nw] cell moments */
+    int profile_tag;          /* != 0: time the line kernel under this tag (the two-pass gather under tag + 5) */
 } GrtGasOpticsArgs;
 
 int grt_launch_gas_optics(void *stream, GrtGasOpticsArgs const *a);
+/* HIP-event brackets on the library stream (grt_device.c; grt_ext.h: grt_profile_*) */
+int grt_profile_begin(void *stream, int tag);
+void grt_profile_end(void *stream, int slot);
 /* fast == 1 only: the cell-moment kernel (k_gas_optics_mp.hip) and whether it applies to a grid */
 int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a);
 int grt_gas_optics_mp_applicable(GrtGasOpticsArgs const *a);

@@ -785,13 +785,17 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
         {
             return (int)e;
         }
+        int slot = a->profile_tag ? grt_profile_begin(stream, a->profile_tag) : -1;
         hipLaunchKernelGGL(gas_optics_mp_kernel<true>, dim3((unsigned)blocks), dim3(kBlock),
                            mp_lds_bytes(nacc, a->tile, 0, a->lay.num_slots), s, *a, fsteps, (unsigned)ngroups,
                            golden_stride(ngroups), a->tile, nacc);
+        if (a->profile_tag) grt_profile_end(stream, slot);
         GrtGasOpticsArgs b = *a;
         b.nslice = 1;
+        slot = a->profile_tag ? grt_profile_begin(stream, a->profile_tag + 5) : -1;
         hipLaunchKernelGGL(gas_optics_far_kernel, dim3((unsigned)tiles, a->lay.num_layers, a->ncol), dim3(kBlock),
                            far_lds_bytes(a->tile, nacc, (int)fsteps, a->lay.num_slots, shift), s, b, fsteps, shift, nacc);
+        if (a->profile_tag) grt_profile_end(stream, slot);
         return (int)hipGetLastError();
     }
     int const ncell = a->tile + 2*(int)fsteps;

@@ -44,7 +44,9 @@ EXTERN int grt_add_molecule_lines(GasOptics_t *gas_optics, int molecule_id, uint
  * fast: 0 = reference operation order (default of a new object: tau within 1e-11 of the
  *          reference's), 1 = fused arithmetic with the far wings summed by cell moments
  *          (production form of the batched pipeline: tau within 2e-6 of each layer's maximum,
- *          fluxes ~1e-6 W m-2), 2 = fused arithmetic, every window point evaluated. */
+ *          fluxes ~1e-6 W m-2), 2 = fused arithmetic, every window point evaluated, 3 = as 1 in two
+ *          passes (every line prepared once; cell moments through a device buffer of 32 bytes per
+ *          column, layer and wavenumber) -- the form bench.py runs. */
 EXTERN int grt_gas_optics_tune(GasOptics_t *gas_optics, int tile, int nslice, int fast);
 
 /* ---- batched columns ------------------------------------------------------------- */
@@ -95,7 +97,8 @@ EXTERN int grt_pipeline_views(GrtPipeline_t *pipeline, int band, fp_t **tau_gas,
 /* ---- HIP-event timing of individual kernels on the library stream -------------------
  * Tags: 1 = line-by-line kernel on a grid of <= 10 000 points (longwave band at 1 cm-1),
  * 2 = line-by-line kernel on a larger grid (shortwave band), 3 = LW solver, 4 = SW solver,
- * 5 = clear-sky optics combine.  Read after grt_pipeline_sync(). */
+ * 5 = clear-sky optics combine, 6 / 7 = far-field gather kernel of the two-pass line kernel (longwave /
+ * shortwave band; tags 1 / 2 then cover its first pass).  Read after grt_pipeline_sync(). */
 EXTERN int grt_profile_enable(int on);
 EXTERN int grt_profile_read(int tag, double *total_ms, int *launches, int reset);
 

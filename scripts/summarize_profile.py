@@ -27,7 +27,7 @@ def newest(pattern):
 
 
 def short(name):
-    for k in ("gas_optics_mp_kernel", "gas_optics_kernel", "sw_kernel", "lw_kernel", "clear_sky_kernel", "integrate_rows_kernel",
+    for k in ("gas_optics_mp_kernel", "gas_optics_far_kernel", "gas_optics_kernel", "sw_kernel", "lw_kernel", "clear_sky_kernel", "integrate_rows_kernel",
               "fillBufferAligned", "copyBuffer"):
         if k in name:
             return k
@@ -80,7 +80,7 @@ for key in sorted(set(fetch) | set(write)):
 json.dump(summary, open(os.path.join(dst, f"{tag}_summary.json"), "w"), indent=1)
 
 # what bench.py reads back into roofline.traffic (dominant kernel = SW-band launch = largest grid)
-gas = {k: v for k, v in summary["kernels"].items() if k.startswith("gas_optics")}
+gas = {k: v for k, v in summary["kernels"].items() if k.startswith("gas_optics") and "far_kernel" not in k}
 if gas:
     sw_key = max(gas, key=lambda k: gas[k]["grid_threads"])
     lw_key = min(gas, key=lambda k: gas[k]["grid_threads"])
