@@ -20,7 +20,7 @@
  *
  * Usage:  rfmip_batch_driver HITRAN.par SOLAR.csv COLUMNS.bin [-h2o-ctm DIR] [-o3-ctm FILE] [-CFC-11 FILE ppmv]
  *             [-CFC-12 FILE ppmv] [-N2-N2 FILE] [-O2-N2 FILE] [-O2-O2 FILE] [-w-lw W0 -W-lw WN -r-lw DW]
- *             [-w-sw W0 -W-sw WN -r-sw DW] [-chunk N] [-fast 0|1|2] [-d DEVICE]
+ *             [-w-sw W0 -W-sw WN -r-sw DW] [-chunk N] [-fast 0|1|2|3] [-d DEVICE]
  * Output: one line per column "col <i>: rlut rlus rldt rlds rsut rsus rsdt rsds" [W m-2] (zeros for the shortwave
  * of night columns).
  */
@@ -104,7 +104,7 @@ int main(int argc, char **argv)
     Device_t device;
     int dev_id = (int)number(argc, argv, "-d", 0.);
     check(create_device(&device, option(argc, argv, "-d", 1) ? &dev_id : NULL));
-    int const method = line_sample, fast = (int)number(argc, argv, "-fast", 1.);
+    int const method = line_sample, fast = (int)number(argc, argv, "-fast", 3.);
     int const mol_ids[7] = {H2O, CO2, O3, N2O, CO, CH4, O2};
     char const *cfc_flag[2] = {"-CFC-11", "-CFC-12"};
     int const cfc_id[2] = {CFC11, CFC12};

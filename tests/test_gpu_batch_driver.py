@@ -73,7 +73,7 @@ def test_batched_c_driver_matches_oracle(tmp_path, oracle, lib):
             "-CFC-11", swb.files["cfc11"], "2.3e-4", "-CFC-12", swb.files["cfc12"], "5.2e-4",
             "-N2-N2", swb.files["cia_n2n2"], "-O2-N2", swb.files["cia_o2n2"], "-O2-O2", swb.files["cia_o2o2"],
             "-w-lw", "1", "-W-lw", "2000", "-r-lw", "1", "-w-sw", "1", "-W-sw", "6000", "-r-sw", "2",
-            "-chunk", "3", "-fast", "1"]
+            "-chunk", "3", "-fast", "3"]
     r = subprocess.run(args, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     got = {}
