@@ -118,3 +118,27 @@ def test_line_centres_exactly_on_grid_points(tmp_path, oracle, lib, device):
     peak = want.argmax(axis=1)
     rows = np.arange(want.shape[0])
     assert np.max(np.abs(mp[rows, peak] - want[rows, peak]) / want[rows, peak]) < 2e-6
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_randomised_grids_profiles_and_launch_shapes(tmp_path, oracle, lib, device, seed):
+    """Random band position, grid spacing (windows of 33 to 501 points), line density, number of levels, surface
+    pressure, temperature offset, tile size and line slicing: the one- and two-pass moment kernels and the ring kernel
+    all within the fused form's tolerance of the oracle, and within rounding of each other."""
+    rng = np.random.default_rng(4242 + seed)
+    dw = float(rng.choice([0.1, 0.2, 0.25, 0.5, 1.0, 1.25, 1.5]))
+    npts = int(rng.integers(150, 900))
+    w0 = float(np.round(rng.choice([1.0, 300.0, 2000.0, 9000.0, 30000.0]) + rng.uniform(0, 50), 2))
+    span = npts * dw
+    if w0 + span > 50000.0:
+        w0 = 50000.0 - span
+    nlines = int(rng.integers(50, 6000))
+    V = int(rng.integers(4, 15))
+    band = Band(str(tmp_path), w0, w0 + span, dw, nlines, seed=int(rng.integers(1, 10**6)), sw=w0 > 3000.0,
+                with_cfc=w0 < 3000.0)
+    col = syn.profile(int(rng.integers(0, 50)), V)
+    col["p"] = col["p"] * float(rng.choice([0.3, 1.0, 1.0, 2.5]))
+    col["t"] = np.clip(col["t"] + float(rng.uniform(-40, 30)), 150.0, 340.0)
+    tile = int(rng.choice([0, 0, 64, 128, 256, 512]))
+    nslice = int(rng.choice([0, 0, 1, 2, 5]))
+    check(band, device, oracle, lib, col, tile=tile, nslice=nslice)
