@@ -735,7 +735,7 @@ int log2_exact(int v)
 extern "C" int grt_gas_optics_mp_applicable(GrtGasOpticsArgs const *a)
 {
     long long const fsteps = (long long)ceil((double)25.f/a->wres);   // kernels.c:417
-    if (fsteps < 16 || fsteps > 4096)
+    if (fsteps < 1 || fsteps > 4096)
     {
         return 0;
     }
