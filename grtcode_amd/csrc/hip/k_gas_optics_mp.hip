@@ -135,7 +135,7 @@ struct MpQueue
 // 8-term remainder below 1e-7 of the far-wing value.  If that asks for more than the window, the whole
 // window is "near" (R = fsteps) and no moments are formed.  ms_l: this layer's [slot][4] block in LDS.
 __device__ int near_radius(GrtGasOpticsArgs const &a, double const *lay, double const *ms_l, long long F1l, int fsteps,
-                           bool *use_moments)
+                           bool *use_moments, double *zmax = nullptr)
 {
     double gmax = 0., dop = 0.;         // max over slots of yair_max (P - Ps) + yself_max Ps; of the Doppler factor
     for (int sl = 0; sl < a.lay.num_slots; ++sl)
@@ -144,6 +144,10 @@ __device__ int near_radius(GrtGasOpticsArgs const &a, double const *lay, double 
         dop = fmax(dop, ms_l[sl*4 + 3]);
     }
     double const eta = gmax*exp(a.lines.nmax*fabs(lay[3]))/a.wres;
+    if (zmax != nullptr)
+    {
+        *zmax = sqrt(0.25 + eta*eta);       // every line of the layer has |z| = |delta + i eta| below this
+    }
     int const r_mp = (int)ceil(7.8*sqrt(0.25 + eta*eta)) - 1;
     int const r_lo = r_mp < 3 ? 3 : r_mp;
     // Humlicek region 1 reaches XLIM0 <= 123.4 Doppler units from the centre: evaluate it inside the ring
@@ -678,18 +682,37 @@ __global__ __launch_bounds__(kBlock) void gas_optics_far_kernel(GrtGasOpticsArgs
         rmin = rtab[t] < rmin ? rtab[t] : rmin;
         rmax = rtab[t] > rmax ? rtab[t] : rmax;
     }
-    for (int i = tid; i < F1 - F0; i += kBlock)
+    // The series is geometric in |z|/r, so the far cells need fewer terms: K terms leave (|z|max/r)^K, kept
+    // below the 7e-8 that 8 terms leave at the edge of the near field (ratio 0.128).  r >= rk[K] may use K terms.
+    int rk[kMom + 1];
+    for (int k = 0; k <= kMom; ++k)
     {
-        int const f = F0 + i;
+        rk[k] = fsteps + 1;
+    }
+    if (fsteps > 64)
+    {
+        bool um;
+        double zmax;
+        near_radius(a, lay, ms_l, F1l, fsteps, &um, &zmax);
+        double const need[kMom + 1] = {1e30, 1e30, 1e30, 240., 61., 27., 15.6, 10.5, 0.};     // (7e-8)^(-1/K)
+        for (int k = 0; k <= kMom; ++k)
+        {
+            double const r = ceil(zmax*need[k]);
+            rk[k] = r < (double)(fsteps + 1) ? (int)r : fsteps + 1;
+        }
+    }
+    auto gather = [&](int i, int f, int r_from, int r_to, auto terms_tag) -> double
+    {
+        constexpr int TERMS = decltype(terms_tag)::value;
         double sum = 0.;
-        for (int r = rmin + 1; r <= fsteps; ++r)
+        for (int r = r_from; r <= r_to; ++r)
         {
             float const u = invr[r];
             float const *ma = mom + (i + fsteps - r);           // cell f - r: offset +r
             float const *mb = mom + (i + fsteps + r);           // cell f + r: offset -r
-            float pa = ma[(kMom - 1)*ncell], pb = mb[(kMom - 1)*ncell];
+            float pa = ma[(TERMS - 1)*ncell], pb = mb[(TERMS - 1)*ncell];
 #pragma unroll
-            for (int k = kMom - 2; k >= 0; --k)
+            for (int k = TERMS - 2; k >= 0; --k)
             {
                 pa = fmaf(pa, u, ma[k*ncell]);
                 pb = fmaf(pb, -u, mb[k*ncell]);
@@ -703,6 +726,21 @@ __global__ __launch_bounds__(kBlock) void gas_optics_far_kernel(GrtGasOpticsArgs
             }
             sum += (double)((pa + pb)*(u*u));
         }
+        return sum;
+    };
+    for (int i = tid; i < F1 - F0; i += kBlock)
+    {
+        int const f = F0 + i;
+        int r = rmin + 1;
+        double sum = 0.;
+        auto upto = [&](int bound) { int const e = bound - 1 < fsteps ? bound - 1 : fsteps; return e; };
+        // (short windows, fsteps <= 64 -- 1 cm-1 has 22 cells a side -- take all terms in one loop: rk[] = fsteps + 1)
+        { int const e = upto(rk[7]); if (r <= e) { sum += gather(i, f, r, e, std::integral_constant<int, 8>{}); r = e + 1; } }
+        { int const e = upto(rk[6]); if (r <= e) { sum += gather(i, f, r, e, std::integral_constant<int, 7>{}); r = e + 1; } }
+        { int const e = upto(rk[5]); if (r <= e) { sum += gather(i, f, r, e, std::integral_constant<int, 6>{}); r = e + 1; } }
+        { int const e = upto(rk[4]); if (r <= e) { sum += gather(i, f, r, e, std::integral_constant<int, 5>{}); r = e + 1; } }
+        { int const e = upto(rk[3]); if (r <= e) { sum += gather(i, f, r, e, std::integral_constant<int, 4>{}); r = e + 1; } }
+        if (r <= fsteps) { sum += gather(i, f, r, fsteps, std::integral_constant<int, 3>{}); }
         acc[i] += sum;
     }
     __syncthreads();
