@@ -25,7 +25,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector
 
 
-def cpu_baseline(wl_args, thin_lw=8, thin_sw=8):
+def cpu_baseline(wl_args, thin_lw=1, thin_sw=1):
     """Reference OpenMP path (oracle/_ref, the reference's own C) -- or our restatement when the
     prebuilt reference library is absent -- timed on a bounded sample: one column, full LW+SW grids
     and solvers, line lists thinned by 1/thin; gas-optics time is scaled back by `thin`."""
@@ -98,8 +98,10 @@ def cpu_baseline(wl_args, thin_lw=8, thin_sw=8):
         detail[band] = dict(gas_optics_s_sample=round(t_gas, 3), rest_s=round(t_rest, 3), thin=thin)
         total += t_gas * thin + t_rest
     return {"value": 1.0 / total, "unit": "columns/s", "cores": cores, "kind": kind,
-            "sample": f"1 column, LW+SW at 1 cm-1, 60 layers, line lists thinned 1/{thin_lw} (LW) and 1/{thin_sw} (SW); "
-                      f"gas-optics time scaled back by the thinning factor, all other stages at full size",
+            "sample": ("1 column of the bench workload at full size (LW+SW at 1 cm-1, 60 layers, all lines)"
+                       if thin_lw == 1 and thin_sw == 1 else
+                       f"1 column, LW+SW at 1 cm-1, 60 layers, line lists thinned 1/{thin_lw} (LW) and 1/{thin_sw} (SW); "
+                       f"gas-optics time scaled back by the thinning factor, all other stages at full size"),
             "seconds_per_column_est": round(total, 2), "detail": detail}
 
 
