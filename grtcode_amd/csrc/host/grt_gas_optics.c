@@ -20,6 +20,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include "grt_internal.h"
 #include "grt_molecule_table.h"
 
@@ -87,15 +88,16 @@ static int fixed_field(char const *rec, int off, int len, char *buf)
    S(10) A(10) g_air(5) g_self(5) E"(10) n(4) delta(8) + 93 unused.  A record is kept
    when the molecule matches and w0 <= nu <= wn (:340).  Isotopologue codes: '0' -> 10,
    'A'.. -> 11.. (:177-194). */
-int grt_parse_hitran(char const *path, int mol_id, double w0, double wn, GrtHostLines *out)
+/* One pass over the file.  mol_id != 0: the reference's behaviour -- keep this molecule's records with
+   w0 <= nu <= wn in `out` (one bucket).  mol_id == 0: every molecule's records, unfiltered, into
+   out[molecule - 1] (NUM_MOLS buckets; records of unknown molecule numbers are skipped) -- the parse-once
+   index below.  Strengths are left as tabulated (296 K). */
+static int scan_hitran(char const *path, int mol_id, double w0, double wn, GrtHostLines *out)
 {
-    GRT_REQUIRE_PTR(path);
-    GRT_REQUIRE_PTR(out);
-    memset(out, 0, sizeof(*out));
     FILE *fp = NULL;
     GRT_TRY(open_file(&fp, path, "r"));
-    GRT_INFO("Reading HITRAN line parameters for molecule %d from %s.", mol_id, path);
-    uint64_t cap = 0;
+    uint64_t cap[NUM_MOLS];
+    memset(cap, 0, sizeof(cap));
     char *line = NULL;
     size_t linecap = 0;
     ssize_t len;
@@ -115,16 +117,18 @@ int grt_parse_hitran(char const *path, int mol_id, double w0, double wn, GrtHost
         int off = fixed_field(line, 0, 2, buf);
         int mol = 0;
         if ((rc = to_int(buf, &mol)) != GRTCODE_SUCCESS) break;
-        if (mol != mol_id)
+        if (mol_id != 0 ? mol != mol_id : (mol < 1 || mol > NUM_MOLS))
         {
             continue;
         }
-        if (out->n == cap)
+        int const bucket = mol_id != 0 ? 0 : mol - 1;
+        GrtHostLines *o = &out[bucket];
+        if (o->n == cap[bucket])
         {
-            cap = cap ? 2*cap : 65536;
-            if ((rc = host_lines_reserve(out, cap)) != GRTCODE_SUCCESS) break;
+            cap[bucket] = cap[bucket] ? 2*cap[bucket] : 65536;
+            if ((rc = host_lines_reserve(o, cap[bucket])) != GRTCODE_SUCCESS) break;
         }
-        uint64_t const k = out->n;
+        uint64_t const k = o->n;
         off = fixed_field(line, off, 1, buf);
         int iso = 0;
         if (buf[0] == '0') iso = 10;
@@ -137,16 +141,16 @@ int grt_parse_hitran(char const *path, int mol_id, double w0, double wn, GrtHost
             rc = GRTCODE_VALUE_ERR;
             break;
         }
-        out->iso[k] = (uint8_t)iso;
+        o->iso[k] = (uint8_t)iso;
         double d;
         off = fixed_field(line, off, 12, buf);
         if ((rc = to_double(buf, &d)) != GRTCODE_SUCCESS) break;
-        out->v0[k] = d;
+        o->v0[k] = d;
         off = fixed_field(line, off, 10, buf);
         if ((rc = to_double(buf, &d)) != GRTCODE_SUCCESS) break;
-        out->s0[k] = d;
+        o->s0[k] = d;
         off += 10;                                     /* Einstein A: unused */
-        float *f32dst[5] = {&out->yair[k], &out->yself[k], &out->en[k], &out->nexp[k], &out->delta[k]};
+        float *f32dst[5] = {&o->yair[k], &o->yself[k], &o->en[k], &o->nexp[k], &o->delta[k]};
         int const width[5] = {5, 5, 10, 4, 8};
         for (int c = 0; c < 5 && rc == GRTCODE_SUCCESS; ++c)
         {
@@ -157,9 +161,9 @@ int grt_parse_hitran(char const *path, int mol_id, double w0, double wn, GrtHost
             }
         }
         if (rc != GRTCODE_SUCCESS) break;
-        if ((w0 < 0 && wn < 0) || (out->v0[k] >= w0 && out->v0[k] <= wn))
+        if (mol_id == 0 || (w0 < 0 && wn < 0) || (o->v0[k] >= w0 && o->v0[k] <= wn))
         {
-            out->n++;
+            o->n++;
         }
     }
     free(line);
@@ -170,9 +174,98 @@ int grt_parse_hitran(char const *path, int mol_id, double w0, double wn, GrtHost
     }
     if (rc != GRTCODE_SUCCESS)
     {
-        grt_free_host_lines(out);
+        for (int m = 0; m < (mol_id != 0 ? 1 : NUM_MOLS); ++m)
+        {
+            grt_free_host_lines(&out[m]);
+        }
         grt_err_frame(__FILE__, __LINE__);
-        return rc;
+    }
+    return rc;
+}
+
+/* Parse-once index (§8(f)-3).  The reference scans the whole .par file once per add_molecule -- seven
+   passes over a few hundred MB for one band, again for the second band.  Here the first request for a
+   file parses every molecule's records into memory once; later requests (any molecule, any gas-optics
+   object of this process) filter from memory.  Keyed by path, size and modification time; the two most
+   recent files are kept.  GRT_HITRAN_CACHE=0 in the environment restores one scan per call. */
+typedef struct HitranIndex
+{
+    char path[DIR_PATH_LEN];
+    long long size, mtime;
+    unsigned long stamp;
+    GrtHostLines mol[NUM_MOLS];
+} HitranIndex;
+static HitranIndex g_hitran_index[2];
+static unsigned long g_hitran_stamp = 0;
+
+static int hitran_index(char const *path, HitranIndex **out)
+{
+    struct stat st;
+    if (stat(path, &st) != 0)
+    {
+        GRT_FAIL(GRTCODE_IO_ERR, "failed to open file %s.", path);
+    }
+    HitranIndex *victim = &g_hitran_index[0];
+    for (int i = 0; i < 2; ++i)
+    {
+        HitranIndex *h = &g_hitran_index[i];
+        if (h->stamp != 0 && strcmp(h->path, path) == 0 && h->size == (long long)st.st_size
+            && h->mtime == (long long)st.st_mtim.tv_sec*1000000000ll + st.st_mtim.tv_nsec)
+        {
+            h->stamp = ++g_hitran_stamp;
+            *out = h;
+            return GRTCODE_SUCCESS;
+        }
+        if (h->stamp < victim->stamp)
+        {
+            victim = h;
+        }
+    }
+    for (int m = 0; m < NUM_MOLS; ++m)
+    {
+        grt_free_host_lines(&victim->mol[m]);
+    }
+    victim->stamp = 0;
+    GRT_INFO("Indexing HITRAN line parameters of every molecule in %s.", path);
+    GRT_TRY(scan_hitran(path, 0, 0., 0., victim->mol));
+    GRT_TRY(copy_str(victim->path, path, DIR_PATH_LEN));
+    victim->size = (long long)st.st_size;
+    victim->mtime = (long long)st.st_mtim.tv_sec*1000000000ll + st.st_mtim.tv_nsec;
+    victim->stamp = ++g_hitran_stamp;
+    *out = victim;
+    return GRTCODE_SUCCESS;
+}
+
+int grt_parse_hitran(char const *path, int mol_id, double w0, double wn, GrtHostLines *out)
+{
+    GRT_REQUIRE_PTR(path);
+    GRT_REQUIRE_PTR(out);
+    memset(out, 0, sizeof(*out));
+    char const *env = getenv("GRT_HITRAN_CACHE");
+    if (mol_id < 1 || mol_id > NUM_MOLS || (env != NULL && env[0] == '0'))
+    {
+        GRT_INFO("Reading HITRAN line parameters for molecule %d from %s.", mol_id, path);
+        GRT_TRY(scan_hitran(path, mol_id, w0, wn, out));
+    }
+    else
+    {
+        HitranIndex *idx = NULL;
+        GRT_TRY(hitran_index(path, &idx));
+        GrtHostLines const *src = &idx->mol[mol_id - 1];
+        if (src->n > 0)
+        {
+            GRT_TRY(host_lines_reserve(out, src->n));
+        }
+        for (uint64_t k = 0; k < src->n; ++k)
+        {
+            if ((w0 < 0 && wn < 0) || (src->v0[k] >= w0 && src->v0[k] <= wn))      /* parse_HITRAN_file.c:340 */
+            {
+                uint64_t const j = out->n++;
+                out->v0[j] = src->v0[k]; out->s0[j] = src->s0[k];
+                out->yair[j] = src->yair[k]; out->yself[j] = src->yself[k]; out->en[j] = src->en[k];
+                out->nexp[j] = src->nexp[k]; out->delta[j] = src->delta[k]; out->iso[j] = src->iso[k];
+            }
+        }
     }
     rescale_strengths(mol_id, out);
     return GRTCODE_SUCCESS;

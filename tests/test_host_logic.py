@@ -156,6 +156,33 @@ def test_hitran_reader_matches_written_records(lib, oracle, tmp_path):
     assert lib.grt_parse_hitran(b"/nonexistent.par", 1, C.c_double(1.0), C.c_double(1000.0), C.byref(hl)) == api.IO_ERR
 
 
+def test_hitran_parse_once_index_equals_per_molecule_scans(lib, tmp_path, monkeypatch):
+    """§8(f)-3: the first request for a file indexes every molecule's records; later requests filter from memory.
+    Same arrays as one scan per call (GRT_HITRAN_CACHE=0, the reference's behaviour); a rewritten file is re-read."""
+    lists = {m: syn.line_list(m, 150 + 10 * m, 50.0, 2500.0) for m in (syn.H2O, syn.CO2, syn.O3, syn.CH4)}
+    path = str(tmp_path / "lines.par")
+    syn.write_hitran_par(path, lists)
+
+    def read(mol, lo, hi):
+        hl = HostLines()
+        assert lib.grt_parse_hitran(path.encode(), mol, C.c_double(lo), C.c_double(hi), C.byref(hl)) == 0
+        out = {k: np.ctypeslib.as_array(getattr(hl, k), shape=(hl.n,)).copy() if hl.n else np.zeros(0)
+               for k in ("v0", "s0", "yair", "yself", "en", "nexp", "delta", "iso")}
+        lib.grt_free_host_lines(C.byref(hl))
+        return out
+    cached = {(m, lo): read(m, lo, hi) for m in lists for lo, hi in ((50.0, 2500.0), (700.0, 900.0))}
+    monkeypatch.setenv("GRT_HITRAN_CACHE", "0")
+    for (m, lo), got in cached.items():
+        want = read(m, lo, 2500.0 if lo == 50.0 else 900.0)
+        assert all(np.array_equal(got[k], want[k]) for k in got)
+    monkeypatch.delenv("GRT_HITRAN_CACHE")
+    assert read(syn.N2O, 50.0, 2500.0)["v0"].size == 0           # a molecule the file does not hold
+    # same path, new content: the index is keyed by size and modification time
+    lists[syn.H2O] = syn.line_list(syn.H2O, 37, 50.0, 2500.0, seed=5)
+    syn.write_hitran_par(path, lists)
+    assert read(syn.H2O, 50.0, 2500.0)["v0"].size == 37
+
+
 def test_table_loader_and_solar_flux(lib, oracle, tmp_path):
     w = np.arange(50.0, 151.0, 10.0)
     y = np.exp(-w / 100.0)
