@@ -74,3 +74,34 @@ def test_fortran_helper_reads_back_device_optics(device):
     assert h.optical_properties(C.byref(o.c), dp(t2), dp(o2), dp(g2)) == 0     # gmemcpy(..., FROM_DEVICE)
     assert np.array_equal(t2, tau) and np.array_equal(o2, om) and np.array_equal(g2, g)
     o.destroy()
+
+
+def _run_reference_test(tmp_path, name, link):
+    exe = str(tmp_path / name)
+    src = [os.path.join(REF, "utilities", "test", name + ".c"), os.path.join(REF, "testing_harness", "src", "test_harness.c")]
+    r = subprocess.run(["gcc", "-std=gnu99", "-w", "-O1", f"-I{REF}/testing_harness/src", *link["inc"], *src, *link["lib"],
+                        "-lm", "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120, cwd=str(tmp_path)).stdout
+    return {ln.split()[2].rstrip(":"): ln.strip().endswith("passed.") for ln in out.splitlines() if ln.startswith("Running test")}
+
+
+@needs_ref
+@pytest.mark.parametrize("name,ours_only_fails", [("test_parse_csv", set()), ("test_utilities", set()),
+                                                  ("test_spectral_grid", {"test_grid_points"})])
+def test_reference_unit_tests_run_against_our_library(tmp_path, name, ours_only_fails):
+    """The reference's own host-side unit tests, compiled unchanged where they lie, linked once against OUR library and
+    once against the reference's utilities sources: the same tests pass and the same (stale) tests fail --
+    except where the reference hands out a HOST_ONLY device and this library deliberately refuses to
+    (test_grid_points: create_device(NULL) without a GPU)."""
+    libdir = os.path.join(ROOT, "grtcode_amd", "lib")
+    ours = _run_reference_test(tmp_path, name, dict(inc=[f"-I{ROOT}/include"],
+                                                    lib=[f"-L{libdir}", "-lgrtcode_hip", f"-Wl,-rpath,{libdir}"]))
+    os.makedirs(tmp_path / "ref", exist_ok=True)
+    ref_src = [os.path.join(REF, "utilities", "src", f) for f in ("utilities.c", "verbosity.c", "spectral_grid.c", "device.c",
+                                                                  "parse_csv.c")]
+    theirs = _run_reference_test(tmp_path / "ref", name, dict(inc=[f"-I{REF}/utilities/src"], lib=ref_src))
+    assert set(ours) == set(theirs) and len(ours) >= 7
+    differ = {t for t in ours if ours[t] != theirs[t]}
+    assert differ == ours_only_fails, (ours, theirs)
+    assert sum(ours.values()) >= 7
