@@ -68,7 +68,6 @@ __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, 
     long long const F0l = (long long)tile_idx*a.tile;
     long long const F1l = (F0l + a.tile < nw) ? F0l + a.tile : nw;                // [F0,F1)
     int const F0 = (int)F0l, F1 = (int)F1l;
-    int const L = a.lay.num_layers;
     int const W = (int)(2*fsteps + 1);                                            // full window
 
     double const *cs = a.colstate + (uint64_t)col*a.lay.stride;
@@ -176,7 +175,6 @@ __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, 
         // the pure-Lorentz value REPWID*Y/(pi(X^2+Y^2)) (:103) are the same Lorentzian.
         float const dc = (float)(wnoadj - ((double)c*a.wres + a.w0));
         float const cl = (repwid*y)*0.318309886f;                                     // 1/pi
-        float const c1 = (kRsqrpi*repwid)*(kRsqrpi*y);                                // region 1 scale
         float const x0q = lorentz ? 0.f : xlim0*xlim0;
         // reference-order form
         float const num = repwid*y;                                                   // :103
