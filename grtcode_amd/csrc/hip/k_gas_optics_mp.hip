@@ -514,6 +514,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
         // per row, sixteen steps.  PERIOD 8 (the wave's near fields fit in 8 grid points -- the usual case
         // at 1 cm-1, R = 3): slots s and s + 8 of a row stand for the same grid point and start half a row
         // apart, so after eight steps the two tokens of a grid point have together met all 16 lines.
+        // PERIOD 4 likewise with four tokens per grid point: spans are covered in pieces of 16, 8 and 4.
         auto ring_block = [&](int fbp, auto period_tag)
         {
             constexpr int PERIOD = decltype(period_tag)::value;
@@ -547,15 +548,28 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
         if (amp == 12345.678) acc[lane] = amp + cl + wr + ndcr + d0r + d2r + a0 + mid + half + xq_near + x0q;
         if (amp == 12345.678)
 #endif
-        for (int fbp = fb; fbp <= fe; fbp += 16)
+        for (int fbp = fb; fbp <= fe;)
         {
-            if (fe - fbp < 8)
+            int const left = fe - fbp + 1;                               // grid points still to cover
+            if (left <= 4)
             {
-                ring_block(fbp, std::integral_constant<int, 8>{});      // what is left fits in 8 points
+                ring_block(fbp, std::integral_constant<int, 4>{});       // four tokens per grid point, four steps
+                fbp += 4;
+            }
+            else if (left <= 8)
+            {
+                ring_block(fbp, std::integral_constant<int, 8>{});
+                fbp += 8;
+            }
+            else if (left <= 12)
+            {
+                ring_block(fbp, std::integral_constant<int, 8>{});       // 8 + 4 rather than 16
+                fbp += 8;
             }
             else
             {
                 ring_block(fbp, std::integral_constant<int, 16>{});
+                fbp += 16;
             }
         }
     }
