@@ -502,9 +502,18 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
         // ---- near field: |f - c| <= R, clipped to the line's window and the tile ----
         int const lo_n = valid ? (lo > c - R ? lo : c - R) : 1;
         int const hi_n = valid ? (hi < c + R ? hi : c + R) : 0;
-        int const fb = wave_min_s(lo_n <= hi_n ? lo_n : 0x7fffffff);
-        int const fe = wave_max_s(lo_n <= hi_n ? hi_n : (int)0x80000000);
-        if (fb > fe)
+        // Each row of 16 lanes is a ring of its own, so each row covers the span of ITS lines (sorted lines:
+        // a row's 16 centres sit in one or two cells, the wave's 64 in two to four); the wave only shares the
+        // number of steps, the longest row's.
+        int fb = lo_n <= hi_n ? lo_n : 0x7fffffff, fe = lo_n <= hi_n ? hi_n : (int)0x80000000;
+        fb = min(fb, dpp_i<0x121>(fb)); fe = max(fe, dpp_i<0x121>(fe));
+        fb = min(fb, dpp_i<0x122>(fb)); fe = max(fe, dpp_i<0x122>(fe));
+        fb = min(fb, dpp_i<0x124>(fb)); fe = max(fe, dpp_i<0x124>(fe));
+        fb = min(fb, dpp_i<0x128>(fb)); fe = max(fe, dpp_i<0x128>(fe));       // the row's span, in every lane of the row
+        int const len = fb <= fe ? fe - fb + 1 : 0;
+        int const span = max(max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 16)),
+                             max(__builtin_amdgcn_readlane(len, 32), __builtin_amdgcn_readlane(len, 48)));
+        if (span == 0)
         {
             continue;
         }
@@ -548,28 +557,23 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
         if (amp == 12345.678) acc[lane] = amp + cl + wr + ndcr + d0r + d2r + a0 + mid + half + xq_near + x0q;
         if (amp == 12345.678)
 #endif
-        for (int fbp = fb; fbp <= fe;)
+        for (int done = 0; done < span;)
         {
-            int const left = fe - fbp + 1;                               // grid points still to cover
+            int const left = span - done;                                // grid points still to cover (longest row)
             if (left <= 4)
             {
-                ring_block(fbp, std::integral_constant<int, 4>{});       // four tokens per grid point, four steps
-                fbp += 4;
-            }
-            else if (left <= 8)
-            {
-                ring_block(fbp, std::integral_constant<int, 8>{});
-                fbp += 8;
+                ring_block(fb + done, std::integral_constant<int, 4>{}); // four tokens per grid point, four steps
+                done += 4;
             }
             else if (left <= 12)
             {
-                ring_block(fbp, std::integral_constant<int, 8>{});       // 8 + 4 rather than 16
-                fbp += 8;
+                ring_block(fb + done, std::integral_constant<int, 8>{}); // 8, or 8 + 4 rather than 16
+                done += 8;
             }
             else
             {
-                ring_block(fbp, std::integral_constant<int, 16>{});
-                fbp += 16;
+                ring_block(fb + done, std::integral_constant<int, 16>{});
+                done += 16;
             }
         }
     }
