@@ -442,6 +442,48 @@ __device__ __forceinline__ void candidate_range(GrtGasOpticsArgs const &a, doubl
     range[1] = (long long)e;
 }
 
+// The same range found by one whole wave: 64 probes per step instead of one (three or four dependent
+// loads instead of twenty for a million lines; the workgroup waits for this before it can start).
+// strict: first index with v > target, else first index with v >= target.
+__device__ __forceinline__ uint64_t wave_partition_point(double const *v, uint64_t n, double target, bool strict, int lane)
+{
+    uint64_t lo = 0, hi = n;                        // the answer lies in [lo, hi]
+    while (hi - lo > 64)
+    {
+        uint64_t const len = hi - lo;
+        uint64_t const pos = lo + ((uint64_t)(lane + 1)*len)/65;        // lo < pos < hi, increasing with the lane
+        double const x = v[pos];
+        bool const left_of_answer = strict ? (x <= target) : (x < target);
+        int const k = __popcll(__ballot(left_of_answer));              // lanes 0..k-1 (v is sorted)
+        uint64_t const new_lo = k == 0 ? lo : lo + ((uint64_t)k*len)/65 + 1;
+        uint64_t const new_hi = k == 64 ? hi : lo + ((uint64_t)(k + 1)*len)/65;
+        lo = new_lo;
+        hi = new_hi;
+    }
+    uint64_t const j = lo + (uint64_t)lane;
+    bool const left_of_answer = j < hi && (strict ? (v[j] <= target) : (v[j] < target));
+    return lo + (uint64_t)__popcll(__ballot(left_of_answer));
+}
+
+__device__ __forceinline__ void candidate_range_wave(GrtGasOpticsArgs const &a, double const *lay, long long F0l,
+                                                     long long F1l, long long fsteps, int slice, long long *range, int lane)
+{
+    double const shift = a.lines.dmax*fabs(lay[0]);
+    double const wlo = a.w0 + ((double)(F0l - fsteps) - 1.5)*a.wres - shift;
+    double const whi = a.w0 + ((double)(F1l + fsteps) + 0.5)*a.wres + shift;
+    uint64_t const jlo = wave_partition_point(a.lines.v0, a.lines.n, wlo, false, lane);
+    uint64_t const jhi = wave_partition_point(a.lines.v0, a.lines.n, whi, true, lane);
+    uint64_t const per = (jhi - jlo + a.nslice - 1)/a.nslice;
+    uint64_t const b = jlo + per*slice;
+    uint64_t e = b + per;
+    if (e > jhi) e = jhi;
+    if (lane == 0)
+    {
+        range[0] = (long long)(b < jhi ? b : jhi);
+        range[1] = (long long)e;
+    }
+}
+
 // Epilogue: fold in continua / CFC / CIA and write the tile once.
 // Two consecutive grid points per lane: one 16-byte store per lane (1 KiB per wave instruction)
 // whenever the row start is 16-byte aligned, which also is the store shape WRITE_SIZE is

@@ -225,9 +225,9 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
         invr[i] = i > 0 ? 1.0f/(float)i : 0.f;
     }
     stage_column_state(a, cs, layer, ms_l, q_l, tid);
-    if (tid == 0)
+    if (wave == 0)
     {
-        candidate_range(a, lay, F0l, F1l, TWO_PASS ? 0 : fsteps_ll, slice, range);
+        candidate_range_wave(a, lay, F0l, F1l, TWO_PASS ? 0 : fsteps_ll, slice, range, lane);
     }
     __syncthreads();
     uint64_t const jbeg = (uint64_t)range[0];
