@@ -38,6 +38,13 @@ class OrcMolecule(C.Structure):
                 ("q", c_double_p), ("h2o_ctm", C.c_int), ("o3_ctm", C.c_int)]
 
 
+class OrcBins(C.Structure):              # oracle/grt_oracle.h
+    _fields_ = [("num_layers", C.c_int), ("w0", C.c_double), ("wres", C.c_double), ("width", C.c_double),
+                ("num_wpoints", C.c_uint64), ("n", C.c_uint64), ("isize", C.c_uint64),
+                ("ppb", C.c_int), ("do_interp", C.c_int), ("last_ppb", C.c_int), ("do_last_interp", C.c_int),
+                ("w", c_double_p), ("tau", c_double_p), ("l", C.POINTER(C.c_uint64)), ("r", C.POINTER(C.c_uint64))]
+
+
 class Oracle:
     """numpy-level wrapper over liboracle.so."""
 
@@ -153,6 +160,23 @@ class Oracle:
         l, r = C.c_uint64(0), C.c_uint64(0)
         rc = self.lib.orc_bracket(C.c_uint64(array.size), _dp(array), C.c_double(val), C.byref(l), C.byref(r))
         return rc, l.value, r.value
+
+    def sweep(self, method, vnn, snn, gamma, alpha, ns, w0, wres, nw, bin_width=1.0):
+        """One molecule through sort_lines + bin sweep (method 0) or line sweep (1), then the interpolation:
+        kernels.c:135-406,514-581 on prepared (layer, line) arrays."""
+        vnn, snn, gamma, alpha, ns = (_f64(a).copy() for a in (vnn, snn, gamma, alpha, ns))
+        L, N = vnn.shape
+        bins = OrcBins()
+        self.lib.orc_bins_create(C.byref(bins), C.c_int(L), C.c_double(w0), C.c_uint64(nw), C.c_double(wres),
+                                 C.c_double(bin_width))
+        tau = np.zeros((L, nw))
+        if method == 0:
+            self.lib.orc_sort_lines(C.c_uint64(N), C.c_int(L), _dp(vnn), _dp(snn), _dp(gamma), _dp(alpha))
+        f = self.lib.orc_bin_sweep if method == 0 else self.lib.orc_line_sweep
+        f(C.c_uint64(N), C.c_int(L), _dp(vnn), _dp(snn), _dp(gamma), _dp(alpha), _dp(ns), C.byref(bins), _dp(tau))
+        self.lib.orc_interpolate(C.byref(bins), _dp(tau))
+        self.lib.orc_bins_destroy(C.byref(bins))
+        return tau
 
     def rayleigh(self, num_layers, p_mb, w0, dw, nw):
         p_mb = _f64(p_mb)

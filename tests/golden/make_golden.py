@@ -51,6 +51,15 @@ def main():
                ls_tavg=tavg, ls_ps=ps, ls_ns=ns, ls_vnn=vnn, ls_snn=snn, ls_gamma=gamma, ls_alpha=alpha_d,
                ls_grid=np.array([w0, dw, nw]), ls_tau=tau)
 
+    # (ii-b) the same prepared lines through the two sweep methods (kernels.c:135-406,514-581) on a grid that
+    # extends 29.5 cm-1 above the highest line (line_sweep indexes one bin past its arrays for nearer lines)
+    sw_nw = 321
+    for method in (0, 1):
+        bins = ref.sweep_bins(vnn.shape[0], w0, dw, sw_nw)
+        t_sw = ref.sweep(method, bins, vnn, snn, gamma, alpha_d, ns, np.zeros((vnn.shape[0], sw_nw)))
+        out["sweep%d_tau" % method] = ref.interpolate(bins, t_sw)
+    out.update(sweep_grid=np.array([w0, dw, sw_nw]))
+
     # (iii) continua / CFC / CIA (kernels.c:469-510,585-630)
     tab = rng.uniform(1e-24, 1e-22, (4, nw))
     tab[2:] = rng.uniform(0.001, 0.03, (2, nw))

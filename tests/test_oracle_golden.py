@@ -117,6 +117,15 @@ def test_line_sample_bit_exact_vs_fixture(oracle, fx):
     assert (ws == 0).any() and (we == int(nw) - 1).any() and (ws > we).any()   # clipping + dropped lines exercised
 
 
+@pytest.mark.parametrize("method", [0, 1])
+def test_sweep_methods_bit_exact_vs_fixture(oracle, fx, method):
+    """wavenumber_sweep / line_sweep on the fixture's prepared lines (committed numbers from the reference build)."""
+    w0, dw, nw = fx["sweep_grid"]
+    got = oracle.sweep(method, fx["ls_vnn"], fx["ls_snn"], fx["ls_gamma"], fx["ls_alpha"], fx["ls_ns"], w0, dw, int(nw))
+    assert np.array_equal(got, fx["sweep%d_tau" % method])
+    assert got.max() > 0
+
+
 def test_continua_bit_exact_vs_fixture(oracle, fx):
     L, nw = fx["ct_h2o"].shape
     tab = fx["ct_tab"]
