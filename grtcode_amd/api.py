@@ -314,6 +314,11 @@ class GasOpticsObject:
     def tune(self, tile=0, nslice=0, fast=0):
         check(self.lib.grt_gas_optics_tune(C.byref(self.c), tile, nslice, fast))
 
+    def last_launch(self):
+        info = (C.c_longlong * 6)()
+        check(self.lib.grt_gas_optics_last_launch(C.byref(self.c), info))
+        return dict(zip(("fast", "tile", "nslice", "tree_levels", "halo", "moment_bytes"), info))
+
     def calculate_optical_depth(self, p_mb, t, optics):
         p_mb, t = _f64(p_mb).copy(), _f64(t).copy()
         check(self.lib.calculate_optical_depth(C.byref(self.c), _dp(p_mb), _dp(t), C.byref(optics.c)))

@@ -75,7 +75,13 @@ typedef struct GrtGasOpticsArgs
     int fast;                 /* 0: reference operation order; 1: fused form, far wings by cell moments
                                  where the window is wide enough; 2: fused form, every point in the ring;
                                  3: as 1 in two passes (cell moments through gmom) */
-    float *gmom;              /* two-pass form only: [ncol][L][8][nw] cell moments */
+    float *gmom;              /* two-pass form only: [ncol][L] blocks of gmom_stride floats; level 0 = [nw][8] cell
+                                 moments, then (tree_levels > 0) levels 1..tree_levels, level l = [ceil(nw/2^l)][8] */
+    uint64_t gmom_stride;
+    int halo;                 /* two-pass form: grid points either side of a cell tile the first pass may add to
+                                 (the window's half-width, or -- tree form -- a bound on the near-field radius) */
+    int rcap;                 /* widest near field taken for the sake of Humlicek region 1 */
+    int tree_levels;          /* > 0: far field by the cell hierarchy (fine grids), this many coarse levels */
     int profile_tag;          /* != 0: time the line kernel under this tag (the two-pass gather under tag + 5) */
 } GrtGasOpticsArgs;
 
@@ -86,6 +92,7 @@ void grt_profile_end(void *stream, int slot);
 /* fast == 1 only: the cell-moment kernel (k_gas_optics_mp.hip) and whether it applies to a grid */
 int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a);
 int grt_gas_optics_mp_applicable(GrtGasOpticsArgs const *a);
+uint64_t grt_gas_optics_moment_floats(uint64_t nw, int levels);   /* per (column, layer) block of gmom */
 
 /* The RFM sweep methods (k_gas_optics_sweep.hip; kernels.c:135-406,514-581).  Per molecule: `prep` holds
    vnn, snn, gamma, alpha as [4][L][n] (grt_launch_line_prep); grt_launch_sweep_sort writes them sorted by

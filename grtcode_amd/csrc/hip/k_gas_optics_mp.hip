@@ -32,7 +32,7 @@
 namespace {
 
 constexpr int kMom = 8;         // moments per cell
-constexpr int kRcap = 12;       // widest near field taken for the sake of region 1 (the moment bound may ask for more)
+constexpr int kRcap = 12;       // widest near field taken for the sake of region 1 unless the host says otherwise (args.rcap)
 constexpr int kCellLoop = 3;    // passes of the in-register moment reduction before falling back to per-lane adds
 
 template <int CTRL>
@@ -157,7 +157,8 @@ __device__ int near_radius(GrtGasOpticsArgs const &a, double const *lay, double 
     double const w_hi = a.w0 + (double)(F1l + fsteps)*a.wres;
     double const alpha_max = 0.83255461115*w_hi*dop;
     double const reach = 123.4*alpha_max/(0.832554611*a.wres) + 0.51;
-    int const r_reg1 = reach < (double)kRcap ? (int)reach : kRcap;
+    int const rcap = a.rcap > 0 ? a.rcap : kRcap;
+    int const r_reg1 = reach < (double)rcap ? (int)reach : rcap;
     int R = r_lo > r_reg1 ? r_lo : r_reg1;
     *use_moments = (R + 4 <= fsteps);
     return *use_moments ? R : fsteps;
@@ -185,7 +186,7 @@ __device__ __forceinline__ void drain_class(double *acc, MpQueue const *q, int w
 // grids want: a tile is 512 points, so at 0.1 cm-1 the one-pass form prepares every line twice.
 template <bool TWO_PASS>
 __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs a, long long fsteps_ll, unsigned ngroups,
-                                                                unsigned perm_stride, int ncell, int nacc)
+                                                                unsigned perm_stride, int ncell, int nacc, int halo)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int const fsteps = (int)fsteps_ll;
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
     long long const F1l = (F0l + a.tile < nw) ? F0l + a.tile : nw;                // [F0,F1)
     int const F0 = (int)F0l, F1 = (int)F1l;
     int const cell0 = TWO_PASS ? F0 : F0 - fsteps;                                // cell of mom[.][0]
-    int const A0 = TWO_PASS ? F0 - fsteps : F0;                                   // grid index of acc[0]
+    int const A0 = TWO_PASS ? F0 - halo : F0;                                     // grid index of acc[0]
 
     double const *cs = a.colstate + (uint64_t)col*a.lay.stride;
     double const *lay = cs + a.lay.off_lay + (uint64_t)layer*4;
@@ -283,9 +284,10 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
         {
             continue;
         }
-        // the line's window, clipped to what the accumulator spans (in the two-pass form that is the whole window)
-        int const lo = valid ? (TWO_PASS || s > F0 ? s : F0) : 1;
-        int const hi = valid ? (TWO_PASS || e_i < F1 - 1 ? e_i : F1 - 1) : 0;
+        // the line's window, clipped to what the accumulator spans (two-pass form: the tile and `halo` points
+        // either side -- the whole window, or, in the tree form, all that a near field can reach)
+        int const lo = valid ? (s > A0 ? s : A0) : 1;
+        int const hi = valid ? (e_i < A0 + nacc - 1 ? e_i : A0 + nacc - 1) : 0;
         double const c2 = -1.4387686f;                                                 // kernels.c:75
         double const invT = lay[2];
         // stimulated emission 1 - exp(c2 v0/T): below exp(-20) = 2e-9 the factor is 1 to fp32 and beyond
@@ -369,7 +371,9 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
             // serves four cells at once; sorted lines rarely put more than two cells in a row.  Whatever is
             // still pending after kCellLoop passes (sparse spectra: a cell per line) is added lane by lane.
             bool pending = valid;
-            for (int pass = 0; pass < kCellLoop && __ballot(pending) != 0ull; ++pass)
+            // (a wave spread over two dozen cells or more -- fine grids -- goes lane by lane at once)
+            bool const sparse = wave_max_s(valid ? c : (int)0x80000000) - c_ref >= 24;
+            for (int pass = 0; pass < kCellLoop && !sparse && __ballot(pending) != 0ull; ++pass)
             {
                 int cr = pending ? c : 0x7fffffff;
                 cr = min(cr, dpp_i<0x121>(cr));
@@ -597,17 +601,17 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
                 unsafeAtomicAdd(&out[f], acc[i]);
             }
         }
-        float *gm = a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*kMom*a.nw;
+        float *gm = a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*a.gmom_stride + (uint64_t)F0*kMom;   // [cell][8]
         for (int i = tid; i < kMom*(F1 - F0); i += kBlock)
         {
-            int const k = i/(F1 - F0), cidx = i - k*(F1 - F0);
+            int const cidx = i >> 3, k = i & 7;
             if (a.nslice == 1)
             {
-                gm[(uint64_t)k*a.nw + F0 + cidx] = mom[k*ncell + cidx];
+                gm[i] = mom[k*ncell + cidx];
             }
             else
             {
-                unsafeAtomicAdd(&gm[(uint64_t)k*a.nw + F0 + cidx], mom[k*ncell + cidx]);
+                unsafeAtomicAdd(&gm[i], mom[k*ncell + cidx]);
             }
         }
         return;
@@ -673,12 +677,12 @@ __global__ __launch_bounds__(kBlock) void gas_optics_far_kernel(GrtGasOpticsArgs
         invr[i] = i > 0 ? 1.0f/(float)i : 0.f;
     }
     int const cell0 = F0 - fsteps;
-    float const *gm = a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*kMom*a.nw;
+    float const *gm = a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*a.gmom_stride;       // [cell][8]
     for (int i = tid; i < kMom*ncell; i += kBlock)
     {
-        int const k = i/ncell, ci = i - k*ncell;
+        int const ci = i >> 3, k = i & 7;
         long long const c = (long long)cell0 + ci;
-        mom[i] = (c >= 0 && c < nw) ? gm[(uint64_t)k*a.nw + c] : 0.f;
+        mom[k*ncell + ci] = (c >= 0 && c < nw) ? gm[(uint64_t)c*kMom + k] : 0.f;
     }
     for (int i = tid; i < F1 - F0; i += kBlock)
     {
@@ -765,6 +769,247 @@ __global__ __launch_bounds__(kBlock) void gas_optics_far_kernel(GrtGasOpticsArgs
     write_tile(a, acc, cs, col, layer, 0, F0l, F1l, tid);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fine grids (windows of thousands of points): the far field through a hierarchy of cells.
+//
+// A level-l cell is 2^l consecutive level-0 cells, [j 2^l, (j+1) 2^l): its lines sit within h/2 = 2^(l-1) grid
+// steps of its centre C = j 2^l + 2^(l-1) - 1/2, so in units of h the series of the level-0 cells holds again,
+//
+//     sum_i A_i/((f - x_i)^2 + eta_i^2) = (1/h) u^2 (m_1 + u (m_2 + ...)),  u = h/(f - C),  m_k = M_k/h^k,
+//
+// wherever |f - C| >= 7.8 sqrt(h^2/4 + eta_max^2) (the same ratio 0.128 as level 0).  A parent's scaled moments
+// follow from its two children's by the binomial shift  m'_k = sum_{j<=k} C(k,j) (-+1/4)^(k-j) 2^-j m_j  -- one
+// 8 x 8 table for every level (moment_up_kernel).  A grid point must receive exactly the cells c with
+// R(c) < |f - c| <= fsteps (kernels.c:435-437: a line's window is its centre index +- fsteps), so the interval
+// on either side of it is tiled greedily with the largest aligned, admissible cells that stay inside the
+// window: ~8 cells per level, ~100 at 0.001 cm-1 instead of 50 000 (gas_optics_tree_kernel).
+// tests/test_moment_tree.py is the same construction in numpy.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kMaxLevels = 20;
+
+__host__ __device__ inline uint64_t level_cells(uint64_t nw, int l)
+{
+    return (nw + ((uint64_t)1 << l) - 1) >> l;
+}
+
+// floats per (column, layer) block of gmom: levels 0..levels
+__host__ __device__ inline uint64_t level_offset(uint64_t nw, int l)
+{
+    uint64_t off = 0;
+    for (int i = 0; i < l; ++i)
+    {
+        off += level_cells(nw, i)*kMom;
+    }
+    return off;
+}
+
+struct ShiftTable
+{
+    float lo[kMom][kMom], hi[kMom][kMom];     // [k][j]: parent m_(k+1) from the lower / upper child's m_(j+1)
+};
+
+__global__ __launch_bounds__(kBlock) void moment_up_kernel(float *gmom, uint64_t stride, uint64_t off_child, uint64_t n_child,
+                                                            uint64_t off_parent, uint64_t n_parent, ShiftTable t)
+{
+    uint64_t const j = (uint64_t)blockIdx.x*kBlock + threadIdx.x;
+    if (j >= n_parent)
+    {
+        return;
+    }
+    float *blk = gmom + (uint64_t)blockIdx.y*stride;
+    float4 const *ch = reinterpret_cast<float4 const *>(blk + off_child + 2*j*kMom);
+    float4 const a0 = ch[0], a1 = ch[1];
+    bool const two = 2*j + 1 < n_child;
+    float4 const zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 const b0 = two ? ch[2] : zero, b1 = two ? ch[3] : zero;
+    float const lo[kMom] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    float const hi[kMom] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    float m[kMom];
+#pragma unroll
+    for (int k = 0; k < kMom; ++k)
+    {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i <= k; ++i)
+        {
+            v = fmaf(t.lo[k][i], lo[i], v);
+            v = fmaf(t.hi[k][i], hi[i], v);
+        }
+        m[k] = v;
+    }
+    float4 *out = reinterpret_cast<float4 *>(blk + off_parent + j*kMom);
+    out[0] = make_float4(m[0], m[1], m[2], m[3]);
+    out[1] = make_float4(m[4], m[5], m[6], m[7]);
+}
+
+// Largest level whose cell, with its near edge dm grid steps from the target, is admissible:
+// (dm + h/2)^2 >= 60.84 (h^2/4 + eta^2)  <=>  14.96 h^2 - dm h - (dm^2 - 60.84 eta^2) <= 0.
+__device__ __forceinline__ int admissible_level(float dm, float eta2x)
+{
+    float const q = fmaf(dm, dm, -eta2x);
+    float const disc = fmaf(59.84f, q, dm*dm);
+    if (!(disc >= 0.f))
+    {
+        return 0;
+    }
+    float const hmax = (dm + __builtin_amdgcn_sqrtf(disc))*(0.999f/29.92f);
+    return hmax >= 2.f ? (__float_as_int(hmax) >> 23) - 127 : 0;
+}
+
+__device__ __forceinline__ float cell_series(float const *cell, float u)
+{
+    float4 const a = reinterpret_cast<float4 const *>(cell)[0], b = reinterpret_cast<float4 const *>(cell)[1];
+    float p = b.w;
+    p = fmaf(p, u, b.z); p = fmaf(p, u, b.y); p = fmaf(p, u, b.x);
+    p = fmaf(p, u, a.w); p = fmaf(p, u, a.z); p = fmaf(p, u, a.y); p = fmaf(p, u, a.x);
+    return p*(u*u);
+}
+
+// Second pass of the tree form: workgroup = (tile of grid points, layer, column); one grid point per thread
+// and turn.  cell_shift: log2 of the first pass's cell-tile size (near-field radii are per cell tile).
+__global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArgs a, long long fsteps_ll, int cell_shift, int ntab)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int const fsteps = (int)fsteps_ll;
+    double *acc = reinterpret_cast<double *>(smem);                               // [tile]
+    double *ms_l = acc + a.tile;                                                  // [num_slots][4]
+    double *q_l = ms_l + 4*a.lay.num_slots;                                       // [num_slots][GRT_MAX_ISO] (unused here)
+    int *rtab = reinterpret_cast<int *>(q_l + GRT_MAX_ISO*a.lay.num_slots);       // [ntab]
+    unsigned *loff = reinterpret_cast<unsigned *>(rtab + ntab);                   // [kMaxLevels + 1] level offsets (floats)
+    int const tid = threadIdx.x;
+    int const layer = blockIdx.y, col = blockIdx.z;
+    int const nw = (int)a.nw;
+    int const F0 = (int)blockIdx.x*a.tile;
+    int const F1 = F0 + a.tile < nw ? F0 + a.tile : nw;
+    double const *cs = a.colstate + (uint64_t)col*a.lay.stride;
+    double const *lay = cs + a.lay.off_lay + (uint64_t)layer*4;
+    double *out = a.tau + (uint64_t)col*a.tau_col_stride + (uint64_t)layer*a.nw;
+    float const *gm = a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*a.gmom_stride;
+    stage_column_state(a, cs, layer, ms_l, q_l, tid);
+    for (int i = tid; i < F1 - F0; i += kBlock)
+    {
+        acc[i] = out[F0 + i];
+    }
+    if (tid <= a.tree_levels)
+    {
+        loff[tid] = (unsigned)level_offset(a.nw, tid);
+    }
+    __syncthreads();
+    // near-field radii of the cell tiles within `halo` of this tile (level-0 cells further away are far for sure)
+    int const t0 = (F0 - a.halo > 0 ? F0 - a.halo : 0) >> cell_shift;
+    int const t1 = (F1 - 1 + a.halo < nw - 1 ? F1 - 1 + a.halo : nw - 1) >> cell_shift;
+    if (tid <= t1 - t0)
+    {
+        long long const c1 = ((long long)(t0 + tid + 1) << cell_shift);
+        bool um;
+        rtab[tid] = near_radius(a, lay, ms_l, c1 < nw ? c1 : nw, fsteps, &um);
+    }
+    __syncthreads();
+    int rmin = fsteps, rmax = 0;
+    for (int t = 0; t <= t1 - t0; ++t)
+    {
+        rmin = rtab[t] < rmin ? rtab[t] : rmin;
+        rmax = rtab[t] > rmax ? rtab[t] : rmax;
+    }
+    bool um;
+    double zmax;
+    near_radius(a, lay, ms_l, F1, fsteps, &um, &zmax);
+    float const eta2x = (float)(60.84*(zmax*zmax - 0.25))*1.0001f;
+    int const lmax = a.tree_levels;
+
+    for (int i = tid; i < F1 - F0; i += kBlock)
+    {
+        int const f = F0 + i;
+        double sum = 0.;
+        // cells above f: x = lowest level-0 cell not yet covered
+        {
+            int const e = f + fsteps < nw - 1 ? f + fsteps : nw - 1;
+            int x = f + 1 + rmin;
+            while (x <= e)
+            {
+                int const D = x - f;
+                int l = 0;
+                bool use = true;
+                if (D > rmax)
+                {
+                    int const la = __builtin_ctz(x), le = 31 - __builtin_clz(e - x + 1);
+                    int const ad = admissible_level((float)D - 0.5f, eta2x);
+                    l = min(min(la, le), min(ad, lmax));
+                }
+                else
+                {
+                    use = D > rtab[(x >> cell_shift) - t0];     // the cell's own tile decides, as in the first pass
+                }
+                if (use)
+                {
+                    float const h = __int_as_float((127 + l) << 23), rh = __int_as_float((127 - l) << 23);
+                    float const d = ((float)D - 0.5f) + 0.5f*h;                     // C - f
+                    float const u = -h*__builtin_amdgcn_rcpf(d);
+                    sum += (double)(cell_series(gm + loff[l] + (size_t)(x >> l)*kMom, u)*rh);
+                }
+                x += 1 << l;
+            }
+        }
+        // cells below f: x = highest level-0 cell not yet covered
+        {
+            int const s = f - fsteps > 0 ? f - fsteps : 0;
+            int x = f - 1 - rmin;
+            while (x >= s)
+            {
+                int const D = f - x;
+                int l = 0;
+                bool use = true;
+                if (D > rmax)
+                {
+                    int const la = __builtin_ctz(x + 1), le = 31 - __builtin_clz(x - s + 1);
+                    int const ad = admissible_level((float)D - 0.5f, eta2x);
+                    l = min(min(la, le), min(ad, lmax));
+                }
+                else
+                {
+                    use = D > rtab[(x >> cell_shift) - t0];
+                }
+                if (use)
+                {
+                    float const h = __int_as_float((127 + l) << 23), rh = __int_as_float((127 - l) << 23);
+                    float const d = ((float)D - 0.5f) + 0.5f*h;                     // f - C
+                    float const u = h*__builtin_amdgcn_rcpf(d);
+                    sum += (double)(cell_series(gm + loff[l] + (size_t)(x >> l)*kMom, u)*rh);
+                }
+                x -= 1 << l;
+            }
+        }
+        acc[i] += sum;
+    }
+    __syncthreads();
+    write_tile(a, acc, cs, col, layer, 0, (long long)F0, (long long)F1, tid);
+}
+
+size_t tree_lds_bytes(int tile, int num_slots, int ntab)
+{
+    return sizeof(double)*tile + sizeof(double)*num_slots*(4 + GRT_MAX_ISO) + sizeof(int)*((size_t)ntab + kMaxLevels + 2);
+}
+
+ShiftTable make_shift_table()
+{
+    ShiftTable t;
+    for (int k = 1; k <= kMom; ++k)
+    {
+        for (int j = 1; j <= kMom; ++j)
+        {
+            double binom = 1.;
+            for (int i = 1; i <= j; ++i)
+            {
+                binom = binom*(double)(k - j + i)/(double)i;        // C(k, j)
+            }
+            double const mag = j <= k ? binom*pow(0.25, k - j)*pow(0.5, j) : 0.;
+            t.hi[k - 1][j - 1] = (float)mag;
+            t.lo[k - 1][j - 1] = (float)(((k - j) & 1) ? -mag : mag);
+        }
+    }
+    return t;
+}
+
 size_t mp_lds_bytes(int nacc, int ncell, int fsteps, int num_slots)
 {
     return sizeof(double)*nacc + sizeof(MpQueue) + 2*sizeof(long long) + sizeof(double)*num_slots*(4 + GRT_MAX_ISO)
@@ -787,22 +1032,45 @@ int log2_exact(int v)
 } // namespace
 
 // 0 when the moment kernel does not apply to this grid (narrow windows, or a window that does not fit LDS).
-// a->fast == 3 asks about the two-pass form (cell tiles must be a power of two).
+// a->fast == 3 asks about the two-pass form (cell tiles must be a power of two); with a->tree_levels > 0 about
+// its tree form, whose first pass spans only the tile and `halo` points either side.
 extern "C" int grt_gas_optics_mp_applicable(GrtGasOpticsArgs const *a)
 {
     long long const fsteps = (long long)ceil((double)25.f/a->wres);   // kernels.c:417
-    if (fsteps < 1 || fsteps > 4096)
+    if (fsteps < 1)
+    {
+        return 0;
+    }
+    if (a->fast == 3 && a->tree_levels > 0)
+    {
+        int const shift = log2_exact(a->tile);
+        return shift >= 6 && a->gmom != NULL && a->tree_levels <= kMaxLevels && a->halo >= 3 && a->rcap <= a->halo
+               && (long long)a->halo + 4 <= fsteps && fsteps < (1ll << 30) && a->nw < (1ull << 30)
+               && ((long long)1 << a->tree_levels) <= fsteps
+               && a->gmom_stride >= level_offset(a->nw, a->tree_levels + 1)
+               && level_offset(a->nw, a->tree_levels + 1) < 0xffffffffull
+               && a->tile + 2*a->halo <= 65535
+               && mp_lds_bytes(a->tile + 2*a->halo, a->tile, 0, a->lay.num_slots) <= 64*1024
+               && tree_lds_bytes(a->tile, a->lay.num_slots, (a->tile + 2*a->halo)/a->tile + 2) <= 64*1024;
+    }
+    if (fsteps > 4096)
     {
         return 0;
     }
     if (a->fast == 3)
     {
         int const shift = log2_exact(a->tile);
-        return shift >= 6 && a->gmom != NULL
+        return shift >= 6 && a->gmom != NULL && a->gmom_stride >= (uint64_t)kMom*a->nw
                && mp_lds_bytes(a->tile + 2*(int)fsteps, a->tile, 0, a->lay.num_slots) <= 64*1024
                && far_lds_bytes(a->tile, a->tile + 2*(int)fsteps, (int)fsteps, a->lay.num_slots, shift) <= 64*1024;
     }
     return mp_lds_bytes(a->tile, a->tile + 2*(int)fsteps, (int)fsteps, a->lay.num_slots) <= 64*1024;
+}
+
+// floats per (column, layer) block of gmom that `levels` coarse levels need (the host sizes the buffer with it)
+extern "C" uint64_t grt_gas_optics_moment_floats(uint64_t nw, int levels)
+{
+    return level_offset(nw, levels + 1);
 }
 
 extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
@@ -827,36 +1095,63 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
     if (a->fast == 3)
     {
         // two passes: near fields and cell moments (every line prepared once), then the far-field gather
-        int const nacc = a->tile + 2*(int)fsteps, shift = log2_exact(a->tile);
-        if (a->ncol > 65535 || a->lay.num_layers > 65535)
+        bool const tree = a->tree_levels > 0;
+        int const halo = tree ? a->halo : (int)fsteps;
+        int const nacc = a->tile + 2*halo, shift = log2_exact(a->tile);
+        if (a->ncol > 65535 || a->lay.num_layers > 65535 || (tree && (a->nslice != 1 || a->ncol*a->lay.num_layers > 65535)))
         {
             return (int)hipErrorInvalidValue;
         }
         hipError_t e = hipMemsetAsync(a->tau, 0, sizeof(double)*a->tau_col_stride*(size_t)a->ncol, s);
         if (e == hipSuccess && a->nslice > 1)
         {
-            e = hipMemsetAsync(a->gmom, 0, sizeof(float)*(size_t)kMom*a->nw*a->lay.num_layers*a->ncol, s);
+            e = hipMemsetAsync(a->gmom, 0, sizeof(float)*a->gmom_stride*a->lay.num_layers*a->ncol, s);
         }
         if (e != hipSuccess)
         {
             return (int)e;
         }
+        GrtGasOpticsArgs b = *a;
+        b.halo = halo;
+        if (!tree)
+        {
+            b.rcap = kRcap;
+        }
         int slot = a->profile_tag ? grt_profile_begin(stream, a->profile_tag) : -1;
         hipLaunchKernelGGL(gas_optics_mp_kernel<true>, dim3((unsigned)blocks), dim3(kBlock),
-                           mp_lds_bytes(nacc, a->tile, 0, a->lay.num_slots), s, *a, fsteps, (unsigned)ngroups,
-                           golden_stride(ngroups), a->tile, nacc);
+                           mp_lds_bytes(nacc, a->tile, 0, a->lay.num_slots), s, b, fsteps, (unsigned)ngroups,
+                           golden_stride(ngroups), a->tile, nacc, halo);
         if (a->profile_tag) grt_profile_end(stream, slot);
-        GrtGasOpticsArgs b = *a;
         b.nslice = 1;
         slot = a->profile_tag ? grt_profile_begin(stream, a->profile_tag + 5) : -1;
-        hipLaunchKernelGGL(gas_optics_far_kernel, dim3((unsigned)tiles, a->lay.num_layers, a->ncol), dim3(kBlock),
-                           far_lds_bytes(a->tile, nacc, (int)fsteps, a->lay.num_slots, shift), s, b, fsteps, shift, nacc);
+        if (tree)
+        {
+            static ShiftTable const table = make_shift_table();
+            for (int l = 1; l <= a->tree_levels; ++l)
+            {
+                uint64_t const n_child = level_cells(a->nw, l - 1), n_parent = level_cells(a->nw, l);
+                hipLaunchKernelGGL(moment_up_kernel, dim3((unsigned)((n_parent + kBlock - 1)/kBlock),
+                                                          (unsigned)(a->lay.num_layers*a->ncol)), dim3(kBlock), 0, s,
+                                   a->gmom, a->gmom_stride, level_offset(a->nw, l - 1), n_child, level_offset(a->nw, l),
+                                   n_parent, table);
+            }
+            int const ntab = nacc/a->tile + 2;
+            hipLaunchKernelGGL(gas_optics_tree_kernel, dim3((unsigned)tiles, a->lay.num_layers, a->ncol), dim3(kBlock),
+                               tree_lds_bytes(a->tile, a->lay.num_slots, ntab), s, b, fsteps, shift, ntab);
+        }
+        else
+        {
+            hipLaunchKernelGGL(gas_optics_far_kernel, dim3((unsigned)tiles, a->lay.num_layers, a->ncol), dim3(kBlock),
+                               far_lds_bytes(a->tile, nacc, (int)fsteps, a->lay.num_slots, shift), s, b, fsteps, shift, nacc);
+        }
         if (a->profile_tag) grt_profile_end(stream, slot);
         return (int)hipGetLastError();
     }
     int const ncell = a->tile + 2*(int)fsteps;
     size_t const lds = mp_lds_bytes(a->tile, ncell, (int)fsteps, a->lay.num_slots);
-    hipLaunchKernelGGL(gas_optics_mp_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), lds, s, *a, fsteps,
-                       (unsigned)ngroups, golden_stride(ngroups), ncell, a->tile);
+    GrtGasOpticsArgs b = *a;
+    b.rcap = kRcap;
+    hipLaunchKernelGGL(gas_optics_mp_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), lds, s, b, fsteps,
+                       (unsigned)ngroups, golden_stride(ngroups), ncell, a->tile, 0);
     return (int)hipGetLastError();
 }

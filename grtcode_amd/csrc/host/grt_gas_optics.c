@@ -765,6 +765,15 @@ EXTERN int get_num_molecules(GasOptics_t const * const gas_optics, int * const n
     return GRTCODE_SUCCESS;
 }
 
+EXTERN int grt_gas_optics_last_launch(GasOptics_t const *gas_optics, long long info[6])
+{
+    GRT_REQUIRE_PTR(gas_optics);
+    GRT_REQUIRE_PTR(gas_optics->impl);
+    GRT_REQUIRE_PTR(info);
+    memcpy(info, impl_of(gas_optics)->last_launch, sizeof(long long)*6);
+    return GRTCODE_SUCCESS;
+}
+
 EXTERN int grt_gas_optics_tune(GasOptics_t *gas_optics, int tile, int nslice, int fast)
 {
     GRT_REQUIRE_PTR(gas_optics);
@@ -1133,6 +1142,42 @@ static void auto_tune(GasOptics_t const *go, int ncol, int moments, int *tile, i
     *nslice = ns;
 }
 
+/* Tree form of the two-pass kernel: a bound, over the batch's columns and layers, on how far from a line's
+   centre index the first pass may add to tau -- near_radius() of k_gas_optics_mp.hip with the region-1 reach
+   uncapped (the moment bound 7.8 |z|max from the largest Lorentz width any line can have in a layer; Humlicek
+   region 1, XLIM0 <= 123.4 Doppler units, at the top of the grid for the lightest molecule), plus a margin
+   for the device's exp(). */
+#define GRT_TREE_MIN_FSTEPS 512
+static int near_halo_bound(GasOptics_t const *go, int ncol, double w_top, double wres)
+{
+    GrtGasOpticsImpl const *im = impl_of(go);
+    GrtColumnLayout const *lo = &im->layout;
+    int const L = go->num_layers;
+    double worst = 3.;
+    for (int c = 0; c < ncol; ++c)
+    {
+        double const *cs = im->colstate_h + (size_t)c*lo->stride;
+        for (int i = 0; i < L; ++i)
+        {
+            double gmax = 0., dop = 0.;
+            for (int sl = 0; sl < go->num_molecules; ++sl)
+            {
+                double const *ms = cs + lo->off_ms + ((size_t)sl*L + i)*4;
+                double const g = (double)im->store.yair_max[sl]*fabs(ms[1]) + (double)im->store.yself_max[sl]*fabs(ms[0]);
+                gmax = g > gmax ? g : gmax;
+                dop = ms[3] > dop ? ms[3] : dop;
+            }
+            double const eta = gmax*exp(im->store.nmax*fabs(cs[lo->off_lay + (size_t)i*4 + 3]))/wres;
+            double const r_mp = ceil(7.8*sqrt(0.25 + eta*eta));
+            double const reach = 123.4*(0.83255461115*w_top*dop)/(0.832554611*wres) + 2.;
+            worst = r_mp > worst ? r_mp : worst;
+            worst = reach > worst ? reach : worst;
+        }
+    }
+    worst = worst*1.001 + 2.;
+    return worst < 1e9 ? (int)worst : 1000000000;
+}
+
 int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_stride, GrtGasOpticsArgs *a)
 {
     GrtGasOpticsImpl *im = impl_of(go);
@@ -1153,10 +1198,32 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
     {
         /* fused form: far wings by cell moments where the grid's windows are wide enough for that */
         auto_tune(go, ncol, im->fast == 3 ? 2 : 1, &a->tile, &a->nslice);
+        a->rcap = 12;
         if (im->fast == 3)
         {
-            /* two passes: the cells' moments travel through global memory */
-            size_t const need = sizeof(float)*8*(size_t)a->nw*(size_t)go->num_layers*(size_t)ncol;
+            /* two passes: the cells' moments travel through global memory.  Windows of more than 512 points a
+               side (grids finer than ~0.05 cm-1): far field through the cell hierarchy */
+            long long const fsteps = (long long)ceil((double)25.f/a->wres);
+            a->halo = (int)(fsteps < 0x3fffffff ? fsteps : 0x3fffffff);
+            if (fsteps > GRT_TREE_MIN_FSTEPS)
+            {
+                int levels = 0;
+                while ((4ll << (levels + 1)) <= fsteps && levels < 20)     /* cells of up to fsteps/4 points */
+                {
+                    ++levels;
+                }
+                a->tree_levels = levels;
+                a->halo = near_halo_bound(go, ncol, a->w0 + ((double)a->nw + (double)fsteps)*a->wres, a->wres);
+                a->rcap = a->halo;
+                a->nslice = 1;
+                if (im->tile == 0)
+                {
+                    a->tile = 512;      /* sparse lines (a fraction of a line per cell): wider cell tiles */
+                    while ((uint64_t)a->tile > a->nw && a->tile > 64) a->tile >>= 1;
+                }
+            }
+            a->gmom_stride = grt_gas_optics_moment_floats(a->nw, a->tree_levels);
+            size_t const need = sizeof(float)*(size_t)a->gmom_stride*(size_t)go->num_layers*(size_t)ncol;
             if (need > im->gmom_bytes)
             {
                 GRT_TRY(grt_dev_free(go->device, im->gmom));
@@ -1170,6 +1237,8 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
         if (!grt_gas_optics_mp_applicable(a))
         {
             a->fast = im->fast == 3 ? 1 : 2;
+            a->tree_levels = 0;
+            a->rcap = 12;
             if (a->fast == 1)
             {
                 auto_tune(go, ncol, 1, &a->tile, &a->nslice);
@@ -1270,6 +1339,9 @@ static int launch_columns(GasOptics_t *go, int ncol, double *tau_dev, uint64_t t
         GRT_TRY(grt_dev_zero(go->device, tau_dev, sizeof(double)*tau_col_stride*ncol, s));
     }
     int const tag = im->profile_tag ? im->profile_tag : (args.nw <= 10000 ? 1 : 2);
+    long long const info[6] = {args.fast, args.tile, args.nslice, args.tree_levels, args.fast == 3 ? args.halo : 0,
+                               args.fast == 3 ? (long long)im->gmom_bytes : 0};
+    memcpy(im->last_launch, info, sizeof(info));
     int rc;
     if (args.fast == 3)
     {

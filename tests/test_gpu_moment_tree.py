@@ -1,0 +1,117 @@
+"""The tree form of the two-pass moment kernel (fast=3 on windows of more than 512 points a side: far field through
+a hierarchy of cells, moment_up_kernel + gas_optics_tree_kernel in k_gas_optics_mp.hip) against the oracle and
+against the ring kernel (fast=2, every window point evaluated).  tests/test_moment_tree.py holds the construction
+in numpy; here every case states which part of the kernels it is there for."""
+import numpy as np
+import pytest
+
+from grtcode_amd import api, synthetic as syn
+from scenario import Band
+from test_gpu_gas_optics import tau_close
+
+pytestmark = pytest.mark.gpu
+FAST_TOL = 2e-6
+
+
+def run(band, device, col, fast, tile=0):
+    V = col["p"].size
+    go, grid = band.gas_optics(device, V, from_file=False)
+    go.tune(tile=tile, nslice=0, fast=fast)
+    band.set_column(go, col)
+    opt = api.OpticsObject(V - 1, grid, device)
+    go.calculate_optical_depth(col["p"], col["t"], opt)
+    tau = opt.read()[0]
+    info = go.last_launch()
+    opt.destroy()
+    go.destroy()
+    return tau, info
+
+
+def check(band, device, oracle, lib, col, tree=True, tile=0):
+    want = band.oracle_tau(oracle, oracle, lib, col)
+    got, info = run(band, device, col, 3, tile=tile)
+    ring, _ = run(band, device, col, 2)
+    e_tree, e_ring, e_between = tau_close(got, want), tau_close(ring, want), tau_close(got, ring)
+    print(f"{info}: tree vs oracle {e_tree:.2e}; ring vs oracle {e_ring:.2e}; tree vs ring {e_between:.2e}")
+    if tree is not None:
+        assert (info["fast"] == 3 and info["tree_levels"] > 0) == tree, info
+    assert e_tree < FAST_TOL
+    assert e_between < 5e-7
+    return info
+
+
+def test_longwave_at_0p02(tmp_path, oracle, lib, device):
+    """Windows of 1 250 points a side, eight coarse levels; near fields of a few to ~50 points."""
+    band = Band(str(tmp_path), 1000.0, 1060.0, 0.02, 2500)
+    info = check(band, device, oracle, lib, syn.profile(2, 9))
+    assert info["tree_levels"] == 8
+
+
+@pytest.mark.parametrize("tile", [0, 64, 256])
+def test_0p005_beyond_the_single_level_kernels(tmp_path, oracle, lib, device, tile):
+    """Windows of 5 000 points a side (the single-level gather stops at 4 096); Lorentz widths of up to ~20 grid
+    steps in the lowest layers, so the fine levels are skipped there and the near field is ~150 points."""
+    band = Band(str(tmp_path), 2000.0, 2030.0, 0.005, 1500)
+    info = check(band, device, oracle, lib, syn.profile(4, 7), tile=tile)
+    assert info["tree_levels"] == 10 and info["halo"] > 100
+
+
+def test_high_pressure_wide_lorentz_lines(tmp_path, oracle, lib, device):
+    """Three atmospheres at 0.01 cm-1: eta up to ~30 grid steps."""
+    band = Band(str(tmp_path), 700.0, 740.0, 0.01, 1200)
+    col = syn.profile(7, 8)
+    col["p"] = col["p"] * 3.0
+    check(band, device, oracle, lib, col)
+
+
+def test_shortwave_region1_reach_of_hundreds_of_points(tmp_path, oracle, lib, device):
+    """30 000 cm-1 at 0.02: Doppler widths of two grid steps, Humlicek region 1 reaches ~300 points -- all of it
+    inside the ring (the near-field halo is sized for it)."""
+    band = Band(str(tmp_path), 30000.0, 30050.0, 0.02, 900, sw=True, with_cfc=False)
+    info = check(band, device, oracle, lib, syn.profile(8, 7))
+    assert info["halo"] > 250
+
+
+def test_grid_shorter_than_a_window(tmp_path, oracle, lib, device):
+    """2 001 points at 0.005 cm-1: every window is clipped at both ends of the grid (kernels.c:435-437)."""
+    band = Band(str(tmp_path), 500.0, 510.0, 0.005, 800, mols=[syn.H2O, syn.CO2], with_cfc=False, with_cia=False)
+    check(band, device, oracle, lib, syn.profile(5, 6))
+
+
+def test_lines_hugging_the_grid_edges_and_beyond(tmp_path, oracle, lib, device):
+    """Centres within a few points of index 0 and n-1, and lines outside the grid whose windows reach in."""
+    band = Band(str(tmp_path), 1200.0, 1260.0, 0.02, 1500, mols=[syn.H2O, syn.CO2], with_cfc=False, with_cia=False,
+                with_ctm=False, line_range=(1190.0, 1270.0))
+    for m in band.lines:
+        v = band.lines[m]["v0"]
+        k = v.size // 4
+        v[:k] = np.round(1200.0 + (v[:k] - 1190.0) * 0.002, 6)
+        v[-k:] = np.round(1260.0 - (1270.0 - v[-k:]) * 0.002, 6)
+        band.lines[m]["v0"] = np.sort(v)
+    check(band, device, oracle, lib, syn.profile(5, 9))
+
+
+def test_near_field_wider_than_the_window_falls_back(tmp_path, oracle, lib, device):
+    """0.04 cm-1 (625 points a side) under 40 atm: the moment bound asks for a near field beyond the window, so
+    the tree form does not apply and the library falls back to the forms that treat the whole window as near."""
+    band = Band(str(tmp_path), 500.0, 560.0, 0.04, 1500)
+    col = syn.profile(3, 7)
+    col["p"] = col["p"] * 40.0
+    check(band, device, oracle, lib, col, tree=False)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_randomised_fine_grids(tmp_path, oracle, lib, device, seed):
+    rng = np.random.default_rng(777 + seed)
+    dw = float(rng.choice([0.04, 0.02, 0.01, 0.005, 0.0025]))
+    npts = int(rng.integers(1500, 9000))
+    w0 = float(np.round(rng.choice([50.0, 700.0, 2300.0, 9000.0, 20000.0]) + rng.uniform(0, 50), 2))
+    V = int(rng.integers(4, 9))
+    nlines = int(rng.integers(40, 1.2e8 / ((V - 1) * 2 * 25 / dw)))      # keeps the oracle to seconds
+    band = Band(str(tmp_path), w0, w0 + npts * dw, dw, nlines, seed=int(rng.integers(1, 10**6)), sw=w0 > 3000.0,
+                with_cfc=w0 < 3000.0)
+    col = syn.profile(int(rng.integers(0, 50)), V)
+    col["p"] = col["p"] * float(rng.choice([0.3, 1.0, 1.0, 2.5]))
+    col["t"] = np.clip(col["t"] + float(rng.uniform(-40, 30)), 150.0, 340.0)
+    # (high wavenumbers on the finest grids put region 1 beyond what the first pass holds in LDS: those fall back)
+    check(band, device, oracle, lib, col, tree=None, tile=int(rng.choice([0, 0, 128, 512])))
