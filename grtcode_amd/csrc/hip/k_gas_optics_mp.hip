@@ -242,6 +242,22 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
     bool use_moments;
     int const R = near_radius(a, lay, ms_l, F1l, fsteps, &use_moments);
 
+    // moments go to the tile's LDS block, or (tree form: ncell == 0, sparse lines, wide tiles) straight to the
+    // zeroed level-0 block in global memory
+    bool const direct = TWO_PASS && ncell == 0;
+    float *gcell = TWO_PASS ? a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*a.gmom_stride : nullptr;      // [cell][8]
+    auto mom_add = [&](int k, int cell, float v)
+    {
+        if (direct)
+        {
+            unsafeAtomicAdd(&gcell[(size_t)cell*kMom + k], v);
+        }
+        else
+        {
+            unsafeAtomicAdd(&mom[k*ncell + (cell - cell0)], v);
+        }
+    };
+
     int qcount[kClasses] = {0, 0, 0};    // wave-uniform
     auto drain = [&](int cls, int first, int count)
     {
@@ -363,7 +379,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
                 float const t = row_sum_transposed(m, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0);
                 if ((lane & 1) == 0)
                 {
-                    unsafeAtomicAdd(&mom[((lane >> 1) & 7)*ncell + (c_ref - cell0)], t);
+                    mom_add((lane >> 1) & 7, c_ref, t);
                 }
                 goto moments_done;
             }
@@ -390,7 +406,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
                 float const t = row_sum_transposed(mm, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0);
                 if (((lane & 1) == 0) & (cr != 0x7fffffff))
                 {
-                    unsafeAtomicAdd(&mom[((lane >> 1) & 7)*ncell + (cr - cell0)], t);
+                    mom_add((lane >> 1) & 7, cr, t);
                 }
                 pending = pending & !mine;
             }
@@ -399,7 +415,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
 #pragma unroll
                 for (int k = 0; k < kMom; ++k)
                 {
-                    unsafeAtomicAdd(&mom[k*ncell + (c - cell0)], m[k]);
+                    mom_add(k, c, m[k]);
                 }
             }
         }
@@ -601,8 +617,8 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
                 unsafeAtomicAdd(&out[f], acc[i]);
             }
         }
-        float *gm = a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*a.gmom_stride + (uint64_t)F0*kMom;   // [cell][8]
-        for (int i = tid; i < kMom*(F1 - F0); i += kBlock)
+        float *gm = gcell + (uint64_t)F0*kMom;
+        for (int i = tid; i < kMom*(F1 - F0) && !direct; i += kBlock)
         {
             int const cidx = i >> 3, k = i & 7;
             if (a.nslice == 1)
@@ -786,6 +802,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_far_kernel(GrtGasOpticsArgs
 // tests/test_moment_tree.py is the same construction in numpy.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kMaxLevels = 20;
+constexpr int kDirectTile = 512;    // tree form, cell tiles wider than this (sparse lines): moments added straight to global memory
 
 __host__ __device__ inline uint64_t level_cells(uint64_t nw, int l)
 {
@@ -807,6 +824,15 @@ struct ShiftTable
 {
     float lo[kMom][kMom], hi[kMom][kMom];     // [k][j]: parent m_(k+1) from the lower / upper child's m_(j+1)
 };
+
+__global__ __launch_bounds__(kBlock) void zero_level0_kernel(float *gmom, uint64_t stride, uint64_t n4)
+{
+    uint64_t const i = (uint64_t)blockIdx.x*kBlock + threadIdx.x;
+    if (i < n4)
+    {
+        reinterpret_cast<float4 *>(gmom + (uint64_t)blockIdx.y*stride)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
 
 __global__ __launch_bounds__(kBlock) void moment_up_kernel(float *gmom, uint64_t stride, uint64_t off_child, uint64_t n_child,
                                                             uint64_t off_parent, uint64_t n_parent, ShiftTable t)
@@ -1050,7 +1076,7 @@ extern "C" int grt_gas_optics_mp_applicable(GrtGasOpticsArgs const *a)
                && a->gmom_stride >= level_offset(a->nw, a->tree_levels + 1)
                && level_offset(a->nw, a->tree_levels + 1) < 0xffffffffull
                && a->tile + 2*a->halo <= 65535
-               && mp_lds_bytes(a->tile + 2*a->halo, a->tile, 0, a->lay.num_slots) <= 64*1024
+               && mp_lds_bytes(a->tile + 2*a->halo, a->tile > kDirectTile ? 0 : a->tile, 0, a->lay.num_slots) <= 64*1024
                && tree_lds_bytes(a->tile, a->lay.num_slots, (a->tile + 2*a->halo)/a->tile + 2) <= 64*1024;
     }
     if (fsteps > 4096)
@@ -1107,6 +1133,14 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
         {
             e = hipMemsetAsync(a->gmom, 0, sizeof(float)*a->gmom_stride*a->lay.num_layers*a->ncol, s);
         }
+        if (e == hipSuccess && tree && a->tile > kDirectTile)
+        {
+            // the first pass adds its moments straight to the level-0 blocks (hipMemset2DAsync runs at a fraction
+            // of the memory rate: 8 ms for the 6 GB of the 0.001 cm-1 grid)
+            hipLaunchKernelGGL(zero_level0_kernel, dim3((unsigned)((a->nw*2 + kBlock - 1)/kBlock),
+                                                        (unsigned)(a->lay.num_layers*a->ncol)), dim3(kBlock), 0, s,
+                               a->gmom, a->gmom_stride, a->nw*2);
+        }
         if (e != hipSuccess)
         {
             return (int)e;
@@ -1118,9 +1152,10 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
             b.rcap = kRcap;
         }
         int slot = a->profile_tag ? grt_profile_begin(stream, a->profile_tag) : -1;
+        int const ncell = (tree && a->tile > kDirectTile) ? 0 : a->tile;
         hipLaunchKernelGGL(gas_optics_mp_kernel<true>, dim3((unsigned)blocks), dim3(kBlock),
-                           mp_lds_bytes(nacc, a->tile, 0, a->lay.num_slots), s, b, fsteps, (unsigned)ngroups,
-                           golden_stride(ngroups), a->tile, nacc, halo);
+                           mp_lds_bytes(nacc, ncell, 0, a->lay.num_slots), s, b, fsteps, (unsigned)ngroups,
+                           golden_stride(ngroups), ncell, nacc, halo);
         if (a->profile_tag) grt_profile_end(stream, slot);
         b.nslice = 1;
         slot = a->profile_tag ? grt_profile_begin(stream, a->profile_tag + 5) : -1;

@@ -1147,7 +1147,7 @@ static void auto_tune(GasOptics_t const *go, int ncol, int moments, int *tile, i
    uncapped (the moment bound 7.8 |z|max from the largest Lorentz width any line can have in a layer; Humlicek
    region 1, XLIM0 <= 123.4 Doppler units, at the top of the grid for the lightest molecule), plus a margin
    for the device's exp(). */
-#define GRT_TREE_MIN_FSTEPS 512
+#define GRT_TREE_MIN_FSTEPS 200
 static int near_halo_bound(GasOptics_t const *go, int ncol, double w_top, double wres)
 {
     GrtGasOpticsImpl const *im = impl_of(go);
@@ -1201,11 +1201,18 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
         a->rcap = 12;
         if (im->fast == 3)
         {
-            /* two passes: the cells' moments travel through global memory.  Windows of more than 512 points a
-               side (grids finer than ~0.05 cm-1): far field through the cell hierarchy */
+            /* two passes: the cells' moments travel through global memory.  Windows of more than 200 points a
+               side (grids finer than ~0.12 cm-1; measured equal at 0.2, 8 % ahead at 0.1, 1.5x at 0.05 cm-1):
+               far field through the cell hierarchy */
             long long const fsteps = (long long)ceil((double)25.f/a->wres);
             a->halo = (int)(fsteps < 0x3fffffff ? fsteps : 0x3fffffff);
-            if (fsteps > GRT_TREE_MIN_FSTEPS)
+            static long long tree_min = -1;       /* GRT_TREE_MIN_FSTEPS in the environment: exploration only */
+            if (tree_min < 0)
+            {
+                char const *env = getenv("GRT_TREE_MIN_FSTEPS");
+                tree_min = env != NULL && atoll(env) > 0 ? atoll(env) : GRT_TREE_MIN_FSTEPS;
+            }
+            if (fsteps > tree_min)
             {
                 int levels = 0;
                 while ((4ll << (levels + 1)) <= fsteps && levels < 20)     /* cells of up to fsteps/4 points */
@@ -1218,7 +1225,11 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
                 a->nslice = 1;
                 if (im->tile == 0)
                 {
-                    a->tile = 512;      /* sparse lines (a fraction of a line per cell): wider cell tiles */
+                    /* sparse lines (a fraction of a line per cell): cell tiles wide enough to give each of a
+                       workgroup's four waves its 64 lines a few times over */
+                    uint64_t const per_line = a->lines.n > 0 ? a->nw/a->lines.n : a->nw;
+                    a->tile = 256;
+                    while ((uint64_t)a->tile < 512*per_line && a->tile < 4096) a->tile <<= 1;
                     while ((uint64_t)a->tile > a->nw && a->tile > 64) a->tile >>= 1;
                 }
             }
@@ -1233,6 +1244,11 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
                 im->gmom_bytes = need;
             }
             a->gmom = im->gmom;
+            /* the first pass keeps tile + 2*halo accumulators in LDS: narrower cell tiles where that is too much */
+            while (a->tree_levels > 0 && im->tile == 0 && a->tile > 64 && !grt_gas_optics_mp_applicable(a))
+            {
+                a->tile >>= 1;
+            }
         }
         if (!grt_gas_optics_mp_applicable(a))
         {

@@ -1,4 +1,4 @@
-"""The tree form of the two-pass moment kernel (fast=3 on windows of more than 512 points a side: far field through
+"""The tree form of the two-pass moment kernel (fast=3 on windows of more than 200 points a side: far field through
 a hierarchy of cells, moment_up_kernel + gas_optics_tree_kernel in k_gas_optics_mp.hip) against the oracle and
 against the ring kernel (fast=2, every window point evaluated).  tests/test_moment_tree.py holds the construction
 in numpy; here every case states which part of the kernels it is there for."""
