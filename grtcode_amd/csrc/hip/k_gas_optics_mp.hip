@@ -184,7 +184,9 @@ __device__ __forceinline__ void drain_class(double *acc, MpQueue const *q, int w
 // (the accumulator spans the tile and fsteps points either side) and leaves the cells' moments in global
 // memory; gas_optics_far_kernel then gathers the far field and folds in the continua.  This is what fine
 // grids want: a tile is 512 points, so at 0.1 cm-1 the one-pass form prepares every line twice.
-template <bool TWO_PASS>
+// TREE (two-pass form on fine grids): the accumulator spans the tile and `halo` < fsteps points either side -- all
+// that a near field can reach -- and the far field is left to the cell hierarchy (gas_optics_tree_kernel).
+template <bool TWO_PASS, bool TREE = false>
 __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs a, long long fsteps_ll, unsigned ngroups,
                                                                 unsigned perm_stride, int ncell, int nacc, int halo)
 {
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
 
     // moments go to the tile's LDS block, or (tree form: ncell == 0, sparse lines, wide tiles) straight to the
     // zeroed level-0 block in global memory
-    bool const direct = TWO_PASS && ncell == 0;
+    bool const direct = TREE && ncell == 0;
     float *gcell = TWO_PASS ? a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*a.gmom_stride : nullptr;      // [cell][8]
     auto mom_add = [&](int k, int cell, float v)
     {
@@ -302,8 +304,8 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
         }
         // the line's window, clipped to what the accumulator spans (two-pass form: the tile and `halo` points
         // either side -- the whole window, or, in the tree form, all that a near field can reach)
-        int const lo = valid ? (s > A0 ? s : A0) : 1;
-        int const hi = valid ? (e_i < A0 + nacc - 1 ? e_i : A0 + nacc - 1) : 0;
+        int const lo = valid ? (TREE ? (s > A0 ? s : A0) : (TWO_PASS || s > F0 ? s : F0)) : 1;
+        int const hi = valid ? (TREE ? (e_i < A0 + nacc - 1 ? e_i : A0 + nacc - 1) : (TWO_PASS || e_i < F1 - 1 ? e_i : F1 - 1)) : 0;
         double const c2 = -1.4387686f;                                                 // kernels.c:75
         double const invT = lay[2];
         // stimulated emission 1 - exp(c2 v0/T): below exp(-20) = 2e-9 the factor is 1 to fp32 and beyond
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
             // still pending after kCellLoop passes (sparse spectra: a cell per line) is added lane by lane.
             bool pending = valid;
             // (a wave spread over two dozen cells or more -- fine grids -- goes lane by lane at once)
-            bool const sparse = wave_max_s(valid ? c : (int)0x80000000) - c_ref >= 24;
+            bool const sparse = __builtin_amdgcn_readlane(c, 63 - __builtin_clzll(vmask)) - c_ref >= 24;    // (sorted lines)
             for (int pass = 0; pass < kCellLoop && !sparse && __ballot(pending) != 0ull; ++pass)
             {
                 int cr = pending ? c : 0x7fffffff;
@@ -1153,9 +1155,18 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
         }
         int slot = a->profile_tag ? grt_profile_begin(stream, a->profile_tag) : -1;
         int const ncell = (tree && a->tile > kDirectTile) ? 0 : a->tile;
-        hipLaunchKernelGGL(gas_optics_mp_kernel<true>, dim3((unsigned)blocks), dim3(kBlock),
-                           mp_lds_bytes(nacc, ncell, 0, a->lay.num_slots), s, b, fsteps, (unsigned)ngroups,
-                           golden_stride(ngroups), ncell, nacc, halo);
+        if (tree)
+        {
+            hipLaunchKernelGGL((gas_optics_mp_kernel<true, true>), dim3((unsigned)blocks), dim3(kBlock),
+                               mp_lds_bytes(nacc, ncell, 0, a->lay.num_slots), s, b, fsteps, (unsigned)ngroups,
+                               golden_stride(ngroups), ncell, nacc, halo);
+        }
+        else
+        {
+            hipLaunchKernelGGL((gas_optics_mp_kernel<true, false>), dim3((unsigned)blocks), dim3(kBlock),
+                               mp_lds_bytes(nacc, ncell, 0, a->lay.num_slots), s, b, fsteps, (unsigned)ngroups,
+                               golden_stride(ngroups), ncell, nacc, halo);
+        }
         if (a->profile_tag) grt_profile_end(stream, slot);
         b.nslice = 1;
         slot = a->profile_tag ? grt_profile_begin(stream, a->profile_tag + 5) : -1;
@@ -1186,7 +1197,7 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
     size_t const lds = mp_lds_bytes(a->tile, ncell, (int)fsteps, a->lay.num_slots);
     GrtGasOpticsArgs b = *a;
     b.rcap = kRcap;
-    hipLaunchKernelGGL(gas_optics_mp_kernel<false>, dim3((unsigned)blocks), dim3(kBlock), lds, s, b, fsteps,
+    hipLaunchKernelGGL((gas_optics_mp_kernel<false, false>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b, fsteps,
                        (unsigned)ngroups, golden_stride(ngroups), ncell, a->tile, 0);
     return (int)hipGetLastError();
 }
