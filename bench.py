@@ -115,6 +115,7 @@ def main():
                     help="3: fused form, far wings by cell moments, two passes (production); 1: the same in one pass; "
                          "2: fused form, ring kernel; 0: reference operation order")
     ap.add_argument("--tile", type=int, default=0, help="exploration only: wavenumbers (cells) per workgroup of the line kernel")
+    ap.add_argument("--lw-nslice", type=int, default=0, help="exploration only: line slices per tile of the longwave launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lw-lines", type=int, default=None)
     ap.add_argument("--sw-lines", type=int, default=None)
@@ -148,7 +149,7 @@ def main():
     lw_grid = (W.LW_GRID[0], W.LW_GRID[1], args.lw_dw or W.LW_GRID[2])
     sw_grid = (W.SW_GRID[0], W.SW_GRID[1], args.sw_dw or W.SW_GRID[2])
     wl = W.G1Workload(device, args.cols, lw_lines=args.lw_lines or W.LW_LINES,
-                      sw_lines=args.sw_lines or W.SW_LINES, fast=args.fast, lw_grid=lw_grid, sw_grid=sw_grid, tile=args.tile)
+                      sw_lines=args.sw_lines or W.SW_LINES, fast=args.fast, lw_grid=lw_grid, sw_grid=sw_grid, tile=args.tile, lw_nslice=args.lw_nslice)
     first, count = multi.shard(world * args.cols, rank, world)      # weak scaling: args.cols columns per rank
     (gcols, keep), _ = wl.columns(first, count)
     out = torch.zeros(args.cols, api.GRT_FLUXES_PER_COLUMN, dtype=torch.float64, device="cuda")

@@ -56,7 +56,7 @@ class G1Workload:
     """Both bands of the headline configuration, resident on one device."""
 
     def __init__(self, device, max_columns, lw_lines=LW_LINES, sw_lines=SW_LINES, num_levels=NUM_LEVELS,
-                 lw_grid=LW_GRID, sw_grid=SW_GRID, root=None, fast=0, tile=0):
+                 lw_grid=LW_GRID, sw_grid=SW_GRID, root=None, fast=0, tile=0, lw_nslice=0):
         self.root = root or tempfile.mkdtemp(prefix="grt_g1_")
         self.device, self.num_levels = device, num_levels
         self.lw_files, _ = write_tables(self.root, sw=False)
@@ -65,8 +65,8 @@ class G1Workload:
         self.sw_lines = band_lines(sw_lines, sw_grid, 20261004)
         self.go_lw, self.grid_lw = build_band(device, lw_grid, self.lw_lines, self.lw_files, num_levels)
         self.go_sw, self.grid_sw = build_band(device, sw_grid, self.sw_lines, self.sw_files, num_levels)
-        if fast or tile:
-            self.go_lw.tune(fast=fast, tile=tile)
+        if fast or tile or lw_nslice:
+            self.go_lw.tune(fast=fast, tile=tile, nslice=lw_nslice)
             self.go_sw.tune(fast=fast, tile=tile)
         self.emis = np.full(self.grid_lw.n, 0.98)
         self.albedo = np.full(self.grid_sw.n, 0.2)
