@@ -112,11 +112,8 @@ __device__ __forceinline__ float row_sum_transposed(float const (&m)[8], bool b3
 // Near-centre points (Humlicek regions 1-4 inside XLIM1) wait in per-wave LDS queues, one queue per
 // class of formula (voigt_class), so that a batch of 64 points runs ONE formula with all lanes busy:
 // evaluated unsorted, a batch pays for every formula present in it (~4x the work of the usual mix).
-#ifndef GRT_MPQ
-#define GRT_MPQ 96
-#endif
 constexpr int kClasses = 3;
-constexpr int kMpQueue = GRT_MPQ;    // entries per (class, wave): batches of 64 leave at most 63 behind
+constexpr int kMpQueue = 96;    // entries per (class, wave): batches of 64 leave at most 63 behind (64 and 128 measured slower)
 
 struct MpQueue
 {
@@ -263,9 +260,6 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
     int qcount[kClasses] = {0, 0, 0};    // wave-uniform
     auto drain = [&](int cls, int first, int count)
     {
-#if defined(GRT_MP_NODRAIN)
-        if (lay[0] == 12345.678)
-#endif
         {
             if (cls == 0) drain_class<0>(acc, nq, wave, first, count, lane);
             else if (cls == 1) drain_class<1>(acc, nq, wave, first, count, lane);
@@ -351,11 +345,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
         float const ndcr = -dc*repwid;
 
         // ---- moments of the Lorentzian about the cell centre ----
-#if defined(GRT_MP_NOMOM)
-        if (use_moments && amp == 12345.678)
-#else
         if (use_moments)
-#endif
         {
             float const rwr = __builtin_amdgcn_rcpf(wr);
             float const eta2 = (yq*rwr)*rwr;
@@ -434,11 +424,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
             int const r_first = (int)floorf(delta - span) + 1;      // smallest integer > delta - span
             int const r_last = (int)ceilf(delta + span) - 1;        // largest integer < delta + span
             int const count = voigt_line ? r_last - r_first + 1 : 0;
-#if defined(GRT_MP_NOPREPASS)
-            int const nmax = wave_max_s(count) > 1000000 ? 1 : 0;
-#else
             int const nmax = wave_max_s(count);
-#endif
             for (int t = 0; t < nmax; ++t)
             {
                 int const r = r_first + t;
@@ -474,11 +460,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
                             nq->repwid[q][wave][pos] = repwid;
                             // the Lorentzian this point also receives (ring: the very same instruction
                             // sequence, so it cancels exactly; moments: to ~1e-8), to be taken back
-#if defined(GRT_MP_NORING)
-                            nq->far[q][wave][pos] = 0.f*cl*__builtin_amdgcn_rcpf(fmaf(xi, xi, yq));
-#else
                             nq->far[q][wave][pos] = cl*__builtin_amdgcn_rcpf(fmaf(xi, xi, yq));
-#endif
                             nq->idx[q][wave][pos] = (unsigned short)(f - A0);
                         }
                         qcount[q] += npush;
@@ -497,11 +479,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
         // cl (1.5 XQ - 0.5 A0) / [(D0+XQ(D2+XQ)) (XQ+YQ)]   (see k_gas_optics.hip) ----
         {
             int const reach0 = voigt_line ? (int)(xlim0*rwr) + 1 : -1;
-#if defined(GRT_MP_NOPREPASS)
-            int const rmax = wave_max_s(reach0) > 1000000 ? 1 : -1;
-#else
             int const rmax = wave_max_s(reach0);
-#endif
             for (int rr = R + 1; rr <= rmax; ++rr)
             {
 #pragma unroll
@@ -575,10 +553,6 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
                 GRT_ACC_ADD(&acc[f - A0], token);
             }
         };
-#if defined(GRT_MP_NORING)
-        if (amp == 12345.678) acc[lane] = amp + cl + wr + ndcr + d0r + d2r + a0 + mid + half + xq_near + x0q;
-        if (amp == 12345.678)
-#endif
         for (int done = 0; done < span;)
         {
             int const left = span - done;                                // grid points still to cover (longest row)
@@ -636,11 +610,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
     }
     // ---- far field: every grid point of the tile gathers the moment series of the cells at
     // distance R < |f - c| <= fsteps (the cells' windows, kernels.c:435-437) ----
-#if defined(GRT_MP_NOFAR)
-    if (use_moments && lay[0] == 12345.678)
-#else
     if (use_moments)
-#endif
     {
         for (int i = tid; i < F1 - F0; i += kBlock)
         {
