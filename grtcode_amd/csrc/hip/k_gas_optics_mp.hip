@@ -802,7 +802,7 @@ __global__ __launch_bounds__(kBlock) void zero_level0_kernel(float *gmom, uint64
     uint64_t const i = (uint64_t)blockIdx.x*kBlock + threadIdx.x;
     if (i < n4)
     {
-        reinterpret_cast<float4 *>(gmom + (uint64_t)blockIdx.y*stride)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float4 *>(gmom + ((uint64_t)blockIdx.z*gridDim.y + blockIdx.y)*stride)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
@@ -814,7 +814,7 @@ __global__ __launch_bounds__(kBlock) void moment_up_kernel(float *gmom, uint64_t
     {
         return;
     }
-    float *blk = gmom + (uint64_t)blockIdx.y*stride;
+    float *blk = gmom + ((uint64_t)blockIdx.z*gridDim.y + blockIdx.y)*stride;      // block of (column z, layer y)
     float4 const *ch = reinterpret_cast<float4 const *>(blk + off_child + 2*j*kMom);
     float4 const a0 = ch[0], a1 = ch[1];
     bool const two = 2*j + 1 < n_child;
@@ -1096,7 +1096,7 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
         bool const tree = a->tree_levels > 0;
         int const halo = tree ? a->halo : (int)fsteps;
         int const nacc = a->tile + 2*halo, shift = log2_exact(a->tile);
-        if (a->ncol > 65535 || a->lay.num_layers > 65535 || (tree && (a->nslice != 1 || a->ncol*a->lay.num_layers > 65535)))
+        if (a->ncol > 65535 || a->lay.num_layers > 65535 || (tree && a->nslice != 1))
         {
             return (int)hipErrorInvalidValue;
         }
@@ -1109,8 +1109,8 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
         {
             // the first pass adds its moments straight to the level-0 blocks (hipMemset2DAsync runs at a fraction
             // of the memory rate: 8 ms for the 6 GB of the 0.001 cm-1 grid)
-            hipLaunchKernelGGL(zero_level0_kernel, dim3((unsigned)((a->nw*2 + kBlock - 1)/kBlock),
-                                                        (unsigned)(a->lay.num_layers*a->ncol)), dim3(kBlock), 0, s,
+            hipLaunchKernelGGL(zero_level0_kernel, dim3((unsigned)((a->nw*2 + kBlock - 1)/kBlock), a->lay.num_layers, a->ncol),
+                               dim3(kBlock), 0, s,
                                a->gmom, a->gmom_stride, a->nw*2);
         }
         if (e != hipSuccess)
@@ -1146,8 +1146,8 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
             for (int l = 1; l <= a->tree_levels; ++l)
             {
                 uint64_t const n_child = level_cells(a->nw, l - 1), n_parent = level_cells(a->nw, l);
-                hipLaunchKernelGGL(moment_up_kernel, dim3((unsigned)((n_parent + kBlock - 1)/kBlock),
-                                                          (unsigned)(a->lay.num_layers*a->ncol)), dim3(kBlock), 0, s,
+                hipLaunchKernelGGL(moment_up_kernel, dim3((unsigned)((n_parent + kBlock - 1)/kBlock), a->lay.num_layers, a->ncol),
+                                   dim3(kBlock), 0, s,
                                    a->gmom, a->gmom_stride, level_offset(a->nw, l - 1), n_child, level_offset(a->nw, l),
                                    n_parent, table);
             }

@@ -91,6 +91,12 @@ def test_lines_hugging_the_grid_edges_and_beyond(tmp_path, oracle, lib, device):
     check(band, device, oracle, lib, syn.profile(5, 9))
 
 
+def test_no_lines_at_all_leaves_the_continua(tmp_path, oracle, lib, device):
+    """An empty line list on a fine grid: zeroed moments, every cell series zero, tau = continua + CFC + CIA."""
+    band = Band(str(tmp_path), 900.0, 930.0, 0.02, 0)
+    check(band, device, oracle, lib, syn.profile(6, 6))
+
+
 def test_near_field_wider_than_the_window_falls_back(tmp_path, oracle, lib, device):
     """0.04 cm-1 (625 points a side) under 40 atm: the moment bound asks for a near field beyond the window, so
     the tree form does not apply and the library falls back to the forms that treat the whole window as near."""
@@ -115,3 +121,38 @@ def test_randomised_fine_grids(tmp_path, oracle, lib, device, seed):
     col["t"] = np.clip(col["t"] + float(rng.uniform(-40, 30)), 150.0, 340.0)
     # (high wavenumbers on the finest grids put region 1 beyond what the first pass holds in LDS: those fall back)
     check(band, device, oracle, lib, col, tree=None, tile=int(rng.choice([0, 0, 128, 512])))
+
+
+@pytest.mark.parametrize("dw,nlines", [(0.02, 4000), (0.005, 700)])
+def test_batched_columns_equal_single_columns(tmp_path, device, dw, nlines):
+    """grt_optical_depth_batch in the tree form (dense lines: moments through LDS; sparse lines: tiles of 1 024+ cells,
+    moments added straight to global memory): every column of a batch equals the one-column call; the halo is the
+    batch's largest (columns of very different surface pressure)."""
+    import ctypes as C
+    from scenario import MOL_ORDER
+    band = Band(str(tmp_path), 1500.0, 1530.0, dw, nlines)
+    V, ncol = 8, 3
+    cols = [syn.profile(20 + c, V) for c in range(ncol)]
+    cols[1]["p"] = cols[1]["p"] * 2.0
+    cols[2]["p"] = cols[2]["p"] * 0.4
+    go, grid = band.gas_optics(device, V, from_file=False)
+    go.tune(fast=3)
+    single, halos = [], []
+    opt = api.OpticsObject(V - 1, grid, device)
+    for col in cols:
+        band.set_column(go, col)
+        go.calculate_optical_depth(col["p"], col["t"], opt)
+        single.append(opt.read()[0])
+        halos.append(go.last_launch()["halo"])
+    opt.destroy()
+    gcols, keep = api.make_columns(cols, MOL_ORDER, cfc_order=(0, 1))
+    buf = api.DeviceBuffer(device, 8 * ncol * (V - 1) * band.nw)
+    api.check(api.load_library().grt_optical_depth_batch(C.byref(go.c), C.byref(gcols), buf.ptr))
+    info = go.last_launch()
+    batch = buf.to_host((ncol, V - 1, band.nw))
+    assert info["tree_levels"] > 0 and info["halo"] == max(halos) and len(set(halos)) > 1, (info, halos)
+    for c in range(ncol):
+        scale = single[c].max(axis=1, keepdims=True)
+        assert np.max(np.abs(batch[c] - single[c]) / scale) < 1e-9      # another halo, another order of additions
+    buf.free()
+    go.destroy()
