@@ -315,9 +315,9 @@ class GasOpticsObject:
         check(self.lib.grt_gas_optics_tune(C.byref(self.c), tile, nslice, fast))
 
     def last_launch(self):
-        info = (C.c_longlong * 6)()
+        info = (C.c_longlong * 8)()
         check(self.lib.grt_gas_optics_last_launch(C.byref(self.c), info))
-        return dict(zip(("fast", "tile", "nslice", "tree_levels", "halo", "moment_bytes"), info))
+        return dict(zip(("fast", "tile", "nslice", "tree_levels", "halo", "moment_bytes", "moments"), info))
 
     def calculate_optical_depth(self, p_mb, t, optics):
         p_mb, t = _f64(p_mb).copy(), _f64(t).copy()

@@ -82,6 +82,8 @@ typedef struct GrtGasOpticsArgs
                                  (the window's half-width, or -- tree form -- a bound on the near-field radius) */
     int rcap;                 /* widest near field taken for the sake of Humlicek region 1 */
     int tree_levels;          /* > 0: far field by the cell hierarchy (fine grids), this many coarse levels */
+    int mom_terms;            /* moments per cell: 8, or -- tree form on sparse lines -- 12 (near field 3.95 |z|max
+                                 instead of 7.8 |z|max); 0 means 8 */
     int profile_tag;          /* != 0: time the line kernel under this tag (the two-pass gather under tag + 5) */
 } GrtGasOpticsArgs;
 
@@ -92,7 +94,8 @@ void grt_profile_end(void *stream, int slot);
 /* fast == 1 only: the cell-moment kernel (k_gas_optics_mp.hip) and whether it applies to a grid */
 int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a);
 int grt_gas_optics_mp_applicable(GrtGasOpticsArgs const *a);
-uint64_t grt_gas_optics_moment_floats(uint64_t nw, int levels);   /* per (column, layer) block of gmom */
+uint64_t grt_gas_optics_moment_floats(uint64_t nw, int levels, int terms);   /* per (column, layer) block of gmom */
+double grt_gas_optics_moment_separation(int terms);   /* near field / |z|max that keeps the series' remainder at 7e-8 */
 
 /* The RFM sweep methods (k_gas_optics_sweep.hip; kernels.c:135-406,514-581).  Per molecule: `prep` holds
    vnn, snn, gamma, alpha as [4][L][n] (grt_launch_line_prep); grt_launch_sweep_sort writes them sorted by

@@ -32,6 +32,13 @@
 namespace {
 
 constexpr int kMom = 8;         // moments per cell
+constexpr int kMomWide = 12;    // ... of the tree form on sparse lines (args.mom_terms)
+
+// The series is geometric in |z|/r: K terms leave (|z|/r)^K.  Near field out to r = sep |z|max keeps that at 7e-8.
+__host__ __device__ inline double moment_separation(int terms)
+{
+    return terms == kMomWide ? 3.95 : 7.8;        // 3.95^-12 = 7e-8 = 7.8^-8
+}
 constexpr int kRcap = 12;       // widest near field taken for the sake of region 1 unless the host says otherwise (args.rcap)
 constexpr int kCellLoop = 3;    // passes of the in-register moment reduction before falling back to per-lane adds
 
@@ -129,7 +136,7 @@ struct MpQueue
 // moment series: every line has |z| <= sqrt(1/4 + eta_max^2), eta_max from the largest half-width any
 // line of the store can have in this layer (kernels.c:105-106: per molecule, the largest air- and
 // self-broadening coefficients times this layer's partial pressures); ratio |z|/(R+1) <= 0.128 keeps the
-// 8-term remainder below 1e-7 of the far-wing value.  If that asks for more than the window, the whole
+// 8-term remainder below 1e-7 of the far-wing value (0.253 with 12 terms: moment_separation).  If that asks for more than the window, the whole
 // window is "near" (R = fsteps) and no moments are formed.  ms_l: this layer's [slot][4] block in LDS.
 __device__ int near_radius(GrtGasOpticsArgs const &a, double const *lay, double const *ms_l, long long F1l, int fsteps,
                            bool *use_moments, double *zmax = nullptr)
@@ -145,7 +152,7 @@ __device__ int near_radius(GrtGasOpticsArgs const &a, double const *lay, double 
     {
         *zmax = sqrt(0.25 + eta*eta);       // every line of the layer has |z| = |delta + i eta| below this
     }
-    int const r_mp = (int)ceil(7.8*sqrt(0.25 + eta*eta)) - 1;
+    int const r_mp = (int)ceil(moment_separation(a.mom_terms)*sqrt(0.25 + eta*eta)) - 1;
     int const r_lo = r_mp < 3 ? 3 : r_mp;
     // Humlicek region 1 reaches XLIM0 <= 123.4 Doppler units from the centre: evaluate it inside the ring
     // where that is within kRcap grid steps for every line of the tile (a performance choice, not a bound
@@ -183,7 +190,7 @@ __device__ __forceinline__ void drain_class(double *acc, MpQueue const *q, int w
 // grids want: a tile is 512 points, so at 0.1 cm-1 the one-pass form prepares every line twice.
 // TREE (two-pass form on fine grids): the accumulator spans the tile and `halo` < fsteps points either side -- all
 // that a near field can reach -- and the far field is left to the cell hierarchy (gas_optics_tree_kernel).
-template <bool TWO_PASS, bool TREE = false>
+template <bool TWO_PASS, bool TREE = false, int K = kMom>
 __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs a, long long fsteps_ll, unsigned ngroups,
                                                                 unsigned perm_stride, int ncell, int nacc, int halo)
 {
@@ -249,7 +256,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
     {
         if (direct)
         {
-            unsafeAtomicAdd(&gcell[(size_t)cell*kMom + k], v);
+            unsafeAtomicAdd(&gcell[(size_t)cell*K + k], v);
         }
         else
         {
@@ -351,11 +358,11 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
             float const eta2 = (yq*rwr)*rwr;
             float const delta = dc*inv_wres_f;
             float const amp_f = valid ? (float)(amp*(double)((cl*rwr)*rwr)) : 0.f;
-            float m[kMom];
+            float m[K];
             {
                 float u = amp_f, pk = 0.f;                  // A Re z^k, A Im z^k / eta
 #pragma unroll
-                for (int k = 0; k < kMom; ++k)
+                for (int k = 0; k < K; ++k)
                 {
                     float const un = fmaf(delta, u, -eta2*pk);
                     pk = fmaf(delta, pk, u);
@@ -363,49 +370,62 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
                     m[k] = pk;
                 }
             }
-            // lines are sorted by centre: most waves sit in one cell (longwave: ~300 lines per cell)
-            unsigned long long const vmask = __ballot(valid);
-            int const c_ref = __builtin_amdgcn_readlane(c, __builtin_ctzll(vmask));
-            if (__ballot(valid & (c != c_ref)) == 0ull)
+            if constexpr (K == kMom)
             {
-                float const t = row_sum_transposed(m, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0);
-                if ((lane & 1) == 0)
+                // lines are sorted by centre: most waves sit in one cell (longwave: ~300 lines per cell)
+                unsigned long long const vmask = __ballot(valid);
+                int const c_ref = __builtin_amdgcn_readlane(c, __builtin_ctzll(vmask));
+                if (__ballot(valid & (c != c_ref)) == 0ull)
                 {
-                    mom_add((lane >> 1) & 7, c_ref, t);
+                    float const t = row_sum_transposed(m, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0);
+                    if ((lane & 1) == 0)
+                    {
+                        mom_add((lane >> 1) & 7, c_ref, t);
+                    }
+                    goto moments_done;
                 }
-                goto moments_done;
-            }
-            // Several cells in the wave: every row of 16 lanes works on ITS lowest pending cell, so one pass
-            // serves four cells at once; sorted lines rarely put more than two cells in a row.  Whatever is
-            // still pending after kCellLoop passes (sparse spectra: a cell per line) is added lane by lane.
-            bool pending = valid;
-            // (a wave spread over two dozen cells or more -- fine grids -- goes lane by lane at once)
-            bool const sparse = __builtin_amdgcn_readlane(c, 63 - __builtin_clzll(vmask)) - c_ref >= 24;    // (sorted lines)
-            for (int pass = 0; pass < kCellLoop && !sparse && __ballot(pending) != 0ull; ++pass)
-            {
-                int cr = pending ? c : 0x7fffffff;
-                cr = min(cr, dpp_i<0x121>(cr));
-                cr = min(cr, dpp_i<0x122>(cr));
-                cr = min(cr, dpp_i<0x124>(cr));
-                cr = min(cr, dpp_i<0x128>(cr));                      // the row's lowest pending cell, in every lane
-                bool const mine = pending & (c == cr);
-                float mm[kMom];
+                // Several cells in the wave: every row of 16 lanes works on ITS lowest pending cell, so one pass
+                // serves four cells at once; sorted lines rarely put more than two cells in a row.  Whatever is
+                // still pending after kCellLoop passes (sparse spectra: a cell per line) is added lane by lane.
+                bool pending = valid;
+                // (a wave spread over two dozen cells or more -- fine grids -- goes lane by lane at once)
+                bool const sparse = __builtin_amdgcn_readlane(c, 63 - __builtin_clzll(vmask)) - c_ref >= 24;    // (sorted lines)
+                for (int pass = 0; pass < kCellLoop && !sparse && __ballot(pending) != 0ull; ++pass)
+                {
+                    int cr = pending ? c : 0x7fffffff;
+                    cr = min(cr, dpp_i<0x121>(cr));
+                    cr = min(cr, dpp_i<0x122>(cr));
+                    cr = min(cr, dpp_i<0x124>(cr));
+                    cr = min(cr, dpp_i<0x128>(cr));                      // the row's lowest pending cell, in every lane
+                    bool const mine = pending & (c == cr);
+                    float mm[kMom];
+    #pragma unroll
+                    for (int k = 0; k < kMom; ++k)
+                    {
+                        mm[k] = mine ? m[k] : 0.f;
+                    }
+                    float const t = row_sum_transposed(mm, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0);
+                    if (((lane & 1) == 0) & (cr != 0x7fffffff))
+                    {
+                        mom_add((lane >> 1) & 7, cr, t);
+                    }
+                    pending = pending & !mine;
+                }
+                if (pending)
+                {
 #pragma unroll
-                for (int k = 0; k < kMom; ++k)
-                {
-                    mm[k] = mine ? m[k] : 0.f;
+                    for (int k = 0; k < kMom; ++k)
+                    {
+                        mom_add(k, c, m[k]);
+                    }
                 }
-                float const t = row_sum_transposed(mm, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0);
-                if (((lane & 1) == 0) & (cr != 0x7fffffff))
-                {
-                    mom_add((lane >> 1) & 7, cr, t);
-                }
-                pending = pending & !mine;
             }
-            if (pending)
+            else if (valid)
             {
+                // twelve moments: only on sparse lines (tiles of 1 024 cells and more), where a wave's 64 lines sit
+                // in dozens of cells -- lane by lane
 #pragma unroll
-                for (int k = 0; k < kMom; ++k)
+                for (int k = 0; k < K; ++k)
                 {
                     mom_add(k, c, m[k]);
                 }
@@ -524,9 +544,13 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
         // at 1 cm-1, R = 3): slots s and s + 8 of a row stand for the same grid point and start half a row
         // apart, so after eight steps the two tokens of a grid point have together met all 16 lines.
         // PERIOD 4 likewise with four tokens per grid point: spans are covered in pieces of 16, 8 and 4.
-        auto ring_block = [&](int fbp, auto period_tag)
+        // MODE 0: general.  MODE 1 (tree form, near fields of hundreds of points): a block that lies inside the
+        // near field of every line of the wave needs no range test; MODE 2: nor, beyond every line's region 1,
+        // anything but the Lorentzian.
+        auto ring_block = [&](int fbp, auto period_tag, auto mode_tag)
         {
             constexpr int PERIOD = decltype(period_tag)::value;
+            constexpr int MODE = decltype(mode_tag)::value;
             double token = 0.;
             float slotf = (float)(lane & (PERIOD - 1));
             float const base_rel = (float)(fbp - c);
@@ -537,11 +561,19 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
                 float const xi = fmaf(rel, wr, ndcr);
                 float const xq = xi*xi;
                 float const d = fmaf(xi, xi, yq);
-                // region 1 (RFM_voigt.c:172-183): K = c (A0+XQ)/(D0+XQ(D2+XQ)); elsewhere the Lorentzian
-                bool const reg1 = (xq >= xq_near) & (xq < x0q);
-                float const den = reg1 ? fmaf(xq, d2r + xq, d0r) : d;
-                float const num = reg1 ? cl*(a0 + xq) : cl;
-                float kf = (fabsf(rel - mid) <= half) ? num*__builtin_amdgcn_rcpf(den) : 0.f;
+                float kf;
+                if (MODE == 2)
+                {
+                    kf = cl*__builtin_amdgcn_rcpf(d);
+                }
+                else
+                {
+                    // region 1 (RFM_voigt.c:172-183): K = c (A0+XQ)/(D0+XQ(D2+XQ)); elsewhere the Lorentzian
+                    bool const reg1 = (xq >= xq_near) & (xq < x0q);
+                    float const den = reg1 ? fmaf(xq, d2r + xq, d0r) : d;
+                    float const num = reg1 ? cl*(a0 + xq) : cl;
+                    kf = (MODE == 1 || fabsf(rel - mid) <= half) ? num*__builtin_amdgcn_rcpf(den) : 0.f;
+                }
                 asm volatile("" : "+v"(kf));        // select in fp32, then widen once
                 token = fma(amp, (double)kf, token);
                 token = row_pass(token);
@@ -553,22 +585,47 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
                 GRT_ACC_ADD(&acc[f - A0], token);
             }
         };
+        std::integral_constant<int, 0> const general{};
+        // the distance from the centre index within which a line has region-1 points (none: pure Lorentz line)
+        float const reach1 = (valid & !lorentz) ? fmaf(xlim0, rwr, 1.5f) : -1e30f;
         for (int done = 0; done < span;)
         {
             int const left = span - done;                                // grid points still to cover (longest row)
             if (left <= 4)
             {
-                ring_block(fb + done, std::integral_constant<int, 4>{}); // four tokens per grid point, four steps
+                ring_block(fb + done, std::integral_constant<int, 4>{}, general);   // four tokens per grid point, four steps
                 done += 4;
             }
             else if (left <= 12)
             {
-                ring_block(fb + done, std::integral_constant<int, 8>{}); // 8, or 8 + 4 rather than 16
+                ring_block(fb + done, std::integral_constant<int, 8>{}, general);   // 8, or 8 + 4 rather than 16
                 done += 8;
             }
             else
             {
-                ring_block(fb + done, std::integral_constant<int, 16>{});
+                int const fbp = fb + done;
+                if (TREE && span >= 128)
+                {
+                    bool const inside = (fbp >= lo_n) & (fbp + 15 <= hi_n);
+                    float const r0 = (float)(fbp - c);
+                    bool const reg1_here = (r0 + 15.f > -reach1) & (r0 < reach1);
+                    if (__ballot(valid & !inside) != 0ull)
+                    {
+                        ring_block(fbp, std::integral_constant<int, 16>{}, general);
+                    }
+                    else if (__ballot(valid & reg1_here) != 0ull)
+                    {
+                        ring_block(fbp, std::integral_constant<int, 16>{}, std::integral_constant<int, 1>{});
+                    }
+                    else
+                    {
+                        ring_block(fbp, std::integral_constant<int, 16>{}, std::integral_constant<int, 2>{});
+                    }
+                }
+                else
+                {
+                    ring_block(fbp, std::integral_constant<int, 16>{}, general);
+                }
                 done += 16;
             }
         }
@@ -781,20 +838,21 @@ __host__ __device__ inline uint64_t level_cells(uint64_t nw, int l)
     return (nw + ((uint64_t)1 << l) - 1) >> l;
 }
 
-// floats per (column, layer) block of gmom: levels 0..levels
-__host__ __device__ inline uint64_t level_offset(uint64_t nw, int l)
+// offset of level l in the (column, layer) block of gmom, floats; `terms` moments per cell
+__host__ __device__ inline uint64_t level_offset(uint64_t nw, int l, int terms)
 {
     uint64_t off = 0;
     for (int i = 0; i < l; ++i)
     {
-        off += level_cells(nw, i)*kMom;
+        off += level_cells(nw, i)*terms;
     }
     return off;
 }
 
+template <int K>
 struct ShiftTable
 {
-    float lo[kMom][kMom], hi[kMom][kMom];     // [k][j]: parent m_(k+1) from the lower / upper child's m_(j+1)
+    float lo[K][K], hi[K][K];     // [k][j]: parent m_(k+1) from the lower / upper child's m_(j+1)
 };
 
 __global__ __launch_bounds__(kBlock) void zero_level0_kernel(float *gmom, uint64_t stride, uint64_t n4)
@@ -806,8 +864,9 @@ __global__ __launch_bounds__(kBlock) void zero_level0_kernel(float *gmom, uint64
     }
 }
 
+template <int K>
 __global__ __launch_bounds__(kBlock) void moment_up_kernel(float *gmom, uint64_t stride, uint64_t off_child, uint64_t n_child,
-                                                            uint64_t off_parent, uint64_t n_parent, ShiftTable t)
+                                                            uint64_t off_parent, uint64_t n_parent, ShiftTable<K> t)
 {
     uint64_t const j = (uint64_t)blockIdx.x*kBlock + threadIdx.x;
     if (j >= n_parent)
@@ -815,16 +874,20 @@ __global__ __launch_bounds__(kBlock) void moment_up_kernel(float *gmom, uint64_t
         return;
     }
     float *blk = gmom + ((uint64_t)blockIdx.z*gridDim.y + blockIdx.y)*stride;      // block of (column z, layer y)
-    float4 const *ch = reinterpret_cast<float4 const *>(blk + off_child + 2*j*kMom);
-    float4 const a0 = ch[0], a1 = ch[1];
+    float4 const *ch = reinterpret_cast<float4 const *>(blk + off_child + 2*j*K);
     bool const two = 2*j + 1 < n_child;
-    float4 const zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 const b0 = two ? ch[2] : zero, b1 = two ? ch[3] : zero;
-    float const lo[kMom] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-    float const hi[kMom] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-    float m[kMom];
+    float lo[K], hi[K];
 #pragma unroll
-    for (int k = 0; k < kMom; ++k)
+    for (int q = 0; q < K/4; ++q)
+    {
+        float4 const a = ch[q];
+        float4 const b = two ? ch[K/4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        lo[4*q] = a.x; lo[4*q + 1] = a.y; lo[4*q + 2] = a.z; lo[4*q + 3] = a.w;
+        hi[4*q] = b.x; hi[4*q + 1] = b.y; hi[4*q + 2] = b.z; hi[4*q + 3] = b.w;
+    }
+    float m[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
     {
         float v = 0.f;
 #pragma unroll
@@ -835,36 +898,48 @@ __global__ __launch_bounds__(kBlock) void moment_up_kernel(float *gmom, uint64_t
         }
         m[k] = v;
     }
-    float4 *out = reinterpret_cast<float4 *>(blk + off_parent + j*kMom);
-    out[0] = make_float4(m[0], m[1], m[2], m[3]);
-    out[1] = make_float4(m[4], m[5], m[6], m[7]);
+    float4 *out = reinterpret_cast<float4 *>(blk + off_parent + j*K);
+#pragma unroll
+    for (int q = 0; q < K/4; ++q)
+    {
+        out[q] = make_float4(m[4*q], m[4*q + 1], m[4*q + 2], m[4*q + 3]);
+    }
 }
 
 // Largest level whose cell, with its near edge dm grid steps from the target, is admissible:
-// (dm + h/2)^2 >= 60.84 (h^2/4 + eta^2)  <=>  14.96 h^2 - dm h - (dm^2 - 60.84 eta^2) <= 0.
-__device__ __forceinline__ int admissible_level(float dm, float eta2x)
+// (dm + h/2)^2 >= sep^2 (h^2/4 + eta^2)  <=>  a h^2 - dm h - (dm^2 - sep^2 eta^2) <= 0,  a = (sep^2 - 1)/4.
+// eta2x = sep^2 eta^2, a4 = 4 a, r2a = 0.999/(2 a).
+__device__ __forceinline__ int admissible_level(float dm, float eta2x, float a4, float r2a)
 {
     float const q = fmaf(dm, dm, -eta2x);
-    float const disc = fmaf(59.84f, q, dm*dm);
+    float const disc = fmaf(a4, q, dm*dm);
     if (!(disc >= 0.f))
     {
         return 0;
     }
-    float const hmax = (dm + __builtin_amdgcn_sqrtf(disc))*(0.999f/29.92f);
+    float const hmax = (dm + __builtin_amdgcn_sqrtf(disc))*r2a;
     return hmax >= 2.f ? (__float_as_int(hmax) >> 23) - 127 : 0;
 }
 
+template <int K>
 __device__ __forceinline__ float cell_series(float const *cell, float u)
 {
-    float4 const a = reinterpret_cast<float4 const *>(cell)[0], b = reinterpret_cast<float4 const *>(cell)[1];
-    float p = b.w;
-    p = fmaf(p, u, b.z); p = fmaf(p, u, b.y); p = fmaf(p, u, b.x);
-    p = fmaf(p, u, a.w); p = fmaf(p, u, a.z); p = fmaf(p, u, a.y); p = fmaf(p, u, a.x);
+    float4 const *c4 = reinterpret_cast<float4 const *>(cell);
+    float4 v = c4[K/4 - 1];
+    float p = v.w;
+    p = fmaf(p, u, v.z); p = fmaf(p, u, v.y); p = fmaf(p, u, v.x);
+#pragma unroll
+    for (int q = K/4 - 2; q >= 0; --q)
+    {
+        v = c4[q];
+        p = fmaf(p, u, v.w); p = fmaf(p, u, v.z); p = fmaf(p, u, v.y); p = fmaf(p, u, v.x);
+    }
     return p*(u*u);
 }
 
 // Second pass of the tree form: workgroup = (tile of grid points, layer, column); one grid point per thread
 // and turn.  cell_shift: log2 of the first pass's cell-tile size (near-field radii are per cell tile).
+template <int K>
 __global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArgs a, long long fsteps_ll, int cell_shift, int ntab)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -890,7 +965,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArg
     }
     if (tid <= a.tree_levels)
     {
-        loff[tid] = (unsigned)level_offset(a.nw, tid);
+        loff[tid] = (unsigned)level_offset(a.nw, tid, K);
     }
     __syncthreads();
     // near-field radii of the cell tiles within `halo` of this tile (level-0 cells further away are far for sure)
@@ -912,7 +987,9 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArg
     bool um;
     double zmax;
     near_radius(a, lay, ms_l, F1, fsteps, &um, &zmax);
-    float const eta2x = (float)(60.84*(zmax*zmax - 0.25))*1.0001f;
+    double const sep = moment_separation(K);
+    float const eta2x = (float)(sep*sep*(zmax*zmax - 0.25))*1.0001f;
+    float const a4 = (float)(sep*sep - 1.), r2a = (float)(0.999*2./(sep*sep - 1.));
     int const lmax = a.tree_levels;
 
     for (int i = tid; i < F1 - F0; i += kBlock)
@@ -931,7 +1008,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArg
                 if (D > rmax)
                 {
                     int const la = __builtin_ctz(x), le = 31 - __builtin_clz(e - x + 1);
-                    int const ad = admissible_level((float)D - 0.5f, eta2x);
+                    int const ad = admissible_level((float)D - 0.5f, eta2x, a4, r2a);
                     l = min(min(la, le), min(ad, lmax));
                 }
                 else
@@ -943,7 +1020,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArg
                     float const h = __int_as_float((127 + l) << 23), rh = __int_as_float((127 - l) << 23);
                     float const d = ((float)D - 0.5f) + 0.5f*h;                     // C - f
                     float const u = -h*__builtin_amdgcn_rcpf(d);
-                    sum += (double)(cell_series(gm + loff[l] + (size_t)(x >> l)*kMom, u)*rh);
+                    sum += (double)(cell_series<K>(gm + loff[l] + (size_t)(x >> l)*K, u)*rh);
                 }
                 x += 1 << l;
             }
@@ -960,7 +1037,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArg
                 if (D > rmax)
                 {
                     int const la = __builtin_ctz(x + 1), le = 31 - __builtin_clz(x - s + 1);
-                    int const ad = admissible_level((float)D - 0.5f, eta2x);
+                    int const ad = admissible_level((float)D - 0.5f, eta2x, a4, r2a);
                     l = min(min(la, le), min(ad, lmax));
                 }
                 else
@@ -972,7 +1049,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArg
                     float const h = __int_as_float((127 + l) << 23), rh = __int_as_float((127 - l) << 23);
                     float const d = ((float)D - 0.5f) + 0.5f*h;                     // f - C
                     float const u = h*__builtin_amdgcn_rcpf(d);
-                    sum += (double)(cell_series(gm + loff[l] + (size_t)(x >> l)*kMom, u)*rh);
+                    sum += (double)(cell_series<K>(gm + loff[l] + (size_t)(x >> l)*K, u)*rh);
                 }
                 x -= 1 << l;
             }
@@ -988,12 +1065,13 @@ size_t tree_lds_bytes(int tile, int num_slots, int ntab)
     return sizeof(double)*tile + sizeof(double)*num_slots*(4 + GRT_MAX_ISO) + sizeof(int)*((size_t)ntab + kMaxLevels + 2);
 }
 
-ShiftTable make_shift_table()
+template <int K>
+ShiftTable<K> make_shift_table()
 {
-    ShiftTable t;
-    for (int k = 1; k <= kMom; ++k)
+    ShiftTable<K> t;
+    for (int k = 1; k <= K; ++k)
     {
-        for (int j = 1; j <= kMom; ++j)
+        for (int j = 1; j <= K; ++j)
         {
             double binom = 1.;
             for (int i = 1; i <= j; ++i)
@@ -1006,6 +1084,22 @@ ShiftTable make_shift_table()
         }
     }
     return t;
+}
+
+// the coarse levels, one launch per level, then the gather
+template <int K>
+void launch_tree(hipStream_t s, GrtGasOpticsArgs const &b, long long fsteps, int shift, int ntab, unsigned tiles)
+{
+    static ShiftTable<K> const table = make_shift_table<K>();
+    for (int l = 1; l <= b.tree_levels; ++l)
+    {
+        uint64_t const n_child = level_cells(b.nw, l - 1), n_parent = level_cells(b.nw, l);
+        hipLaunchKernelGGL(moment_up_kernel<K>, dim3((unsigned)((n_parent + kBlock - 1)/kBlock), b.lay.num_layers, b.ncol),
+                           dim3(kBlock), 0, s, b.gmom, b.gmom_stride, level_offset(b.nw, l - 1, K), n_child,
+                           level_offset(b.nw, l, K), n_parent, table);
+    }
+    hipLaunchKernelGGL(gas_optics_tree_kernel<K>, dim3(tiles, b.lay.num_layers, b.ncol), dim3(kBlock),
+                       tree_lds_bytes(b.tile, b.lay.num_slots, ntab), s, b, fsteps, shift, ntab);
 }
 
 size_t mp_lds_bytes(int nacc, int ncell, int fsteps, int num_slots)
@@ -1042,16 +1136,23 @@ extern "C" int grt_gas_optics_mp_applicable(GrtGasOpticsArgs const *a)
     if (a->fast == 3 && a->tree_levels > 0)
     {
         int const shift = log2_exact(a->tile);
+        int const terms = a->mom_terms == 0 ? kMom : a->mom_terms;
+        bool const direct = a->tile > kDirectTile;
         return shift >= 6 && a->gmom != NULL && a->tree_levels <= kMaxLevels && a->halo >= 3 && a->rcap <= a->halo
+               && (terms == kMom || (terms == kMomWide && direct))
                && (long long)a->halo + 4 <= fsteps && fsteps < (1ll << 30) && a->nw < (1ull << 30)
                && ((long long)1 << a->tree_levels) <= fsteps
-               && a->gmom_stride >= level_offset(a->nw, a->tree_levels + 1)
-               && level_offset(a->nw, a->tree_levels + 1) < 0xffffffffull
+               && a->gmom_stride >= level_offset(a->nw, a->tree_levels + 1, terms)
+               && level_offset(a->nw, a->tree_levels + 1, terms) < 0xffffffffull
                && a->tile + 2*a->halo <= 65535
-               && mp_lds_bytes(a->tile + 2*a->halo, a->tile > kDirectTile ? 0 : a->tile, 0, a->lay.num_slots) <= 64*1024
+               && mp_lds_bytes(a->tile + 2*a->halo, direct ? 0 : a->tile, 0, a->lay.num_slots) <= 64*1024
                && tree_lds_bytes(a->tile, a->lay.num_slots, (a->tile + 2*a->halo)/a->tile + 2) <= 64*1024;
     }
     if (fsteps > 4096)
+    {
+        return 0;
+    }
+    if (a->mom_terms != 0 && a->mom_terms != kMom)
     {
         return 0;
     }
@@ -1066,9 +1167,14 @@ extern "C" int grt_gas_optics_mp_applicable(GrtGasOpticsArgs const *a)
 }
 
 // floats per (column, layer) block of gmom that `levels` coarse levels need (the host sizes the buffer with it)
-extern "C" uint64_t grt_gas_optics_moment_floats(uint64_t nw, int levels)
+extern "C" uint64_t grt_gas_optics_moment_floats(uint64_t nw, int levels, int terms)
 {
-    return level_offset(nw, levels + 1);
+    return level_offset(nw, levels + 1, terms == 0 ? kMom : terms);
+}
+
+extern "C" double grt_gas_optics_moment_separation(int terms)
+{
+    return moment_separation(terms);
 }
 
 extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
@@ -1105,13 +1211,14 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
         {
             e = hipMemsetAsync(a->gmom, 0, sizeof(float)*a->gmom_stride*a->lay.num_layers*a->ncol, s);
         }
+        bool const wide = tree && a->mom_terms == kMomWide;
         if (e == hipSuccess && tree && a->tile > kDirectTile)
         {
             // the first pass adds its moments straight to the level-0 blocks (hipMemset2DAsync runs at a fraction
             // of the memory rate: 8 ms for the 6 GB of the 0.001 cm-1 grid)
-            hipLaunchKernelGGL(zero_level0_kernel, dim3((unsigned)((a->nw*2 + kBlock - 1)/kBlock), a->lay.num_layers, a->ncol),
-                               dim3(kBlock), 0, s,
-                               a->gmom, a->gmom_stride, a->nw*2);
+            uint64_t const n4 = a->nw*(wide ? kMomWide : kMom)/4;
+            hipLaunchKernelGGL(zero_level0_kernel, dim3((unsigned)((n4 + kBlock - 1)/kBlock), a->lay.num_layers, a->ncol),
+                               dim3(kBlock), 0, s, a->gmom, a->gmom_stride, n4);
         }
         if (e != hipSuccess)
         {
@@ -1119,41 +1226,43 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
         }
         GrtGasOpticsArgs b = *a;
         b.halo = halo;
+        b.mom_terms = wide ? kMomWide : kMom;
         if (!tree)
         {
             b.rcap = kRcap;
         }
         int slot = a->profile_tag ? grt_profile_begin(stream, a->profile_tag) : -1;
         int const ncell = (tree && a->tile > kDirectTile) ? 0 : a->tile;
-        if (tree)
+        size_t const lds = mp_lds_bytes(nacc, ncell, 0, a->lay.num_slots);
+        if (wide)
         {
-            hipLaunchKernelGGL((gas_optics_mp_kernel<true, true>), dim3((unsigned)blocks), dim3(kBlock),
-                               mp_lds_bytes(nacc, ncell, 0, a->lay.num_slots), s, b, fsteps, (unsigned)ngroups,
-                               golden_stride(ngroups), ncell, nacc, halo);
+            hipLaunchKernelGGL((gas_optics_mp_kernel<true, true, kMomWide>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
+                               fsteps, (unsigned)ngroups, golden_stride(ngroups), ncell, nacc, halo);
+        }
+        else if (tree)
+        {
+            hipLaunchKernelGGL((gas_optics_mp_kernel<true, true, kMom>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
+                               fsteps, (unsigned)ngroups, golden_stride(ngroups), ncell, nacc, halo);
         }
         else
         {
-            hipLaunchKernelGGL((gas_optics_mp_kernel<true, false>), dim3((unsigned)blocks), dim3(kBlock),
-                               mp_lds_bytes(nacc, ncell, 0, a->lay.num_slots), s, b, fsteps, (unsigned)ngroups,
-                               golden_stride(ngroups), ncell, nacc, halo);
+            hipLaunchKernelGGL((gas_optics_mp_kernel<true, false, kMom>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
+                               fsteps, (unsigned)ngroups, golden_stride(ngroups), ncell, nacc, halo);
         }
         if (a->profile_tag) grt_profile_end(stream, slot);
         b.nslice = 1;
         slot = a->profile_tag ? grt_profile_begin(stream, a->profile_tag + 5) : -1;
         if (tree)
         {
-            static ShiftTable const table = make_shift_table();
-            for (int l = 1; l <= a->tree_levels; ++l)
-            {
-                uint64_t const n_child = level_cells(a->nw, l - 1), n_parent = level_cells(a->nw, l);
-                hipLaunchKernelGGL(moment_up_kernel, dim3((unsigned)((n_parent + kBlock - 1)/kBlock), a->lay.num_layers, a->ncol),
-                                   dim3(kBlock), 0, s,
-                                   a->gmom, a->gmom_stride, level_offset(a->nw, l - 1), n_child, level_offset(a->nw, l),
-                                   n_parent, table);
-            }
             int const ntab = nacc/a->tile + 2;
-            hipLaunchKernelGGL(gas_optics_tree_kernel, dim3((unsigned)tiles, a->lay.num_layers, a->ncol), dim3(kBlock),
-                               tree_lds_bytes(a->tile, a->lay.num_slots, ntab), s, b, fsteps, shift, ntab);
+            if (wide)
+            {
+                launch_tree<kMomWide>(s, b, fsteps, shift, ntab, (unsigned)tiles);
+            }
+            else
+            {
+                launch_tree<kMom>(s, b, fsteps, shift, ntab, (unsigned)tiles);
+            }
         }
         else
         {

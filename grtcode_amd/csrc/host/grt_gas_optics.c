@@ -765,12 +765,12 @@ EXTERN int get_num_molecules(GasOptics_t const * const gas_optics, int * const n
     return GRTCODE_SUCCESS;
 }
 
-EXTERN int grt_gas_optics_last_launch(GasOptics_t const *gas_optics, long long info[6])
+EXTERN int grt_gas_optics_last_launch(GasOptics_t const *gas_optics, long long info[8])
 {
     GRT_REQUIRE_PTR(gas_optics);
     GRT_REQUIRE_PTR(gas_optics->impl);
     GRT_REQUIRE_PTR(info);
-    memcpy(info, impl_of(gas_optics)->last_launch, sizeof(long long)*6);
+    memcpy(info, impl_of(gas_optics)->last_launch, sizeof(long long)*8);
     return GRTCODE_SUCCESS;
 }
 
@@ -1144,11 +1144,11 @@ static void auto_tune(GasOptics_t const *go, int ncol, int moments, int *tile, i
 
 /* Tree form of the two-pass kernel: a bound, over the batch's columns and layers, on how far from a line's
    centre index the first pass may add to tau -- near_radius() of k_gas_optics_mp.hip with the region-1 reach
-   uncapped (the moment bound 7.8 |z|max from the largest Lorentz width any line can have in a layer; Humlicek
+   uncapped (the moment bound sep |z|max from the largest Lorentz width any line can have in a layer; Humlicek
    region 1, XLIM0 <= 123.4 Doppler units, at the top of the grid for the lightest molecule), plus a margin
    for the device's exp(). */
 #define GRT_TREE_MIN_FSTEPS 200
-static int near_halo_bound(GasOptics_t const *go, int ncol, double w_top, double wres)
+static int near_halo_bound(GasOptics_t const *go, int ncol, double w_top, double wres, double sep)
 {
     GrtGasOpticsImpl const *im = impl_of(go);
     GrtColumnLayout const *lo = &im->layout;
@@ -1168,7 +1168,7 @@ static int near_halo_bound(GasOptics_t const *go, int ncol, double w_top, double
                 dop = ms[3] > dop ? ms[3] : dop;
             }
             double const eta = gmax*exp(im->store.nmax*fabs(cs[lo->off_lay + (size_t)i*4 + 3]))/wres;
-            double const r_mp = ceil(7.8*sqrt(0.25 + eta*eta));
+            double const r_mp = ceil(sep*sqrt(0.25 + eta*eta));
             double const reach = 123.4*(0.83255461115*w_top*dop)/(0.832554611*wres) + 2.;
             worst = r_mp > worst ? r_mp : worst;
             worst = reach > worst ? reach : worst;
@@ -1220,9 +1220,8 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
                     ++levels;
                 }
                 a->tree_levels = levels;
-                a->halo = near_halo_bound(go, ncol, a->w0 + ((double)a->nw + (double)fsteps)*a->wres, a->wres);
-                a->rcap = a->halo;
                 a->nslice = 1;
+                double const w_top = a->w0 + ((double)a->nw + (double)fsteps)*a->wres;
                 if (im->tile == 0)
                 {
                     /* sparse lines (a fraction of a line per cell): cell tiles wide enough to give each of a
@@ -1232,28 +1231,48 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
                     while ((uint64_t)a->tile < 512*per_line && a->tile < 4096) a->tile <<= 1;
                     while ((uint64_t)a->tile > a->nw && a->tile > 64) a->tile >>= 1;
                 }
+                /* tiles of more than 512 cells add their moments straight to global memory, lane by lane, and
+                   afford twelve of them: half the near field in the pressure-broadened layers.  The first pass
+                   keeps tile + 2*halo accumulators in LDS: narrower cell tiles where that is too much. */
+                for (;;)
+                {
+                    a->mom_terms = a->tile > 512 ? 12 : 8;
+                    a->halo = near_halo_bound(go, ncol, w_top, a->wres, grt_gas_optics_moment_separation(a->mom_terms));
+                    a->rcap = a->halo;
+                    a->gmom_stride = grt_gas_optics_moment_floats(a->nw, a->tree_levels, a->mom_terms);
+                    a->gmom = (float *)8;       /* (any non-null value: the question is about sizes) */
+                    if (im->tile != 0 || a->tile <= 64 || grt_gas_optics_mp_applicable(a))
+                    {
+                        break;
+                    }
+                    a->tile >>= 1;
+                }
             }
-            a->gmom_stride = grt_gas_optics_moment_floats(a->nw, a->tree_levels);
-            size_t const need = sizeof(float)*(size_t)a->gmom_stride*(size_t)go->num_layers*(size_t)ncol;
-            if (need > im->gmom_bytes)
+            a->gmom_stride = grt_gas_optics_moment_floats(a->nw, a->tree_levels, a->mom_terms);
+            a->gmom = (float *)8;
+            if (grt_gas_optics_mp_applicable(a))
             {
-                GRT_TRY(grt_dev_free(go->device, im->gmom));
-                im->gmom = NULL;
-                im->gmom_bytes = 0;
-                GRT_TRY(grt_dev_alloc(go->device, (void **)&im->gmom, need));
-                im->gmom_bytes = need;
+                size_t const need = sizeof(float)*(size_t)a->gmom_stride*(size_t)go->num_layers*(size_t)ncol;
+                if (need > im->gmom_bytes)
+                {
+                    GRT_TRY(grt_dev_free(go->device, im->gmom));
+                    im->gmom = NULL;
+                    im->gmom_bytes = 0;
+                    GRT_TRY(grt_dev_alloc(go->device, (void **)&im->gmom, need));
+                    im->gmom_bytes = need;
+                }
+                a->gmom = im->gmom;
             }
-            a->gmom = im->gmom;
-            /* the first pass keeps tile + 2*halo accumulators in LDS: narrower cell tiles where that is too much */
-            while (a->tree_levels > 0 && im->tile == 0 && a->tile > 64 && !grt_gas_optics_mp_applicable(a))
+            else
             {
-                a->tile >>= 1;
+                a->gmom = NULL;
             }
         }
         if (!grt_gas_optics_mp_applicable(a))
         {
             a->fast = im->fast == 3 ? 1 : 2;
             a->tree_levels = 0;
+            a->mom_terms = 0;
             a->rcap = 12;
             if (a->fast == 1)
             {
@@ -1355,8 +1374,9 @@ static int launch_columns(GasOptics_t *go, int ncol, double *tau_dev, uint64_t t
         GRT_TRY(grt_dev_zero(go->device, tau_dev, sizeof(double)*tau_col_stride*ncol, s));
     }
     int const tag = im->profile_tag ? im->profile_tag : (args.nw <= 10000 ? 1 : 2);
-    long long const info[6] = {args.fast, args.tile, args.nslice, args.tree_levels, args.fast == 3 ? args.halo : 0,
-                               args.fast == 3 ? (long long)im->gmom_bytes : 0};
+    long long const info[8] = {args.fast, args.tile, args.nslice, args.tree_levels, args.fast == 3 ? args.halo : 0,
+                               args.fast == 3 ? (long long)im->gmom_bytes : 0,
+                               (args.fast == 1 || args.fast == 3) ? (args.mom_terms ? args.mom_terms : 8) : 0, 0};
     memcpy(im->last_launch, info, sizeof(info));
     int rc;
     if (args.fast == 3)

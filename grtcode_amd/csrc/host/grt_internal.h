@@ -82,7 +82,7 @@ typedef struct GrtGasOpticsImpl
     void *bins_block;              /* device allocation backing bins.w / bins.l / bins.r / bins.tau */
     float *gmom;                   /* two-pass moment kernel: [ncol][L][8][n] cell moments */
     size_t gmom_bytes;
-    long long last_launch[6];    /* grt_gas_optics_last_launch */
+    long long last_launch[8];    /* grt_gas_optics_last_launch */
     /* spectral tables on device, each [n]: */
     double *h2o_tables;            /* [4][n] F296,S296,CKDF,CKDS or NULL */
     double *lin_tables;            /* [GRT_MAX_TABLES][n]; row k used when k < num_lin */

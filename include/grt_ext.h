@@ -51,9 +51,9 @@ EXTERN int grt_gas_optics_tune(GasOptics_t *gas_optics, int tile, int nslice, in
 
 /* What the last line-by-line launch of this object actually ran (the fused forms fall back 3 -> 1 -> 2 where a
  * grid does not suit them): info = {fast, tile, nslice, coarse levels of the cell hierarchy (0: single-level
- * far field), near-field halo in grid points, moment-buffer bytes}.  Windows of more than 200 points a side
+ * far field), near-field halo in grid points, moment-buffer bytes, moments per cell (8; 12 on sparse fine grids), 0}.  Windows of more than 200 points a side
  * (grids finer than ~0.12 cm-1) make fast = 3 sum the far field through a hierarchy of cells. */
-EXTERN int grt_gas_optics_last_launch(GasOptics_t const *gas_optics, long long info[6]);
+EXTERN int grt_gas_optics_last_launch(GasOptics_t const *gas_optics, long long info[8]);
 
 /* ---- batched columns ------------------------------------------------------------- */
 typedef struct GrtColumns

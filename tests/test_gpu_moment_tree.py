@@ -53,7 +53,9 @@ def test_0p005_beyond_the_single_level_kernels(tmp_path, oracle, lib, device, ti
     steps in the lowest layers, so the fine levels are skipped there and the near field is ~150 points."""
     band = Band(str(tmp_path), 2000.0, 2030.0, 0.005, 1500)
     info = check(band, device, oracle, lib, syn.profile(4, 7), tile=tile)
-    assert info["tree_levels"] == 10 and info["halo"] > 100
+    assert info["tree_levels"] == 10 and info["halo"] > 50
+    # four cells per line: the automatic tile is 2 048 cells, moments straight to global memory, twelve of them
+    assert (info["moments"], info["tile"]) == ((12, 2048) if tile == 0 else (8, tile)), info
 
 
 def test_high_pressure_wide_lorentz_lines(tmp_path, oracle, lib, device):

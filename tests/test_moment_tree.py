@@ -7,7 +7,8 @@ C = j 2^l + 2^(l-1) - 1/2, so in units of h the same series holds:
     sum_i A_i / ((f - x_i)^2 + e_i^2) = (1/h) u^2 (m_1 + u (m_2 + ... )),   u = h/(f - C),
     m_k = M_k / h^k,    M_k = sum_i A_i Im(z_i^k)/e_i,  z_i = (x_i - C) + i e_i,
 
-valid (8 terms, ratio 0.128) where |f - C| >= 7.8 sqrt(h^2/4 + e_max^2).  Parents come from their two children
+valid (8 terms, ratio 0.128) where |f - C| >= 7.8 sqrt(h^2/4 + e_max^2) -- or 12 terms, ratio 0.253, 3.95 sqrt(...):
+the sparse-line form of the kernels, with half the near field.  Parents come from their two children
 by the binomial shift  m'_k = sum_{j<=k} C(k,j) (-+1/4)^(k-j) 2^-j m_j  (the same table at every level).
 
 A target f must receive exactly the cells c with R(c) < |f - c| <= fsteps (kernels.c:435-437: the window of a
@@ -19,11 +20,10 @@ import math
 import numpy as np
 import pytest
 
-K = 8
-RATIO2 = 7.8 ** 2
+SEP = {8: 7.8, 12: 3.95}      # near field / |z|max: sep^-K = 7e-8 (moment_separation in k_gas_optics_mp.hip)
 
 
-def shift_tables():
+def shift_tables(K):
     """T[side][k][j]: parent m_(k+1) from child m_(j+1); side 0 = lower child (shift -1/4), 1 = upper (+1/4)."""
     T = np.zeros((2, K, K))
     for side, s in enumerate((-0.25, 0.25)):
@@ -33,7 +33,7 @@ def shift_tables():
     return T
 
 
-def level0_moments(nw, c, delta, eta, A, dtype):
+def level0_moments(nw, c, delta, eta, A, dtype, K=8):
     """[nw][K] moments about the cells' grid points; the kernel's two-term recurrence."""
     M = np.zeros((nw, K))
     u, p = A.astype(dtype), np.zeros_like(A, dtype=dtype)
@@ -45,7 +45,8 @@ def level0_moments(nw, c, delta, eta, A, dtype):
 
 
 def build_levels(m0, nlev, dtype):
-    T = shift_tables().astype(dtype)
+    K = m0.shape[1]
+    T = shift_tables(K).astype(dtype)
     levels = [m0]
     for _ in range(nlev):
         ch = levels[-1]
@@ -59,15 +60,15 @@ def build_levels(m0, nlev, dtype):
 def cell_value(m, h, d_signed, dtype):
     u = dtype(h) / dtype(d_signed)
     acc = dtype(0)
-    for k in range(K - 1, -1, -1):
+    for k in range(len(m) - 1, -1, -1):
         acc = dtype(acc * u + m[k])
     return float(dtype(acc * (u * u)) / dtype(h))
 
 
-def admissible_level(dm, eta_max):
-    """Largest l with (dm + h/2) >= 7.8 sqrt(h^2/4 + eta^2), h = 2^l; dm = distance to the cell's near edge."""
-    q = dm * dm - RATIO2 * eta_max ** 2
-    a = (RATIO2 - 1.0) / 4.0
+def admissible_level(dm, eta_max, sep=7.8):
+    """Largest l with (dm + h/2) >= sep sqrt(h^2/4 + eta^2), h = 2^l; dm = distance to the cell's near edge."""
+    q = dm * dm - sep ** 2 * eta_max ** 2
+    a = (sep ** 2 - 1.0) / 4.0
     disc = dm * dm + 4 * a * q
     if disc < 0:
         return 0
@@ -77,11 +78,12 @@ def admissible_level(dm, eta_max):
 
 def tree_far_field(f, levels, nw, fsteps, R, eta_max, dtype, counts=None):
     total, lmax = 0.0, len(levels) - 1
+    sep = SEP[levels[0].shape[1]]
 
     def pick(D, align, room):
         l = 0
         if D > R:
-            l = min(admissible_level(D - 0.5, eta_max), align, room.bit_length() - 1, lmax)
+            l = min(admissible_level(D - 0.5, eta_max, sep), align, room.bit_length() - 1, lmax)
         return l
 
     x, e = f + 1, min(f + fsteps, nw - 1)
@@ -107,8 +109,8 @@ def tree_far_field(f, levels, nw, fsteps, R, eta_max, dtype, counts=None):
     return total
 
 
-def radius(eta_max):
-    return max(3, int(np.ceil(7.8 * np.sqrt(0.25 + eta_max ** 2))) - 1)
+def radius(eta_max, K=8):
+    return max(3, int(np.ceil(SEP[K] * np.sqrt(0.25 + eta_max ** 2))) - 1)
 
 
 def exact_far_field(f, c, delta, eta, A, fsteps, R):
@@ -117,22 +119,23 @@ def exact_far_field(f, c, delta, eta, A, fsteps, R):
     return float(np.sum(A[sel] / ((r[sel] - delta[sel]) ** 2 + eta[sel] ** 2)))
 
 
+@pytest.mark.parametrize("K", [8, 12])
 @pytest.mark.parametrize("eta_max,fsteps,nw", [(0.02, 1000, 5000), (2.5, 1000, 5000), (70.0, 2500, 9000),
                                                  (0.3, 333, 1500)])
-def test_tree_equals_the_windowed_sum(eta_max, fsteps, nw):
+def test_tree_equals_the_windowed_sum(eta_max, fsteps, nw, K):
     rng = np.random.default_rng(int(eta_max * 100) + fsteps)
     n = nw // 3
     c = np.sort(rng.integers(0, nw, n))
     delta = rng.uniform(-0.5, 0.5, n)
     eta = eta_max * rng.uniform(0.05, 1, n)
     A = 10.0 ** rng.uniform(-4, 0, n) * eta         # cl/wr^2 ~ S gamma
-    R = radius(eta_max)
+    R = radius(eta_max, K)
     nlev = int(math.log2(fsteps)) - 1
     targets = np.unique(np.concatenate([rng.integers(0, nw, 40), [0, 1, nw - 1, nw // 2, fsteps, fsteps + 1,
                                                                    nw - fsteps - 1, nw - fsteps]]))
     scale = max(exact_far_field(int(f), c, delta, eta, A, fsteps, -1) for f in targets)   # the layer's largest tau
     for dtype, tol in ((np.float64, 1.5e-7), (np.float32, 6e-7)):
-        levels = build_levels(level0_moments(nw, c, delta, eta, A, dtype), nlev, dtype)
+        levels = build_levels(level0_moments(nw, c, delta, eta, A, dtype, K), nlev, dtype)
         worst, counts = 0.0, {}
         for f in targets:
             got = tree_far_field(int(f), levels, nw, fsteps, R, eta_max, dtype, counts)
