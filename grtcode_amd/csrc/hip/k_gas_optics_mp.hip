@@ -132,39 +132,85 @@ struct MpQueue
     unsigned short idx[kClasses][kWaves][kMpQueue];   // accumulator index f - F0
 };
 
+constexpr int binomial(int n, int k)
+{
+    int r = 1;
+    for (int i = 1; i <= k; ++i)
+    {
+        r = r*(n - k + i)/i;
+    }
+    return r;
+}
+
+// a Voigt line with a region 1 at all (RFM_voigt.c:97,122-126)
+__device__ __forceinline__ bool voigt_reg1(float y, bool lorentz)
+{
+    return !lorentz & (y > 0.000001f);
+}
+
 // Near-field radius R of a (cell tile, layer), the same for every line of the tile.
 // moment series: every line has |z| <= sqrt(1/4 + eta_max^2), eta_max from the largest half-width any
 // line of the store can have in this layer (kernels.c:105-106: per molecule, the largest air- and
 // self-broadening coefficients times this layer's partial pressures); ratio |z|/(R+1) <= 0.128 keeps the
 // 8-term remainder below 1e-7 of the far-wing value (0.253 with 12 terms: moment_separation).  If that asks for more than the window, the whole
 // window is "near" (R = fsteps) and no moments are formed.  ms_l: this layer's [slot][4] block in LDS.
-__device__ int near_radius(GrtGasOpticsArgs const &a, double const *lay, double const *ms_l, long long F1l, int fsteps,
-                           bool *use_moments, double *zmax = nullptr)
+//
+// Humlicek region 1 (XLIM1 <= |x| < XLIM0 <= 123.4 Doppler widths) differs from the Lorentzian the moments carry,
+//     K1 - K0 = cl [ 1.5/q^2 + (1.25 - 5 Y)/q^3 + (10.5 Y^2 - 8.75 Y + 0.875)/q^4 + ... ],   q = x^2, Y = y^2
+// (RFM_voigt.c:172-183 against :103, both expanded in 1/q).  Where every line of the (tile, layer) has y <= 4 the
+// three terms are FOLDED INTO THE MOMENTS (`corrected`: with x = (r - delta) wr they are multiples of
+// (r - delta)^-4, ^-6, ^-8, expanded about the cell centre like the Lorentzian), so the near field only has to
+// reach where that series is good -- X1 = max(13, 8 y_max) Doppler widths, which also covers XLIM1 <= 12.85 --
+// instead of all of region 1.  Cost: the series goes on beyond a line's XLIM0, where the reference has switched
+// back to the Lorentzian: <= 1.5 cl/XLIM0^4, 1e-7 of the line's own peak at y = 4 (3e-8 at y = 2), falling as x^-4.
+// Elsewhere (some line of the tile may have y > 4: low wavenumbers, high pressures) region 1 is evaluated inside
+// the ring where it lies within rcap grid steps (a performance choice: region-1 points beyond R are picked up
+// line by line in pre-pass 2; shrinking R below that was measured slower).
+// [F0l, F1l): the cells of the tile (one-pass form: including the fsteps cells either side it prepares).
+constexpr double kCorrectedYmax = 4.;
+__device__ int near_radius(GrtGasOpticsArgs const &a, double const *lay, double const *ms_l, long long F0l, long long F1l,
+                           int fsteps, bool *use_moments, bool *corrected, double *zmax = nullptr)
 {
-    double gmax = 0., dop = 0.;         // max over slots of yair_max (P - Ps) + yself_max Ps; of the Doppler factor
+    double gmax = 0., dop = 0., dop_min = 1e30;     // max over slots of yair_max (P - Ps) + yself_max Ps; Doppler factors
     for (int sl = 0; sl < a.lay.num_slots; ++sl)
     {
         gmax = fmax(gmax, (double)a.lines.yair_max[sl]*fabs(ms_l[sl*4 + 1]) + (double)a.lines.yself_max[sl]*fabs(ms_l[sl*4]));
         dop = fmax(dop, ms_l[sl*4 + 3]);
+        dop_min = fmin(dop_min, ms_l[sl*4 + 3]);
     }
-    double const eta = gmax*exp(a.lines.nmax*fabs(lay[3]))/a.wres;
+    double const gamma_max = gmax*exp(a.lines.nmax*fabs(lay[3]));
+    double const eta = gamma_max/a.wres;
     if (zmax != nullptr)
     {
         *zmax = sqrt(0.25 + eta*eta);       // every line of the layer has |z| = |delta + i eta| below this
     }
     int const r_mp = (int)ceil(moment_separation(a.mom_terms)*sqrt(0.25 + eta*eta)) - 1;
     int const r_lo = r_mp < 3 ? 3 : r_mp;
-    // Humlicek region 1 reaches XLIM0 <= 123.4 Doppler units from the centre: evaluate it inside the ring
-    // where that is within kRcap grid steps for every line of the tile (a performance choice, not a bound
-    // the results depend on: region-1 points beyond R are picked up line by line in pre-pass 2; shrinking R
-    // below this estimate was measured slower)
     double const w_hi = a.w0 + (double)(F1l + fsteps)*a.wres;
     double const alpha_max = 0.83255461115*w_hi*dop;
     double const reach = 123.4*alpha_max/(0.832554611*a.wres) + 0.51;
     int const rcap = a.rcap > 0 ? a.rcap : kRcap;
     int const r_reg1 = reach < (double)rcap ? (int)reach : rcap;
     int R = r_lo > r_reg1 ? r_lo : r_reg1;
+    *corrected = false;
+    // largest y = sqrt(ln 2) gamma/alpha any line of the tile can have in this layer (kernels.c:105-106,127)
+    double const w_lo = a.w0 + ((double)F0l - 1.)*a.wres;
+    double const alpha_min = 0.83255461115*w_lo*dop_min;
+    if (alpha_min > 0. && 0.8326*gamma_max <= kCorrectedYmax*alpha_min*0.999)
+    {
+        double const y_max = 0.8326*gamma_max/alpha_min;
+        double const x1 = fmax(13., 8.*y_max);
+        double const reach_c = x1*alpha_max/(0.832554611*a.wres) + 1.51;
+        int const rc = reach_c < 1e9 ? (int)reach_c : 1000000000;
+        int const Rc = r_lo > rc ? r_lo : rc;
+        if (Rc + 4 <= fsteps && (Rc < R || reach >= (double)(rcap + 1)))
+        {
+            *corrected = true;
+            R = Rc;
+        }
+    }
     *use_moments = (R + 4 <= fsteps);
+    *corrected = *corrected && *use_moments;
     return *use_moments ? R : fsteps;
 }
 
@@ -246,7 +292,8 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
     int const nw_i = (int)nw;
 
     bool use_moments;
-    int const R = near_radius(a, lay, ms_l, F1l, fsteps, &use_moments);
+    bool corrected;
+    int const R = near_radius(a, lay, ms_l, TWO_PASS ? F0l : F0l - fsteps_ll, F1l, fsteps, &use_moments, &corrected);
 
     // moments go to the tile's LDS block, or (tree form: ncell == 0, sparse lines, wide tiles) straight to the
     // zeroed level-0 block in global memory
@@ -368,6 +415,35 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
                     pk = fmaf(delta, pk, u);
                     u = un;
                     m[k] = pk;
+                }
+            }
+            if (corrected)
+            {
+                // region 1 minus the Lorentzian (near_radius): amp cl [c2/q^2 + c3/q^3 + c4/q^4], q = (r - delta)^2 wr^2,
+                // i.e. b4 (r-delta)^-4 + b6 (r-delta)^-6 + b8 (r-delta)^-8, each expanded about the cell centre:
+                // (r - delta)^-n = sum_j C(n-1+j, j) delta^j r^-(n+j); m[i] multiplies r^-(i+2).
+                // Lines without a region 1 (y <= 1e-6, RFM_voigt.c:122-126) take no part.
+                bool const has_reg1 = voigt_reg1(y, lorentz);
+                float const rw2 = rwr*rwr;
+                float const b4 = has_reg1 ? 1.5f*(amp_f*rw2) : 0.f;
+                float const b6 = has_reg1 ? fmaf(-5.f, yq, 1.25f)*((amp_f*rw2)*rw2) : 0.f;
+                float const b8 = has_reg1 ? fmaf(yq, fmaf(10.5f, yq, -8.75f), 0.875f)*(((amp_f*rw2)*rw2)*rw2) : 0.f;
+                float d4 = b4, d6 = b6, d8 = b8;        // b_n delta^j
+#pragma unroll
+                for (int i = 2; i < K; ++i)
+                {
+                    m[i] = fmaf((float)binomial(i + 1, 3), d4, m[i]);
+                    d4 *= delta;
+                    if (i >= 4)
+                    {
+                        m[i] = fmaf((float)binomial(i + 1, 5), d6, m[i]);
+                        d6 *= delta;
+                    }
+                    if (i >= 6)
+                    {
+                        m[i] = fmaf((float)binomial(i + 1, 7), d8, m[i]);
+                        d8 *= delta;
+                    }
                 }
             }
             if constexpr (K == kMom)
@@ -499,7 +575,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
         // cl (1.5 XQ - 0.5 A0) / [(D0+XQ(D2+XQ)) (XQ+YQ)]   (see k_gas_optics.hip) ----
         {
             int const reach0 = voigt_line ? (int)(xlim0*rwr) + 1 : -1;
-            int const rmax = wave_max_s(reach0);
+            int const rmax = corrected ? -1 : wave_max_s(reach0);      // (corrected: the moments carry region 1)
             for (int rr = R + 1; rr <= rmax; ++rr)
             {
 #pragma unroll
@@ -739,8 +815,8 @@ __global__ __launch_bounds__(kBlock) void gas_optics_far_kernel(GrtGasOpticsArgs
     if (tid <= t1 - t0)
     {
         long long const c1 = ((long long)(t0 + tid + 1) << cell_shift);
-        bool um;
-        rtab[tid] = near_radius(a, lay, ms_l, c1 < nw ? c1 : nw, fsteps, &um);
+        bool um, cr;
+        rtab[tid] = near_radius(a, lay, ms_l, (long long)(t0 + tid) << cell_shift, c1 < nw ? c1 : nw, fsteps, &um, &cr);
     }
     __syncthreads();
     int rmin = fsteps, rmax = 0;
@@ -758,9 +834,9 @@ __global__ __launch_bounds__(kBlock) void gas_optics_far_kernel(GrtGasOpticsArgs
     }
     if (fsteps > 64)
     {
-        bool um;
+        bool um, cr;
         double zmax;
-        near_radius(a, lay, ms_l, F1l, fsteps, &um, &zmax);
+        near_radius(a, lay, ms_l, F0l, F1l, fsteps, &um, &cr, &zmax);
         double const need[kMom + 1] = {1e30, 1e30, 1e30, 240., 61., 27., 15.6, 10.5, 0.};     // (7e-8)^(-1/K)
         for (int k = 0; k <= kMom; ++k)
         {
@@ -974,8 +1050,8 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArg
     if (tid <= t1 - t0)
     {
         long long const c1 = ((long long)(t0 + tid + 1) << cell_shift);
-        bool um;
-        rtab[tid] = near_radius(a, lay, ms_l, c1 < nw ? c1 : nw, fsteps, &um);
+        bool um, cr;
+        rtab[tid] = near_radius(a, lay, ms_l, (long long)(t0 + tid) << cell_shift, c1 < nw ? c1 : nw, fsteps, &um, &cr);
     }
     __syncthreads();
     int rmin = fsteps, rmax = 0;
@@ -984,9 +1060,9 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArg
         rmin = rtab[t] < rmin ? rtab[t] : rmin;
         rmax = rtab[t] > rmax ? rtab[t] : rmax;
     }
-    bool um;
+    bool um, cr;
     double zmax;
-    near_radius(a, lay, ms_l, F1, fsteps, &um, &zmax);
+    near_radius(a, lay, ms_l, F0, F1, fsteps, &um, &cr, &zmax);
     double const sep = moment_separation(K);
     float const eta2x = (float)(sep*sep*(zmax*zmax - 0.25))*1.0001f;
     float const a4 = (float)(sep*sep - 1.), r2a = (float)(0.999*2./(sep*sep - 1.));
