@@ -9,12 +9,8 @@
 
 #pragma clang fp contract(off)
 
-// Ablation hooks for timing experiments only (never defined in the product build).
-#if defined(GRT_EXP_NOATOMIC)
-#define GRT_ACC_ADD(ptr, v) (*(ptr) += (v))
-#else
+// accumulation into the workgroup's LDS tile (ds_add_f64 / ds_add_f32, no return value)
 #define GRT_ACC_ADD(ptr, v) unsafeAtomicAdd((ptr), (v))
-#endif
 
 namespace {
 
@@ -88,13 +84,8 @@ __device__ __forceinline__ Prepared prepare_line(RawLine const &ln,
     }
     else
     {
-#if defined(GRT_EXP_NOPREP)
-        p.snn = ln.s0*(c2*en/T)*(1.f - (c2*v0/T))*q[ln.iso - 1];
-        p.gamma = (tref/T + nexp)*(yair*pf + yself*ps);
-#else
         p.snn = ln.s0*exp(c2*en/T)*(1.f - exp(c2*v0/T))*q[ln.iso - 1];   // kernels.c:83-85
         p.gamma = pow(tref/T, nexp)*(yair*pf + yself*ps);                  // kernels.c:105-106
-#endif
     }
     p.alpha = sqrt_ln2*p.vnn*dop;                                    // kernels.c:127
     // kernels.c:431-432: fcenterid = floor((2*((vnn - w0)/wres) + 1)/2), bit-exact.  The quotient is
@@ -329,14 +320,8 @@ __device__ __forceinline__ double ring_pass(double v)
     // v_mov_b32_dpp wave_rol:1 (DPP control 0x134): lane l <- lane l+1, lane 63 <- lane 0;
     // register-file latency, no LDS crossbar trip (direction verified on gfx950 hardware)
     int lo = __double2loint(v), hi = __double2hiint(v);
-#if defined(GRT_RING_BPERMUTE)
-    int const src = ((threadIdx.x + 1) & 63) << 2;
-    lo = __builtin_amdgcn_ds_bpermute(src, lo);
-    hi = __builtin_amdgcn_ds_bpermute(src, hi);
-#else
     lo = __builtin_amdgcn_update_dpp(lo, lo, 0x134, 0xf, 0xf, true);
     hi = __builtin_amdgcn_update_dpp(hi, hi, 0x134, 0xf, 0xf, true);
-#endif
     return __hiloint2double(hi, lo);
 }
 

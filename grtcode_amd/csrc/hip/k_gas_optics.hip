@@ -194,11 +194,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, 
         {
             bool const voigt_line = (lo <= hi) & !lorentz;
             int const reach = voigt_line ? (int)(xlim0/(repwid*wres_f)) + 2 : -1;
-#if defined(GRT_EXP_NOPREPASS)
-            int const rmax = wave_max(reach) > 1000000 ? 1 : -1;
-#else
             int const rmax = wave_max(reach);
-#endif
             // (staggering the lanes' walks to spread the LDS adds was measured: no gain -- this loop is
             // instruction-bound, not conflict-bound)
             for (int r = -rmax; r <= rmax; ++r)
@@ -315,12 +311,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, 
         // reference-order form: every remaining point (far wing of Voigt lines, all of the Lorentz
         // lines); fused form: the Lorentzian at EVERY window point -- the pre-pass has already added
         // (true value - Lorentzian) for the inner points, so no test is needed here.
-#if defined(GRT_EXP_NORING)
-        if (amp == 12345.678) acc[lane] = amp + wr + ndcr + cl + yq + num + yrrtpi + norm + dwno + wnoadj + xlim0 + xlim1 + s + c;
-        for (int fbp = fb; fbp <= fe && amp == 12345.678; fbp += 64)
-#else
         for (int fbp = fb; fbp <= fe; fbp += 64)
-#endif
         {
             double token = 0.;
             int slot = lane;                        // (lane + t) & 63
