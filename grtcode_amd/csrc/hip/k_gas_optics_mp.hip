@@ -64,19 +64,9 @@ __device__ __forceinline__ int dpp_i(int v)
     return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
 }
 
-// Wave-wide integer min / max as scalars: rotations inside the rows of 16 lanes (every lane of a row
+// Wave-wide integer max as a scalar: rotations inside the rows of 16 lanes (every lane of a row
 // ends up with the row's extreme, whatever the direction of row_ror), then the four rows on the
 // scalar unit.
-__device__ __forceinline__ int wave_min_s(int v)
-{
-    v = min(v, dpp_i<0x121>(v));
-    v = min(v, dpp_i<0x122>(v));
-    v = min(v, dpp_i<0x124>(v));
-    v = min(v, dpp_i<0x128>(v));
-    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
-}
-
 __device__ __forceinline__ int wave_max_s(int v)
 {
     v = max(v, dpp_i<0x121>(v));
