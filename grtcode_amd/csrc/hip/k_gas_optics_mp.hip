@@ -161,14 +161,18 @@ constexpr double kCorrectedYmax = 4.;
 __device__ int near_radius(GrtGasOpticsArgs const &a, double const *lay, double const *ms_l, long long F0l, long long F1l,
                            int fsteps, bool *use_moments, bool *corrected, double *zmax = nullptr)
 {
-    double gmax = 0., dop = 0., dop_min = 1e30;     // max over slots of yair_max (P - Ps) + yself_max Ps; Doppler factors
+    // max over slots of yair_max (P - Ps) + yself_max Ps (Lorentz width at 296 K); of the Doppler factor; of their
+    // quotient, molecule by molecule (y = gamma/(nu dop))
+    double gmax = 0., dop = 0., gd_max = 0.;
     for (int sl = 0; sl < a.lay.num_slots; ++sl)
     {
-        gmax = fmax(gmax, (double)a.lines.yair_max[sl]*fabs(ms_l[sl*4 + 1]) + (double)a.lines.yself_max[sl]*fabs(ms_l[sl*4]));
+        double const g = (double)a.lines.yair_max[sl]*fabs(ms_l[sl*4 + 1]) + (double)a.lines.yself_max[sl]*fabs(ms_l[sl*4]);
+        gmax = fmax(gmax, g);
         dop = fmax(dop, ms_l[sl*4 + 3]);
-        dop_min = fmin(dop_min, ms_l[sl*4 + 3]);
+        gd_max = fmax(gd_max, ms_l[sl*4 + 3] > 0. ? g/ms_l[sl*4 + 3] : 1e300);
     }
-    double const gamma_max = gmax*exp(a.lines.nmax*fabs(lay[3]));
+    double const tfac = exp(a.lines.nmax*fabs(lay[3]));
+    double const gamma_max = gmax*tfac;
     double const eta = gamma_max/a.wres;
     if (zmax != nullptr)
     {
@@ -183,12 +187,13 @@ __device__ int near_radius(GrtGasOpticsArgs const &a, double const *lay, double 
     int const r_reg1 = reach < (double)rcap ? (int)reach : rcap;
     int R = r_lo > r_reg1 ? r_lo : r_reg1;
     *corrected = false;
-    // largest y = sqrt(ln 2) gamma/alpha any line of the tile can have in this layer (kernels.c:105-106,127)
+    // largest y = sqrt(ln 2) gamma/alpha = gamma/(nu dop) any line of the tile can have in this layer, molecule by
+    // molecule (kernels.c:105-106,127)
     double const w_lo = a.w0 + ((double)F0l - 1.)*a.wres;
-    double const alpha_min = 0.83255461115*w_lo*dop_min;
-    if (alpha_min > 0. && 0.8326*gamma_max <= kCorrectedYmax*alpha_min*0.999)
+    double const y_num = 1.001*gd_max*tfac;
+    if (w_lo > 0. && y_num <= kCorrectedYmax*w_lo)
     {
-        double const y_max = 0.8326*gamma_max/alpha_min;
+        double const y_max = y_num/w_lo;
         double const x1 = fmax(13., 8.*y_max);
         double const reach_c = x1*alpha_max/(0.832554611*a.wres) + 1.51;
         int const rc = reach_c < 1e9 ? (int)reach_c : 1000000000;
