@@ -158,3 +158,37 @@ def test_batched_columns_equal_single_columns(tmp_path, device, dw, nlines):
         assert np.max(np.abs(batch[c] - single[c]) / scale) < 1e-9      # another halo, another order of additions
     buf.free()
     go.destroy()
+
+
+def test_full_3m_point_grid_tree_equals_ring(device):
+    """BASELINE.json's ~3 M-wavenumber grid at full width (1-3250 cm-1 at 0.001 cm-1, n = 3 249 001, 10^6 lines,
+    12 layers to keep the read-back small): the oracle would need hours here, so the check is the size-independent
+    one -- the cell hierarchy against the ring kernel, which evaluates every one of the 50 001 window points of
+    every line and is itself pinned to the oracle on the small grids above."""
+    import tempfile
+    from grtcode_amd import workload as W
+    V = 13
+    root = tempfile.mkdtemp(prefix="grt_g3_")
+    files, _ = W.write_tables(root, sw=False)
+    spec = (1.0, 3250.0, 0.001)
+    go, grid = W.build_band(device, spec, W.band_lines(W.LW_LINES, spec, 20261003), files, V)
+    assert grid.n == 3249001
+    col = syn.profile(3, V)
+    for m in W.MOL_ORDER:
+        go.set_molecule_ppmv(m, col["ppmv"][m])
+    go.set_cfc_ppmv(0, col["cfc_ppmv"][0])
+    go.set_cfc_ppmv(1, col["cfc_ppmv"][1])
+    go.set_cia_ppmv(0, col["ppmv"][syn.N2])
+    go.set_cia_ppmv(1, col["ppmv"][syn.O2])
+    opt = api.OpticsObject(V - 1, grid, device)
+    out = {}
+    for fast in (3, 2):
+        go.tune(fast=fast)
+        go.calculate_optical_depth(col["p"], col["t"], opt)
+        out[fast] = (opt.read()[0], go.last_launch())
+    opt.destroy()
+    go.destroy()
+    (tree, info), (ring, _) = out[3], out[2]
+    assert info["fast"] == 3 and info["tree_levels"] == 12 and info["moments"] == 12, info
+    assert np.all(np.isfinite(tree)) and tree.min() >= 0.0
+    assert tau_close(tree, ring) < 5e-7
