@@ -984,12 +984,9 @@ __device__ __forceinline__ int admissible_level(float dm, float eta2x, float a4,
 {
     float const q = fmaf(dm, dm, -eta2x);
     float const disc = fmaf(a4, q, dm*dm);
-    if (!(disc >= 0.f))
-    {
-        return 0;
-    }
-    float const hmax = (dm + __builtin_amdgcn_sqrtf(disc))*r2a;
-    return hmax >= 2.f ? (__float_as_int(hmax) >> 23) - 127 : 0;
+    float const hmax = disc >= 0.f ? (dm + __builtin_amdgcn_sqrtf(fmaxf(disc, 0.f)))*r2a : 0.f;    // (no root: no level)
+    int const e = (__float_as_int(hmax) >> 23) - 127;           // floor(log2 hmax); below 1: level 0
+    return e > 0 ? e : 0;
 }
 
 template <int K>
@@ -1067,32 +1064,31 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArg
     {
         int const f = F0 + i;
         double sum = 0.;
-        // cells above f: x = lowest level-0 cell not yet covered
+        // cells above f: x = lowest level-0 cell not yet covered.  First the level-0 cells within the largest near
+        // field of the neighbourhood (each asks its own cell tile's radius, as the first pass did), then the greedy
+        // walk, free of branches: level = min(alignment, room to the window's edge, admissible, top level)
         {
             int const e = f + fsteps < nw - 1 ? f + fsteps : nw - 1;
             int x = f + 1 + rmin;
+            int const xa = f + rmax < e ? f + rmax : e;
+            for (; x <= xa; ++x)
+            {
+                int const D = x - f;
+                if (D > rtab[(x >> cell_shift) - t0])
+                {
+                    float const u = -__builtin_amdgcn_rcpf((float)D);
+                    sum += (double)cell_series<K>(gm + (size_t)x*K, u);
+                }
+            }
             while (x <= e)
             {
                 int const D = x - f;
-                int l = 0;
-                bool use = true;
-                if (D > rmax)
-                {
-                    int const la = __builtin_ctz(x), le = 31 - __builtin_clz(e - x + 1);
-                    int const ad = admissible_level((float)D - 0.5f, eta2x, a4, r2a);
-                    l = min(min(la, le), min(ad, lmax));
-                }
-                else
-                {
-                    use = D > rtab[(x >> cell_shift) - t0];     // the cell's own tile decides, as in the first pass
-                }
-                if (use)
-                {
-                    float const h = __int_as_float((127 + l) << 23), rh = __int_as_float((127 - l) << 23);
-                    float const d = ((float)D - 0.5f) + 0.5f*h;                     // C - f
-                    float const u = -h*__builtin_amdgcn_rcpf(d);
-                    sum += (double)(cell_series<K>(gm + loff[l] + (size_t)(x >> l)*K, u)*rh);
-                }
+                int const la = __builtin_ctz(x), le = 31 - __builtin_clz(e - x + 1);
+                int const l = min(min(la, le), min(admissible_level((float)D - 0.5f, eta2x, a4, r2a), lmax));
+                float const h = __int_as_float((127 + l) << 23), rh = __int_as_float((127 - l) << 23);
+                float const d = ((float)D - 0.5f) + 0.5f*h;                     // C - f
+                float const u = -h*__builtin_amdgcn_rcpf(d);
+                sum += (double)(cell_series<K>(gm + loff[l] + (size_t)(x >> l)*K, u)*rh);
                 x += 1 << l;
             }
         }
@@ -1100,28 +1096,25 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArg
         {
             int const s = f - fsteps > 0 ? f - fsteps : 0;
             int x = f - 1 - rmin;
+            int const xa = f - rmax > s ? f - rmax : s;
+            for (; x >= xa; --x)
+            {
+                int const D = f - x;
+                if (D > rtab[(x >> cell_shift) - t0])
+                {
+                    float const u = __builtin_amdgcn_rcpf((float)D);
+                    sum += (double)cell_series<K>(gm + (size_t)x*K, u);
+                }
+            }
             while (x >= s)
             {
                 int const D = f - x;
-                int l = 0;
-                bool use = true;
-                if (D > rmax)
-                {
-                    int const la = __builtin_ctz(x + 1), le = 31 - __builtin_clz(x - s + 1);
-                    int const ad = admissible_level((float)D - 0.5f, eta2x, a4, r2a);
-                    l = min(min(la, le), min(ad, lmax));
-                }
-                else
-                {
-                    use = D > rtab[(x >> cell_shift) - t0];
-                }
-                if (use)
-                {
-                    float const h = __int_as_float((127 + l) << 23), rh = __int_as_float((127 - l) << 23);
-                    float const d = ((float)D - 0.5f) + 0.5f*h;                     // f - C
-                    float const u = h*__builtin_amdgcn_rcpf(d);
-                    sum += (double)(cell_series<K>(gm + loff[l] + (size_t)(x >> l)*K, u)*rh);
-                }
+                int const la = __builtin_ctz(x + 1), le = 31 - __builtin_clz(x - s + 1);
+                int const l = min(min(la, le), min(admissible_level((float)D - 0.5f, eta2x, a4, r2a), lmax));
+                float const h = __int_as_float((127 + l) << 23), rh = __int_as_float((127 - l) << 23);
+                float const d = ((float)D - 0.5f) + 0.5f*h;                     // f - C
+                float const u = h*__builtin_amdgcn_rcpf(d);
+                sum += (double)(cell_series<K>(gm + loff[l] + (size_t)(x >> l)*K, u)*rh);
                 x -= 1 << l;
             }
         }
