@@ -142,8 +142,9 @@ __device__ __forceinline__ bool voigt_reg1(float y, bool lorentz)
 // moment series: every line has |z| <= sqrt(1/4 + eta_max^2), eta_max from the largest half-width any
 // line of the store can have in this layer (kernels.c:105-106: per molecule, the largest air- and
 // self-broadening coefficients times this layer's partial pressures); ratio |z|/(R+1) <= 0.128 keeps the
-// 8-term remainder below 1e-7 of the far-wing value (0.253 with 12 terms: moment_separation).  If that asks for more than the window, the whole
-// window is "near" (R = fsteps) and no moments are formed.  ms_l: this layer's [slot][4] block in LDS.
+// 8-term remainder below 1e-7 of the far-wing value (0.253 with 12 terms: moment_separation).  If that asks
+// for more than the window, the whole window is "near" (R = fsteps) and no moments are formed.
+// ms_l: this layer's [slot][4] block in LDS.
 //
 // Humlicek region 1 (XLIM1 <= |x| < XLIM0 <= 123.4 Doppler widths) differs from the Lorentzian the moments carry,
 //     K1 - K0 = cl [ 1.5/q^2 + (1.25 - 5 Y)/q^3 + (10.5 Y^2 - 8.75 Y + 0.875)/q^4 + ... ],   q = x^2, Y = y^2
