@@ -135,7 +135,7 @@ set_cia_ppmv calculate_optical_depth get_num_molecules inittips_d Q
 create_longwave destroy_longwave calculate_lw_fluxes
 create_shortwave destroy_shortwave calculate_sw_fluxes rayleigh_scattering
 create_solar_flux destroy_solar_flux disort_shortwave
-grt_tips_load grt_tips_reset grt_tips_is_table grt_sizeof grt_add_molecule_lines grt_gas_optics_tune grt_gas_optics_last_launch
+grt_tips_load grt_tips_reset grt_tips_is_table grt_sizeof grt_add_molecule_lines grt_gas_optics_tune grt_gas_optics_last_launch grt_hitran_index_stats
 grt_optical_depth_batch grt_pipeline_create grt_pipeline_destroy grt_pipeline_run grt_pipeline_sync
 grt_pipeline_stream grt_pipeline_views grt_device_malloc grt_device_free grt_device_to_host
 grt_host_to_device grt_debug_line_prep grt_profile_enable grt_profile_read

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include "grt_internal.h"
 #include "grt_molecule_table.h"
 
@@ -187,7 +188,8 @@ static int scan_hitran(char const *path, int mol_id, double w0, double wn, GrtHo
    passes over a few hundred MB for one band, again for the second band.  Here the first request for a
    file parses every molecule's records into memory once; later requests (any molecule, any gas-optics
    object of this process) filter from memory.  Keyed by path, size and modification time; the two most
-   recent files are kept.  GRT_HITRAN_CACHE=0 in the environment restores one scan per call. */
+   recent files are kept.  GRT_HITRAN_CACHE=0 in the environment restores one scan per call;
+   GRT_HITRAN_CACHE_DIR=<directory> keeps a binary copy of the index on disk for later processes. */
 typedef struct HitranIndex
 {
     char path[DIR_PATH_LEN];
@@ -197,6 +199,125 @@ typedef struct HitranIndex
 } HitranIndex;
 static HitranIndex g_hitran_index[2];
 static unsigned long g_hitran_stamp = 0;
+static long long g_hitran_stats[3];     /* requests served from memory, index files read, .par files scanned */
+
+/* On-disk copy of the index (GRT_HITRAN_CACHE_DIR=<directory> in the environment): one binary file per
+   (.par path, size, modification time), the arrays of every molecule as they sit in memory.  A later
+   process reads that instead of parsing text: a few hundred MB of %12lf fields become a few reads. */
+#define GRT_IDX_MAGIC "GRTIDX01"
+typedef struct IndexHeader
+{
+    char magic[8];
+    long long size, mtime;
+    uint64_t num_mols, path_hash;
+    uint64_t n[NUM_MOLS];
+} IndexHeader;
+
+static uint64_t fnv1a(char const *str)
+{
+    uint64_t h = 1469598103934665603ull;
+    for (; *str != '\0'; ++str)
+    {
+        h = (h ^ (unsigned char)*str)*1099511628211ull;
+    }
+    return h;
+}
+
+static int index_file_name(char const *par, long long size, long long mtime, char *out, size_t len)
+{
+    char const *dir = getenv("GRT_HITRAN_CACHE_DIR");
+    if (dir == NULL || dir[0] == '\0')
+    {
+        return 0;
+    }
+    int const w = snprintf(out, len, "%s/%016llx_%lld_%lld.grtidx", dir, (unsigned long long)fnv1a(par), size, mtime);
+    return w > 0 && (size_t)w < len;
+}
+
+static size_t const g_idx_width[8] = {sizeof(double), sizeof(double), sizeof(float), sizeof(float), sizeof(float),
+                                      sizeof(float), sizeof(float), sizeof(uint8_t)};
+static void idx_arrays(GrtHostLines *l, void *a[8])
+{
+    a[0] = l->v0; a[1] = l->s0; a[2] = l->yair; a[3] = l->yself; a[4] = l->en; a[5] = l->nexp; a[6] = l->delta;
+    a[7] = l->iso;
+}
+
+/* 1 when the index was read from its file; 0 when there is none (or it does not match: the caller scans). */
+static int index_read(char const *file, char const *par, long long size, long long mtime, GrtHostLines *mol)
+{
+    FILE *fp = fopen(file, "rb");
+    if (fp == NULL)
+    {
+        return 0;
+    }
+    IndexHeader h;
+    int ok = fread(&h, sizeof(h), 1, fp) == 1 && memcmp(h.magic, GRT_IDX_MAGIC, 8) == 0 && h.size == size
+             && h.mtime == mtime && h.num_mols == NUM_MOLS && h.path_hash == fnv1a(par);
+    for (int m = 0; m < NUM_MOLS && ok; ++m)
+    {
+        if (h.n[m] == 0)
+        {
+            continue;
+        }
+        ok = h.n[m] < ((uint64_t)1 << 40) && host_lines_reserve(&mol[m], h.n[m]) == GRTCODE_SUCCESS;
+        void *a[8];
+        idx_arrays(&mol[m], a);
+        for (int k = 0; k < 8 && ok; ++k)
+        {
+            ok = fread(a[k], g_idx_width[k], h.n[m], fp) == h.n[m];
+        }
+        mol[m].n = ok ? h.n[m] : 0;
+    }
+    ok = ok && fgetc(fp) == EOF;        /* nothing may follow the last array */
+    fclose(fp);
+    if (!ok)
+    {
+        for (int m = 0; m < NUM_MOLS; ++m)
+        {
+            grt_free_host_lines(&mol[m]);
+        }
+    }
+    return ok;
+}
+
+/* Best effort: a cache that cannot be written is not an error.  Written under a temporary name and renamed,
+   so that a reader never sees half a file. */
+static void index_write(char const *file, char const *par, long long size, long long mtime, GrtHostLines *mol)
+{
+    char tmp[DIR_PATH_LEN + 64];
+    if (snprintf(tmp, sizeof(tmp), "%s.%ld.tmp", file, (long)getpid()) >= (int)sizeof(tmp))
+    {
+        return;
+    }
+    FILE *fp = fopen(tmp, "wb");
+    if (fp == NULL)
+    {
+        return;
+    }
+    IndexHeader h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.magic, GRT_IDX_MAGIC, 8);
+    h.size = size; h.mtime = mtime; h.num_mols = NUM_MOLS; h.path_hash = fnv1a(par);
+    for (int m = 0; m < NUM_MOLS; ++m)
+    {
+        h.n[m] = mol[m].n;
+    }
+    int ok = fwrite(&h, sizeof(h), 1, fp) == 1;
+    for (int m = 0; m < NUM_MOLS && ok; ++m)
+    {
+        void *a[8];
+        idx_arrays(&mol[m], a);
+        for (int k = 0; k < 8 && ok && mol[m].n > 0; ++k)
+        {
+            ok = fwrite(a[k], g_idx_width[k], mol[m].n, fp) == mol[m].n;
+        }
+    }
+    ok = (fclose(fp) == 0) && ok;
+    if (!ok || rename(tmp, file) != 0)
+    {
+        remove(tmp);
+    }
+}
 
 static int hitran_index(char const *path, HitranIndex **out)
 {
@@ -205,14 +326,15 @@ static int hitran_index(char const *path, HitranIndex **out)
     {
         GRT_FAIL(GRTCODE_IO_ERR, "failed to open file %s.", path);
     }
+    long long const mtime = (long long)st.st_mtim.tv_sec*1000000000ll + st.st_mtim.tv_nsec;
     HitranIndex *victim = &g_hitran_index[0];
     for (int i = 0; i < 2; ++i)
     {
         HitranIndex *h = &g_hitran_index[i];
-        if (h->stamp != 0 && strcmp(h->path, path) == 0 && h->size == (long long)st.st_size
-            && h->mtime == (long long)st.st_mtim.tv_sec*1000000000ll + st.st_mtim.tv_nsec)
+        if (h->stamp != 0 && strcmp(h->path, path) == 0 && h->size == (long long)st.st_size && h->mtime == mtime)
         {
             h->stamp = ++g_hitran_stamp;
+            g_hitran_stats[0]++;
             *out = h;
             return GRTCODE_SUCCESS;
         }
@@ -226,13 +348,37 @@ static int hitran_index(char const *path, HitranIndex **out)
         grt_free_host_lines(&victim->mol[m]);
     }
     victim->stamp = 0;
-    GRT_INFO("Indexing HITRAN line parameters of every molecule in %s.", path);
-    GRT_TRY(scan_hitran(path, 0, 0., 0., victim->mol));
+    char file[DIR_PATH_LEN + 64];
+    int const on_disk = index_file_name(path, (long long)st.st_size, mtime, file, sizeof(file));
+    if (on_disk && index_read(file, path, (long long)st.st_size, mtime, victim->mol))
+    {
+        GRT_INFO("Read the index of %s from %s.", path, file);
+        g_hitran_stats[1]++;
+    }
+    else
+    {
+        GRT_INFO("Indexing HITRAN line parameters of every molecule in %s.", path);
+        GRT_TRY(scan_hitran(path, 0, 0., 0., victim->mol));
+        g_hitran_stats[2]++;
+        if (on_disk)
+        {
+            index_write(file, path, (long long)st.st_size, mtime, victim->mol);
+        }
+    }
     GRT_TRY(copy_str(victim->path, path, DIR_PATH_LEN));
     victim->size = (long long)st.st_size;
-    victim->mtime = (long long)st.st_mtim.tv_sec*1000000000ll + st.st_mtim.tv_nsec;
+    victim->mtime = mtime;
     victim->stamp = ++g_hitran_stamp;
     *out = victim;
+    return GRTCODE_SUCCESS;
+}
+
+/* {requests served from the in-memory index, index files read, .par files scanned for the index} since the
+   library was loaded (grt_ext.h) */
+EXTERN int grt_hitran_index_stats(long long stats[3])
+{
+    GRT_REQUIRE_PTR(stats);
+    memcpy(stats, g_hitran_stats, sizeof(g_hitran_stats));
     return GRTCODE_SUCCESS;
 }
 

@@ -23,6 +23,14 @@ EXTERN int grt_tips_load(char const *path);
 EXTERN int grt_tips_reset(void);
 EXTERN int grt_tips_is_table(void);
 
+/* ---- HITRAN line parameters: parse once ------------------------------------------
+ * The first add_molecule on a .par file indexes every molecule's records in memory (later calls, any molecule,
+ * any object of the process, filter from that; GRT_HITRAN_CACHE=0 restores the reference's scan per call).
+ * With GRT_HITRAN_CACHE_DIR=<directory> in the environment the index is also kept as a binary file there,
+ * keyed by the .par file's path, size and modification time, and later processes read that instead of parsing
+ * text.  stats = {requests served from memory, index files read, .par files scanned}. */
+EXTERN int grt_hitran_index_stats(long long stats[3]);
+
 /* ---- struct sizes for FFI callers (ctypes; cf. fortran-bindings/malloc_structs.c:40-66) */
 enum grt_struct_kind
 {

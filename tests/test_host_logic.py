@@ -183,6 +183,64 @@ def test_hitran_parse_once_index_equals_per_molecule_scans(lib, tmp_path, monkey
     assert read(syn.H2O, 50.0, 2500.0)["v0"].size == 37
 
 
+def test_hitran_index_on_disk(lib, tmp_path, monkeypatch):
+    """GRT_HITRAN_CACHE_DIR: the index of a .par file is also written as a binary file; once the in-memory copy has
+    been displaced (two other files) the next request reads that instead of parsing text -- same arrays; a
+    truncated index file is ignored and rewritten; a rewritten .par file gets an index of its own."""
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    monkeypatch.setenv("GRT_HITRAN_CACHE_DIR", str(cache))
+    files = []
+    for k in range(3):
+        lists = {m: syn.line_list(m, 120 + 7 * m + k, 50.0, 2500.0, seed=11 + k) for m in (syn.H2O, syn.CO2, syn.CH4)}
+        path = str(tmp_path / f"lines{k}.par")
+        syn.write_hitran_par(path, lists)
+        files.append(path)
+
+    def read(path, mol):
+        hl = HostLines()
+        assert lib.grt_parse_hitran(path.encode(), mol, C.c_double(100.0), C.c_double(2000.0), C.byref(hl)) == 0
+        out = {k: np.ctypeslib.as_array(getattr(hl, k), shape=(hl.n,)).copy()
+               for k in ("v0", "s0", "yair", "yself", "en", "nexp", "delta", "iso")}
+        lib.grt_free_host_lines(C.byref(hl))
+        return out
+
+    def stats():
+        st = (C.c_longlong * 3)()
+        assert lib.grt_hitran_index_stats(st) == 0
+        return list(st)
+    s0 = stats()
+    first = read(files[0], syn.CO2)
+    assert [b - a for a, b in zip(s0, stats())] == [0, 0, 1]          # parsed, and written to the cache directory
+    idx = list(cache.glob("*.grtidx"))
+    assert len(idx) == 1 and idx[0].stat().st_size > 1000
+    read(files[0], syn.H2O)
+    assert [b - a for a, b in zip(s0, stats())] == [1, 0, 1]          # from memory
+    read(files[1], syn.H2O)
+    read(files[2], syn.H2O)                                           # two more files: the first one leaves memory
+    s1 = stats()
+    again = read(files[0], syn.CO2)
+    assert [b - a for a, b in zip(s1, stats())] == [0, 1, 0]          # from its index file
+    assert all(np.array_equal(first[k], again[k]) for k in first) and first["v0"].size > 50
+    # a damaged index file is not trusted
+    blob = idx[0].read_bytes()
+    idx[0].write_bytes(blob[: len(blob) // 2])
+    read(files[1], syn.CO2)
+    read(files[2], syn.CO2)
+    s2 = stats()
+    third = read(files[0], syn.CO2)
+    assert [b - a for a, b in zip(s2, stats())][1:] == [0, 1]         # scanned again ...
+    assert idx[0].read_bytes() == blob                                # ... and the index rewritten
+    assert all(np.array_equal(first[k], third[k]) for k in first)
+    # without the variable nothing is written
+    monkeypatch.delenv("GRT_HITRAN_CACHE_DIR")
+    lists = {syn.H2O: syn.line_list(syn.H2O, 20, 50.0, 2500.0, seed=3)}
+    path = str(tmp_path / "lines3.par")
+    syn.write_hitran_par(path, lists)
+    read(path, syn.H2O)
+    assert len(list(cache.glob("*.grtidx"))) == 3
+
+
 def test_table_loader_and_solar_flux(lib, oracle, tmp_path):
     w = np.arange(50.0, 151.0, 10.0)
     y = np.exp(-w / 100.0)
