@@ -24,8 +24,9 @@
 // Near points (|r| <= R) run through a wave ring as before, but 16 slots wide: four independent
 // rings, one per DPP row, rotate with row_ror:1; 16 steps cover 16 grid points for 64 lines.  The
 // token carries its slot number with it, so nothing depends on the direction of the rotation.
-// Humlicek region 1 (XLIM1 <= |x| < XLIM0) is evaluated inside the ring whenever it lies within R;
-// regions 2-4 go through the per-wave queue exactly as in the ring kernel.
+// Humlicek region 1 (XLIM1 <= |x| < XLIM0) is evaluated inside the ring whenever it lies within R (or travels
+// with the moments: near_radius); regions 2-4 go through per-wave queues, one per class of formula, and those
+// points are skipped by the ring, whose tokens are fp32 sums of at most 16 lines' values (fp64 from there on).
 #include <type_traits>
 #include "gas_optics_dev.h"
 
@@ -118,7 +119,7 @@ struct MpQueue
     float xi[kClasses][kWaves][kMpQueue];
     float y[kClasses][kWaves][kMpQueue];
     float repwid[kClasses][kWaves][kMpQueue];
-    float far[kClasses][kWaves][kMpQueue];      // the Lorentzian this point also receives, to be taken back
+    float far[kClasses][kWaves][kMpQueue];      // the Lorentzian the moments supply at this point (beyond R), to be taken back
     unsigned short idx[kClasses][kWaves][kMpQueue];   // accumulator index f - F0
 };
 
@@ -361,9 +362,8 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
         }
         double const snn = ln.s0*exp_fast((c2*(double)ln.en)*invT)*stim*q_l[ln.slot*GRT_MAX_ISO + ln.iso - 1];   // :83-85
         // snn*n (kernels.c:459), rounded to fp32 ONCE and used in that form everywhere (ring, queue,
-        // moments): the near-centre queue takes back amp*K_lorentz that the ring added, and at a grid
-        // point that happens to sit on a narrow line's centre K_lorentz is hundreds of times the true
-        // value -- the two products must be of the very same amp to cancel
+        // moments): for a near-centre point beyond the near field the queue takes back amp*K_lorentz that
+        // the moments supply -- the two products must be of the same amp
         double const amp = valid ? (double)(float)(snn*ms[2]) : 0.;
         double const gamma = exp_fast((double)ln.nexp*lay[3])
                              *fma((double)ln.yair, ms[1], (double)ln.yself*ms[0]);       // kernels.c:105-106
@@ -550,9 +550,11 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
                             nq->xi[q][wave][pos] = xr;
                             nq->y[q][wave][pos] = y;
                             nq->repwid[q][wave][pos] = repwid;
-                            // the Lorentzian this point also receives (ring: the very same instruction
-                            // sequence, so it cancels exactly; moments: to ~1e-8), to be taken back
-                            nq->far[q][wave][pos] = cl*__builtin_amdgcn_rcpf(fmaf(xi, xi, yq));
+                            // inside the near field the point is the queue's alone (the ring skips it: at a grid
+                            // point on a narrow line's centre the Lorentzian is hundreds of times the true value,
+                            // nothing to put through fp32 partial sums); beyond it the moments supply the
+                            // Lorentzian there (to ~1e-8), to be taken back
+                            nq->far[q][wave][pos] = (r >= -R) & (r <= R) ? 0.f : cl*__builtin_amdgcn_rcpf(fmaf(xi, xi, yq));
                             nq->idx[q][wave][pos] = (unsigned short)(f - A0);
                         }
                         qcount[q] += npush;
@@ -609,6 +611,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
         {
             continue;
         }
+        float const amp_f32 = (float)amp;
         float const mid = 0.5f*(float)(lo_n + hi_n) - (float)c;
         float const half = lo_n <= hi_n ? 0.5f*(float)(hi_n - lo_n) + 0.25f : -1.f;
         // One pass of the row rings over the grid points [fbp, fbp + PERIOD).  PERIOD 16: sixteen tokens
@@ -623,7 +626,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
         {
             constexpr int PERIOD = decltype(period_tag)::value;
             constexpr int MODE = decltype(mode_tag)::value;
-            double token = 0.;
+            float token = 0.f;
             float slotf = (float)(lane & (PERIOD - 1));
             float const base_rel = (float)(fbp - c);
 #pragma unroll 4
@@ -640,21 +643,22 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
                 }
                 else
                 {
-                    // region 1 (RFM_voigt.c:172-183): K = c (A0+XQ)/(D0+XQ(D2+XQ)); elsewhere the Lorentzian
-                    bool const reg1 = (xq >= xq_near) & (xq < x0q);
+                    // region 1 (RFM_voigt.c:172-183): K = c (A0+XQ)/(D0+XQ(D2+XQ)); beyond it the Lorentzian; the
+                    // near-centre points (|x| < XLIM1) are the queue's alone
+                    bool const outer = xq >= xq_near;
+                    bool const reg1 = outer & (xq < x0q);
                     float const den = reg1 ? fmaf(xq, d2r + xq, d0r) : d;
                     float const num = reg1 ? cl*(a0 + xq) : cl;
-                    kf = (MODE == 1 || fabsf(rel - mid) <= half) ? num*__builtin_amdgcn_rcpf(den) : 0.f;
+                    kf = (outer & (MODE == 1 || fabsf(rel - mid) <= half)) ? num*__builtin_amdgcn_rcpf(den) : 0.f;
                 }
-                asm volatile("" : "+v"(kf));        // select in fp32, then widen once
-                token = fma(amp, (double)kf, token);
-                token = row_pass(token);
+                token = fmaf(amp_f32, kf, token);
+                token = dpp_f<0x121>(token);
                 slotf = dpp_f<0x121>(slotf);
             }
             int const f = fbp + (int)slotf;
             if (f <= fe)
             {
-                GRT_ACC_ADD(&acc[f - A0], token);
+                GRT_ACC_ADD(&acc[f - A0], (double)token);
             }
         };
         std::integral_constant<int, 0> const general{};

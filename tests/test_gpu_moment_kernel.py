@@ -43,7 +43,7 @@ def check(band, device, oracle, lib, col, **kw):
     assert e_ring < FAST_TOL
     assert e_two < FAST_TOL
     assert e_between < 5e-7
-    assert e_forms < 1e-7                               # same arithmetic, different order of additions
+    assert e_forms < 3e-7                               # same arithmetic, other groupings of the fp32 ring sums
     return mp, want
 
 
