@@ -233,9 +233,9 @@ __device__ __forceinline__ void drain_class(double *acc, MpQueue const *q, int w
 // grids want: a tile is 512 points, so at 0.1 cm-1 the one-pass form prepares every line twice.
 // TREE (two-pass form on fine grids): the accumulator spans the tile and `halo` < fsteps points either side -- all
 // that a near field can reach -- and the far field is left to the cell hierarchy (gas_optics_tree_kernel).
-template <bool TWO_PASS, bool TREE = false, int K = kMom>
-__global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs a, long long fsteps_ll, unsigned ngroups,
-                                                                unsigned perm_stride, int ncell, int nacc, int halo)
+template <bool TWO_PASS, bool TREE, int K>
+__device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long long fsteps_ll, unsigned ngroups,
+                                               unsigned perm_stride, int ncell, int nacc, int halo)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int const fsteps = (int)fsteps_ll;
@@ -767,6 +767,24 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
         __syncthreads();
     }
     write_tile(a, acc, cs, col, layer, slice, F0l, F1l, tid);
+}
+
+template <bool TWO_PASS, bool TREE = false, int K = kMom>
+__global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs a, long long fsteps_ll, unsigned ngroups,
+                                                                unsigned perm_stride, int ncell, int nacc, int halo)
+{
+    mp_kernel_body<TWO_PASS, TREE, K>(a, fsteps_ll, ngroups, perm_stride, ncell, nacc, halo);
+}
+
+// The same, told to fit four waves per SIMD: the one-pass form and the 8-moment tree form come out a register over
+// the 128-VGPR line otherwise (three waves per SIMD: 0.01 cm-1 6.5 instead of 5.8 ms); the plain two-pass form fits
+// as it is and schedules a little better left alone.
+template <bool TWO_PASS, bool TREE, int K>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void gas_optics_mp_kernel_w4(GrtGasOpticsArgs a, long long fsteps_ll, unsigned ngroups, unsigned perm_stride, int ncell,
+                             int nacc, int halo)
+{
+    mp_kernel_body<TWO_PASS, TREE, K>(a, fsteps_ll, ngroups, perm_stride, ncell, nacc, halo);
 }
 
 // Second pass of the two-pass form: workgroup = (tile of grid points, layer, column).  Stages the moments
@@ -1310,7 +1328,7 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
         }
         else if (tree)
         {
-            hipLaunchKernelGGL((gas_optics_mp_kernel<true, true, kMom>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
+            hipLaunchKernelGGL((gas_optics_mp_kernel_w4<true, true, kMom>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
                                fsteps, (unsigned)ngroups, golden_stride(ngroups), ncell, nacc, halo);
         }
         else
@@ -1345,7 +1363,7 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
     size_t const lds = mp_lds_bytes(a->tile, ncell, (int)fsteps, a->lay.num_slots);
     GrtGasOpticsArgs b = *a;
     b.rcap = kRcap;
-    hipLaunchKernelGGL((gas_optics_mp_kernel<false, false>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b, fsteps,
+    hipLaunchKernelGGL((gas_optics_mp_kernel_w4<false, false, kMom>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b, fsteps,
                        (unsigned)ngroups, golden_stride(ngroups), ncell, a->tile, 0);
     return (int)hipGetLastError();
 }
