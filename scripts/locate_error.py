@@ -1,0 +1,45 @@
+"""Scratch: where does the fused form differ most from the oracle in one of the randomised cases of
+tests/test_gpu_moment_kernel.py?   PYTHONPATH=.:tests python scripts/locate_error.py SEED"""
+import sys, tempfile
+import numpy as np
+from grtcode_amd import api, synthetic as syn
+from scenario import Band
+from oracle.bindings import Oracle
+
+seed = int(sys.argv[1])
+rng = np.random.default_rng(4242 + seed)
+dw = float(rng.choice([0.1, 0.2, 0.25, 0.5, 1.0, 1.25, 1.5]))
+npts = int(rng.integers(150, 900))
+w0 = float(np.round(rng.choice([1.0, 300.0, 2000.0, 9000.0, 30000.0]) + rng.uniform(0, 50), 2))
+span = npts * dw
+if w0 + span > 50000.0:
+    w0 = 50000.0 - span
+nlines = int(rng.integers(50, 6000))
+V = int(rng.integers(4, 15))
+tmp = tempfile.mkdtemp()
+band = Band(tmp, w0, w0 + span, dw, nlines, seed=int(rng.integers(1, 10**6)), sw=w0 > 3000.0, with_cfc=w0 < 3000.0)
+col = syn.profile(int(rng.integers(0, 50)), V)
+col["p"] = col["p"] * float(rng.choice([0.3, 1.0, 1.0, 2.5]))
+col["t"] = np.clip(col["t"] + float(rng.uniform(-40, 30)), 150.0, 340.0)
+lib = api.load_library(); device = api.create_device(0); orc = Oracle()
+want = band.oracle_tau(orc, orc, lib, col)
+out = {}
+for fast in (2, 3):
+    go, grid = band.gas_optics(device, V, from_file=False)
+    go.tune(fast=fast); band.set_column(go, col)
+    opt = api.OpticsObject(V - 1, grid, device)
+    go.calculate_optical_depth(col["p"], col["t"], opt)
+    out[fast] = opt.read()[0]; opt.destroy(); go.destroy()
+print(f"seed {seed}: dw {dw} w0 {w0} n {band.nw} lines {nlines} V {V} p_surf {col['p'][-1]:.1f} T {col['t'][0]:.0f}-{col['t'][-1]:.0f}")
+for fast, tau in out.items():
+    err = np.abs(tau - want) / want.max(axis=1, keepdims=True)
+    L, f = np.unravel_index(err.argmax(), err.shape)
+    wn = band.w0 + f * dw
+    print(f"fast {fast}: worst {err.max():.2e} at layer {L} (p {0.5*(col['p'][L]+col['p'][L+1]):.3f} mb, T {0.5*(col['t'][L]+col['t'][L+1]):.1f}), point {f} ({wn:.4f} cm-1); tau there {want[L, f]:.4e}, layer max {want[L].max():.4e} at {band.w0 + want[L].argmax()*dw:.4f}")
+    # nearest lines
+    best = []
+    for m in band.mols:
+        v = band.lines[m]["v0"]; k = np.argsort(np.abs(v - wn))[:2]
+        best += [(abs(v[i] - wn), m, v[i], band.lines[m]["s0"][i], band.lines[m]["yair"][i]) for i in k]
+    for d, m, v, s, g in sorted(best)[:3]:
+        print(f"    line of molecule {m} at {v:.6f} (distance {d:.6f} cm-1 = {d/dw:.3f} steps), S {s:.3e}, g_air {g:.3f}")

@@ -2,6 +2,8 @@
 a hierarchy of cells, moment_up_kernel + gas_optics_tree_kernel in k_gas_optics_mp.hip) against the oracle and
 against the ring kernel (fast=2, every window point evaluated).  tests/test_moment_tree.py holds the construction
 in numpy; here every case states which part of the kernels it is there for."""
+import os
+
 import numpy as np
 import pytest
 
@@ -108,7 +110,7 @@ def test_near_field_wider_than_the_window_falls_back(tmp_path, oracle, lib, devi
     check(band, device, oracle, lib, col, tree=False)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GRT_STRESS_SEEDS", 6))))   # more seeds: a soak run
 def test_randomised_fine_grids(tmp_path, oracle, lib, device, seed):
     rng = np.random.default_rng(777 + seed)
     dw = float(rng.choice([0.04, 0.02, 0.01, 0.005, 0.0025]))
