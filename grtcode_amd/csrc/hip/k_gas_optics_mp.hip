@@ -154,12 +154,14 @@ __device__ __forceinline__ bool voigt_reg1(float y, bool lorentz)
 // (r - delta)^-4, ^-6, ^-8, expanded about the cell centre like the Lorentzian), so the near field only has to
 // reach where that series is good -- X1 = max(13, 8 y_max) Doppler widths, which also covers XLIM1 <= 12.85 --
 // instead of all of region 1.  Cost: the series goes on beyond a line's XLIM0, where the reference has switched
-// back to the Lorentzian: <= 1.5 cl/XLIM0^4, 1e-7 of the line's own peak at y = 4 (3e-8 at y = 2), falling as x^-4.
+// back to the Lorentzian: 1.5 cl/x^4 there, 1e-4 of the line's value at XLIM0 and falling as x^-4 -- 1e-7 of the
+// line's own peak at y = 4 (3e-8 at y = 2); against a layer maximum that is itself a wing value see kFoldWrMax.
 // Elsewhere (some line of the tile may have y > 4: low wavenumbers, high pressures) region 1 is evaluated inside
 // the ring where it lies within rcap grid steps (a performance choice: region-1 points beyond R are picked up
 // line by line in pre-pass 2; shrinking R below that was measured slower).
 // [F0l, F1l): the cells of the tile (one-pass form: including the fsteps cells either side it prepares).
 constexpr double kCorrectedYmax = 4.;
+constexpr float kFoldWrMax = 25.f;      // Doppler units per grid step up to which a line's region 1 is folded (see the kernel)
 __device__ int near_radius(GrtGasOpticsArgs const &a, double const *lay, double const *ms_l, long long F0l, long long F1l,
                            int fsteps, bool *use_moments, bool *corrected, double *zmax = nullptr)
 {
@@ -394,6 +396,18 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         float const wr = wres_f*repwid;
         float const ndcr = -dc*repwid;
 
+        // Region 1 beyond the near field, line by line (`corrected` (tile, layer)s, near_radius): a line whose
+        // region 1 ends inside the near field has no far region-1 point at all; one whose Doppler width is above a
+        // 25th of the grid step (wr <= 25) has it folded into the moments; the few in between -- region 1 reaching
+        // one or two points beyond R -- take pre-pass 2 like every line of an uncorrected tile.  Why 25: the folded
+        // series goes on beyond XLIM0, 1.5/XLIM0^2 = 1e-4 of the value THERE, and where the grid is coarse against
+        // the line the layer's largest tau may itself be a wing value, at up to wr/2 Doppler widths from the
+        // centre: 6.5e-9 (wr/2)^2 of it, 1e-6 at wr = 25 in the worst alignment, 3e-7 on average.
+        float const delta_c = dc*inv_wres_f;
+        bool const reg1_far = valid & voigt_reg1(y, lorentz) & (((float)(R + 1) - fabsf(delta_c))*wr < xlim0);
+        bool const fold = corrected & reg1_far & (wr <= kFoldWrMax);
+        bool const direct_reg1 = valid & !lorentz & (corrected ? reg1_far & (wr > kFoldWrMax) : true);
+
         // ---- moments of the Lorentzian about the cell centre ----
         if (use_moments)
         {
@@ -418,12 +432,10 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                 // region 1 minus the Lorentzian (near_radius): amp cl [c2/q^2 + c3/q^3 + c4/q^4], q = (r - delta)^2 wr^2,
                 // i.e. b4 (r-delta)^-4 + b6 (r-delta)^-6 + b8 (r-delta)^-8, each expanded about the cell centre:
                 // (r - delta)^-n = sum_j C(n-1+j, j) delta^j r^-(n+j); m[i] multiplies r^-(i+2).
-                // Lines without a region 1 (y <= 1e-6, RFM_voigt.c:122-126) take no part.
-                bool const has_reg1 = voigt_reg1(y, lorentz);
                 float const rw2 = rwr*rwr;
-                float const b4 = has_reg1 ? 1.5f*(amp_f*rw2) : 0.f;
-                float const b6 = has_reg1 ? fmaf(-5.f, yq, 1.25f)*((amp_f*rw2)*rw2) : 0.f;
-                float const b8 = has_reg1 ? fmaf(yq, fmaf(10.5f, yq, -8.75f), 0.875f)*(((amp_f*rw2)*rw2)*rw2) : 0.f;
+                float const b4 = fold ? 1.5f*(amp_f*rw2) : 0.f;
+                float const b6 = fold ? fmaf(-5.f, yq, 1.25f)*((amp_f*rw2)*rw2) : 0.f;
+                float const b8 = fold ? fmaf(yq, fmaf(10.5f, yq, -8.75f), 0.875f)*(((amp_f*rw2)*rw2)*rw2) : 0.f;
                 float d4 = b4, d6 = b6, d8 = b8;        // b_n delta^j
 #pragma unroll
                 for (int i = 2; i < K; ++i)
@@ -572,8 +584,8 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         // fine grids, high wavenumbers), as a correction to the Lorentzian the moments supply:
         // cl (1.5 XQ - 0.5 A0) / [(D0+XQ(D2+XQ)) (XQ+YQ)]   (see k_gas_optics.hip) ----
         {
-            int const reach0 = voigt_line ? (int)(xlim0*rwr) + 1 : -1;
-            int const rmax = corrected ? -1 : wave_max_s(reach0);      // (corrected: the moments carry region 1)
+            int const reach0 = direct_reg1 ? (int)(xlim0*rwr) + 1 : -1;       // (folded lines: the moments carry region 1)
+            int const rmax = __ballot(reach0 > R) != 0ull ? wave_max_s(reach0) : -1;
             for (int rr = R + 1; rr <= rmax; ++rr)
             {
 #pragma unroll
@@ -776,9 +788,8 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
     mp_kernel_body<TWO_PASS, TREE, K>(a, fsteps_ll, ngroups, perm_stride, ncell, nacc, halo);
 }
 
-// The same, told to fit four waves per SIMD: the one-pass form and the 8-moment tree form come out a register over
-// the 128-VGPR line otherwise (three waves per SIMD: 0.01 cm-1 6.5 instead of 5.8 ms); the plain two-pass form fits
-// as it is and schedules a little better left alone.
+// The same, told to fit four waves per SIMD: the 8-moment instantiations come out a register over the 128-VGPR
+// line otherwise (three waves per SIMD: 1 cm-1 302 instead of 348 columns/s, 0.01 cm-1 6.5 instead of 5.8 ms).
 template <bool TWO_PASS, bool TREE, int K>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void gas_optics_mp_kernel_w4(GrtGasOpticsArgs a, long long fsteps_ll, unsigned ngroups, unsigned perm_stride, int ncell,
@@ -1333,7 +1344,7 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
         }
         else
         {
-            hipLaunchKernelGGL((gas_optics_mp_kernel<true, false, kMom>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
+            hipLaunchKernelGGL((gas_optics_mp_kernel_w4<true, false, kMom>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
                                fsteps, (unsigned)ngroups, golden_stride(ngroups), ncell, nacc, halo);
         }
         if (a->profile_tag) grt_profile_end(stream, slot);

@@ -17,6 +17,10 @@ from test_gpu_gas_optics import tau_close
 
 pytestmark = pytest.mark.gpu
 FAST_TOL = 2e-6
+# moment kernel against ring kernel: the moments carry Humlicek region 1 on beyond a line's XLIM0, where the reference
+# (and the ring kernel) switch back to the Lorentzian -- 1e-4 of the value there, at most 1e-6 of a layer's largest tau
+# (kFoldWrMax in k_gas_optics_mp.hip); everything else they share to ~2e-7
+BETWEEN_TOL = 1.2e-6
 
 
 def run(band, device, col, fast, tile=0, nslice=0, from_file=False):
@@ -44,7 +48,7 @@ def check(band, device, oracle, lib, col, **kw):
     assert e_mp < FAST_TOL
     assert e_ring < FAST_TOL
     assert e_two < FAST_TOL
-    assert e_between < 5e-7
+    assert e_between < BETWEEN_TOL
     assert e_forms < 3e-7                               # same arithmetic, other groupings of the fp32 ring sums
     return mp, want
 
@@ -122,7 +126,8 @@ def test_line_centres_exactly_on_grid_points(tmp_path, oracle, lib, device):
     assert np.max(np.abs(mp[rows, peak] - want[rows, peak]) / want[rows, peak]) < 2e-6
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("GRT_STRESS_SEEDS", 16))))   # more seeds: a soak run
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GRT_STRESS_FIRST", 0)),
+                                         int(os.environ.get("GRT_STRESS_FIRST", 0)) + int(os.environ.get("GRT_STRESS_SEEDS", 16))))   # soak runs
 def test_randomised_grids_profiles_and_launch_shapes(tmp_path, oracle, lib, device, seed):
     """Random band position, grid spacing (windows of 33 to 501 points), line density, number of levels, surface
     pressure, temperature offset, tile size and line slicing: the one- and two-pass moment kernels and the ring kernel

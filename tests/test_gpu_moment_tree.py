@@ -13,6 +13,10 @@ from test_gpu_gas_optics import tau_close
 
 pytestmark = pytest.mark.gpu
 FAST_TOL = 2e-6
+# moment kernel against ring kernel: the moments carry Humlicek region 1 on beyond a line's XLIM0, where the reference
+# (and the ring kernel) switch back to the Lorentzian -- 1e-4 of the value there, at most 1e-6 of a layer's largest tau
+# (kFoldWrMax in k_gas_optics_mp.hip); everything else they share to ~2e-7
+BETWEEN_TOL = 1.2e-6
 
 
 def run(band, device, col, fast, tile=0):
@@ -38,7 +42,7 @@ def check(band, device, oracle, lib, col, tree=True, tile=0):
     if tree is not None:
         assert (info["fast"] == 3 and info["tree_levels"] > 0) == tree, info
     assert e_tree < FAST_TOL
-    assert e_between < 5e-7
+    assert e_between < BETWEEN_TOL
     return info
 
 
@@ -110,7 +114,8 @@ def test_near_field_wider_than_the_window_falls_back(tmp_path, oracle, lib, devi
     check(band, device, oracle, lib, col, tree=False)
 
 
-@pytest.mark.parametrize("seed", range(int(os.environ.get("GRT_STRESS_SEEDS", 6))))   # more seeds: a soak run
+@pytest.mark.parametrize("seed", range(int(os.environ.get("GRT_STRESS_FIRST", 0)),
+                                         int(os.environ.get("GRT_STRESS_FIRST", 0)) + int(os.environ.get("GRT_STRESS_SEEDS", 6))))   # soak runs
 def test_randomised_fine_grids(tmp_path, oracle, lib, device, seed):
     rng = np.random.default_rng(777 + seed)
     dw = float(rng.choice([0.04, 0.02, 0.01, 0.005, 0.0025]))
@@ -193,4 +198,4 @@ def test_full_3m_point_grid_tree_equals_ring(device):
     (tree, info), (ring, _) = out[3], out[2]
     assert info["fast"] == 3 and info["tree_levels"] == 12 and info["moments"] == 12, info
     assert np.all(np.isfinite(tree)) and tree.min() >= 0.0
-    assert tau_close(tree, ring) < 5e-7
+    assert tau_close(tree, ring) < BETWEEN_TOL
