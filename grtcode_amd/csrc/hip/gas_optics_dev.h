@@ -58,6 +58,28 @@ __device__ __forceinline__ double exp_fast(double x)
     return ldexp((double)r, (int)n);
 }
 
+// exp(x) to ~1e-10 relative, all in fp64 (range reduction, ninth-degree Taylor series of e^t on |t| <= ln(2)/2).
+// For the one place where exp_fast's 1e-7 is not enough: the Lorentz width.  y = REPWID*gamma is rounded to fp32 and
+// Humlicek region 4 (whose fp32 sums cancel) turns ONE ulp of y into up to 1e-6 of the line shape -- the soak runs of
+// the randomised parity cases found 1.5e-6 at line centres in thin layers until y was the reference's own bit for bit.
+__device__ __forceinline__ double exp_fp64(double x)
+{
+    double const z = x*1.4426950408889634;
+    double const n = rint(z);
+    double const t = fma(n, -0.6931471805599453, x) + n*-2.3190468138462996e-17;     // x - n ln 2, ln 2 in two parts
+    double p = 2.7557319223985893e-06;                                                // 1/9!
+    p = fma(p, t, 2.48015873015873e-05);
+    p = fma(p, t, 1.984126984126984e-04);
+    p = fma(p, t, 1.388888888888889e-03);
+    p = fma(p, t, 8.333333333333333e-03);
+    p = fma(p, t, 4.1666666666666664e-02);
+    p = fma(p, t, 1.6666666666666666e-01);
+    p = fma(p, t, 0.5);
+    p = fma(p, t, 1.0);
+    p = fma(p, t, 1.0);
+    return ldexp(p, (int)n);
+}
+
 // kernels.c:34-131 for one (layer, line) + the window of kernels.c:431-437.
 // lay: pavg, tavg, 1/tavg, log(296/tavg); ms: ps, pavg-ps, ns, doppler factor.
 template <bool FAST>
@@ -80,7 +102,7 @@ __device__ __forceinline__ Prepared prepare_line(RawLine const &ln,
     {
         double const invT = lay[2];
         p.snn = ln.s0*exp_fast((c2*en)*invT)*(1.0 - exp_fast((c2*v0)*invT))*q[ln.iso - 1];
-        p.gamma = exp_fast(nexp*lay[3])*fma(yair, pf, yself*ps);
+        p.gamma = exp_fp64(nexp*lay[3])*(yair*pf + yself*ps);
     }
     else
     {
@@ -139,7 +161,7 @@ __device__ __forceinline__ float quot_rounded(float a, float b)
     return fmaf(fmaf(-b, q, a), r, q);
 }
 
-// 1/b likewise (one Newton step: within half an ulp and a little)
+// 1/b likewise (two Newton steps: one leaves the odd last-place difference, which region 4 turns into 1.5e-6)
 template <bool FAST>
 __device__ __forceinline__ float recip_rounded(float b)
 {
@@ -147,7 +169,8 @@ __device__ __forceinline__ float recip_rounded(float b)
     {
         return 1.0f/b;
     }
-    float const r = __builtin_amdgcn_rcpf(b);
+    float r = __builtin_amdgcn_rcpf(b);
+    r = fmaf(fmaf(-b, r, 1.0f), r, r);
     return fmaf(fmaf(-b, r, 1.0f), r, r);
 }
 

@@ -41,6 +41,7 @@ __host__ __device__ inline double moment_separation(int terms)
     return terms == kMomWide ? 3.95 : 7.8;        // 3.95^-12 = 7e-8 = 7.8^-8
 }
 constexpr int kRcap = 12;       // widest near field taken for the sake of region 1 unless the host says otherwise (args.rcap)
+constexpr int kPowTable = 128;  // tabulated temperature exponents n = k/100 (kernels.c:105)
 constexpr int kCellLoop = 3;    // passes of the in-register moment reduction before falling back to per-lane adds
 
 template <int CTRL>
@@ -122,6 +123,13 @@ struct MpQueue
     float far[kClasses][kWaves][kMpQueue];      // the Lorentzian the moments supply at this point (beyond R), to be taken back
     unsigned short idx[kClasses][kWaves][kMpQueue];   // accumulator index f - F0
 };
+
+// (a call, not inline code: the lines that need it -- exponents that are not hundredths -- are rare, and its registers
+// would count against every wave)
+__device__ __attribute__((noinline)) double exp_fp64_call(double x)
+{
+    return exp_fp64(x);
+}
 
 constexpr int binomial(int n, int k)
 {
@@ -246,7 +254,8 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
     long long *range = reinterpret_cast<long long *>(nq + 1);                     // [2]
     double *ms_l = reinterpret_cast<double *>(range + 2);                         // [num_slots][4]
     double *q_l = ms_l + 4*a.lay.num_slots;                                       // [num_slots][GRT_MAX_ISO]
-    float *mom = reinterpret_cast<float *>(q_l + GRT_MAX_ISO*a.lay.num_slots);    // [kMom][ncell]
+    double *ptab = q_l + GRT_MAX_ISO*a.lay.num_slots;                             // [kPowTable]: (296/T)^(k/100)
+    float *mom = reinterpret_cast<float *>(ptab + kPowTable);                     // [kMom][ncell]
     float *invr = mom + (size_t)kMom*ncell;                                       // [fsteps + 1]
 
     int const tid = threadIdx.x;
@@ -277,6 +286,13 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         invr[i] = i > 0 ? 1.0f/(float)i : 0.f;
     }
     stage_column_state(a, cs, layer, ms_l, q_l, tid);
+    // (296/T)^n for n = 0.00, 0.01, ... 1.27 (kernels.c:105): HITRAN writes the exponent with two decimals (F4.2), so a
+    // line looks its factor up instead of raising a power; to 1e-10, because y = REPWID*gamma has to come out as the
+    // reference's fp32 number bit for bit (exp_fp64, gas_optics_dev.h)
+    for (int i = tid; i < kPowTable; i += kBlock)
+    {
+        ptab[i] = exp_fp64((double)((float)i/100.f)*lay[3]);
+    }
     if (wave == 0)
     {
         candidate_range_wave(a, lay, F0l, F1l, TWO_PASS ? 0 : fsteps_ll, slice, range, lane);
@@ -367,8 +383,17 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         // moments): for a near-centre point beyond the near field the queue takes back amp*K_lorentz that
         // the moments supply -- the two products must be of the same amp
         double const amp = valid ? (double)(float)(snn*ms[2]) : 0.;
-        double const gamma = exp_fast((double)ln.nexp*lay[3])
-                             *fma((double)ln.yair, ms[1], (double)ln.yself*ms[0]);       // kernels.c:105-106
+        // (296/T)^n: from the table where n is a whole number of hundredths (any line read from a HITRAN file), else
+        // the one exponential that has to be better than 1e-7; the sum as the reference writes it
+        float const n100 = ln.nexp*100.f, nk = rintf(n100);
+        bool const tabulated = (fabsf(n100 - nk) <= 2e-5f) & (nk >= 0.f) & (nk < (float)kPowTable);
+        double tpow = ptab[tabulated ? (int)nk : 0];
+        if (__ballot(valid & !tabulated) != 0ull)
+        {
+            double const e = exp_fp64_call((double)ln.nexp*lay[3]);
+            tpow = tabulated ? tpow : e;
+        }
+        double const gamma = tpow*((double)ln.yair*ms[1] + (double)ln.yself*ms[0]);     // kernels.c:105-106
         double const alpha = ((double)0.83255461115f*wnoadj)*ms[3];                    // kernels.c:127
         // RFM_voigt.c:94, rounded as the reference's REPWID (see k_gas_optics.hip)
         double const r0 = (double)__builtin_amdgcn_rcpf((float)alpha);
@@ -1202,7 +1227,7 @@ void launch_tree(hipStream_t s, GrtGasOpticsArgs const &b, long long fsteps, int
 
 size_t mp_lds_bytes(int nacc, int ncell, int fsteps, int num_slots)
 {
-    return sizeof(double)*nacc + sizeof(MpQueue) + 2*sizeof(long long) + sizeof(double)*num_slots*(4 + GRT_MAX_ISO)
+    return sizeof(double)*nacc + sizeof(MpQueue) + 2*sizeof(long long) + sizeof(double)*(num_slots*(4 + GRT_MAX_ISO) + kPowTable)
            + sizeof(float)*((size_t)kMom*ncell + fsteps + 1);
 }
 
