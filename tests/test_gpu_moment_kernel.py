@@ -111,6 +111,20 @@ def test_window_narrower_than_near_field_falls_back_to_all_near(tmp_path, oracle
     check(band, device, oracle, lib, col)
 
 
+def test_temperature_exponents_that_are_not_hundredths(tmp_path, oracle, lib, device):
+    """HITRAN writes n_air with two decimals and the kernel tabulates (296/T)^(k/100) per workgroup; lines that come in
+    through grt_add_molecule_lines may carry anything -- negative, above 1.27, seven digits -- and take the direct
+    exponential (a call inside the kernel).  Both in one wave."""
+    band = Band(str(tmp_path), 1200.0, 1500.0, 1.0, 3000, mols=[syn.H2O, syn.CO2, syn.CH4])
+    rng = np.random.default_rng(5)
+    for m in band.lines:
+        n = band.lines[m]["nexp"].copy()
+        odd = rng.random(n.size) < 0.4
+        n[odd] = np.float32(rng.uniform(-0.5, 1.6, odd.sum()))
+        band.lines[m]["nexp"] = n.astype(np.float32).astype(np.float64)
+    check(band, device, oracle, lib, syn.profile(12, 10))
+
+
 def test_line_centres_exactly_on_grid_points(tmp_path, oracle, lib, device):
     """x = 0 at a grid point in every layer (no pressure shift): in the thin upper layers the Lorentzian the ring
     adds there, y/(pi y^2), is hundreds of times the true Voigt value the near-centre queue replaces it with -- the
