@@ -101,7 +101,8 @@ __device__ __forceinline__ Prepared prepare_line(RawLine const &ln,
     if (FAST)
     {
         double const invT = lay[2];
-        p.snn = ln.s0*exp_fast((c2*en)*invT)*(1.0 - exp_fast((c2*v0)*invT))*q[ln.iso - 1];
+        double const x2 = (c2*v0)*invT;       // (1 - e^x cancels in the far infrared: exp_fp64 there, see k_gas_optics_mp.hip)
+        p.snn = ln.s0*exp_fast((c2*en)*invT)*(1.0 - (x2 > -2. ? exp_fp64(x2) : exp_fast(x2)))*q[ln.iso - 1];
         p.gamma = exp_fp64(nexp*lay[3])*(yair*pf + yself*ps);
     }
     else

@@ -377,6 +377,13 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         if (__ballot(valid & (x2 > -20.)) != 0ull)
         {
             stim = 1.0 - exp_fast(x2);
+            // far infrared (nu < ~1.4 T): the difference cancels and exp_fast's 1e-7 comes back divided by it -- 2.7e-6
+            // at 1 cm-1, found by the soak runs; there the exponential is taken to 1e-10
+            if (__ballot(valid & (x2 > -2.)) != 0ull)
+            {
+                double const e = exp_fp64_call(x2);
+                stim = x2 > -2. ? 1.0 - e : stim;
+            }
         }
         double const snn = ln.s0*exp_fast((c2*(double)ln.en)*invT)*stim*q_l[ln.slot*GRT_MAX_ISO + ln.iso - 1];   // :83-85
         // snn*n (kernels.c:459), rounded to fp32 ONCE and used in that form everywhere (ring, queue,
