@@ -1,6 +1,6 @@
 """Where does the fused form differ most from the oracle (and the moment kernel from the ring kernel) in one of the
 randomised cases of tests/test_gpu_moment_kernel.py?   PYTHONPATH=.:tests python scripts/locate_error.py SEED"""
-import sys, tempfile
+import os, sys, tempfile
 import numpy as np
 from grtcode_amd import api, synthetic as syn
 from scenario import Band
@@ -23,6 +23,8 @@ else:
     dw = float(rng.choice([0.1, 0.2, 0.25, 0.5, 1.0, 1.25, 1.5]))
     npts = int(rng.integers(150, 900))
     w0 = float(np.round(rng.choice([1.0, 300.0, 2000.0, 9000.0, 30000.0]) + rng.uniform(0, 50), 2))
+    if os.environ.get("GRT_STRESS_WIDE"):
+        w0 = float(np.round(10.0 ** rng.uniform(0.0, 4.69), 2))
     span = npts * dw
     if w0 + span > 50000.0:
         w0 = 50000.0 - span

@@ -150,6 +150,8 @@ def test_randomised_grids_profiles_and_launch_shapes(tmp_path, oracle, lib, devi
     dw = float(rng.choice([0.1, 0.2, 0.25, 0.5, 1.0, 1.25, 1.5]))
     npts = int(rng.integers(150, 900))
     w0 = float(np.round(rng.choice([1.0, 300.0, 2000.0, 9000.0, 30000.0]) + rng.uniform(0, 50), 2))
+    if os.environ.get("GRT_STRESS_WIDE"):       # soak runs: band positions anywhere, log-uniform
+        w0 = float(np.round(10.0 ** rng.uniform(0.0, 4.69), 2))
     span = npts * dw
     if w0 + span > 50000.0:
         w0 = 50000.0 - span
