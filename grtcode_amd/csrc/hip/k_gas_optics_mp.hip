@@ -169,7 +169,7 @@ __device__ __forceinline__ bool voigt_reg1(float y, bool lorentz)
 // line by line in pre-pass 2; shrinking R below that was measured slower).
 // [F0l, F1l): the cells of the tile (one-pass form: including the fsteps cells either side it prepares).
 constexpr double kCorrectedYmax = 4.;
-constexpr float kFoldWrMax = 25.f;      // Doppler units per grid step up to which a line's region 1 is folded (see the kernel)
+constexpr float kFoldWrMax = 25.f;      // region 1 is folded for lines within kFoldWrMax/2 Doppler widths of their grid point (see the kernel)
 __device__ int near_radius(GrtGasOpticsArgs const &a, double const *lay, double const *ms_l, long long F0l, long long F1l,
                            int fsteps, bool *use_moments, bool *corrected, double *zmax = nullptr)
 {
@@ -429,16 +429,17 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         float const ndcr = -dc*repwid;
 
         // Region 1 beyond the near field, line by line (`corrected` (tile, layer)s, near_radius): a line whose
-        // region 1 ends inside the near field has no far region-1 point at all; one whose Doppler width is above a
-        // 25th of the grid step (wr <= 25) has it folded into the moments; the few in between -- region 1 reaching
-        // one or two points beyond R -- take pre-pass 2 like every line of an uncorrected tile.  Why 25: the folded
-        // series goes on beyond XLIM0, 1.5/XLIM0^2 = 1e-4 of the value THERE, and where the grid is coarse against
-        // the line the layer's largest tau may itself be a wing value, at up to wr/2 Doppler widths from the
-        // centre: 6.5e-9 (wr/2)^2 of it, 1e-6 at wr = 25 in the worst alignment, 3e-7 on average.
+        // region 1 ends inside the near field has no far region-1 point at all; one whose centre lies within
+        // kFoldWrMax/2 = 12.5 Doppler widths of its grid point has it folded into the moments; the few others --
+        // coarse grid against the line, centre between two points, region 1 reaching one or two points beyond R --
+        // take pre-pass 2 like every line of an uncorrected tile.  Why: the folded series goes on beyond XLIM0,
+        // 1.5/XLIM0^2 = 1e-4 of the line's value THERE, and the layer's largest tau is at least the line's value at
+        // its own grid point, x_c = |delta| wr Doppler widths from the centre: the excess is at most
+        // 6.5e-9 x_c^2 of it -- 1e-6 at x_c = 12.5.
         float const delta_c = dc*inv_wres_f;
         bool const reg1_far = valid & voigt_reg1(y, lorentz) & (((float)(R + 1) - fabsf(delta_c))*wr < xlim0);
-        bool const fold = corrected & reg1_far & (wr <= kFoldWrMax);
-        bool const direct_reg1 = valid & !lorentz & (corrected ? reg1_far & (wr > kFoldWrMax) : true);
+        bool const fold = corrected & reg1_far & (fabsf(delta_c)*wr <= 0.5f*kFoldWrMax);
+        bool const direct_reg1 = valid & !lorentz & (corrected ? reg1_far & !fold : true);
 
         // ---- moments of the Lorentzian about the cell centre ----
         if (use_moments)
