@@ -21,18 +21,21 @@ if len(sys.argv) > 2 and sys.argv[2] == "tree":        # the cases of tests/test
 else:
     rng = np.random.default_rng(4242 + seed)
     dw = float(rng.choice([0.1, 0.2, 0.25, 0.5, 1.0, 1.25, 1.5]))
+    wide = os.environ.get("GRT_STRESS_WIDE", "")     # soak runs: "1" band anywhere, "2" also grids, pressures, levels
+    if wide == "2":
+        dw = float(rng.choice([0.05, 0.1, 0.25, 0.5, 1.0, 2.0, 5.0]))
     npts = int(rng.integers(150, 900))
     w0 = float(np.round(rng.choice([1.0, 300.0, 2000.0, 9000.0, 30000.0]) + rng.uniform(0, 50), 2))
-    if os.environ.get("GRT_STRESS_WIDE"):
+    if wide:
         w0 = float(np.round(10.0 ** rng.uniform(0.0, 4.69), 2))
     span = npts * dw
     if w0 + span > 50000.0:
         w0 = 50000.0 - span
     nlines = int(rng.integers(50, 6000))
-    V = int(rng.integers(4, 15))
+    V = int(rng.integers(4, 15)) if wide != "2" else int(rng.integers(4, 40))
     band = Band(tmp, w0, w0 + span, dw, nlines, seed=int(rng.integers(1, 10**6)), sw=w0 > 3000.0, with_cfc=w0 < 3000.0)
     col = syn.profile(int(rng.integers(0, 50)), V)
-col["p"] = col["p"] * float(rng.choice([0.3, 1.0, 1.0, 2.5]))
+col["p"] = col["p"] * (float(rng.choice([0.3, 1.0, 1.0, 2.5])) if os.environ.get("GRT_STRESS_WIDE", "") != "2" else float(10.0 ** rng.uniform(-1.5, 0.7)))
 col["t"] = np.clip(col["t"] + float(rng.uniform(-40, 30)), 150.0, 340.0)
 lib = api.load_library(); device = api.create_device(0); orc = Oracle()
 want = band.oracle_tau(orc, orc, lib, col)

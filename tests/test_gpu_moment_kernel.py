@@ -49,7 +49,9 @@ def check(band, device, oracle, lib, col, **kw):
     assert e_ring < FAST_TOL
     assert e_two < FAST_TOL
     assert e_between < BETWEEN_TOL
-    assert e_forms < 3e-7                               # same arithmetic, other groupings of the fp32 ring sums
+    # same arithmetic, other groupings of the fp32 ring sums (where the one-pass form does not apply -- wide windows --
+    # fast=1 is the ring kernel itself and the comparison is the one above)
+    assert e_forms < (3e-7 if e_between > 1e-12 else BETWEEN_TOL)
     return mp, want
 
 
@@ -148,19 +150,22 @@ def test_randomised_grids_profiles_and_launch_shapes(tmp_path, oracle, lib, devi
     all within the fused form's tolerance of the oracle, and within rounding of each other."""
     rng = np.random.default_rng(4242 + seed)
     dw = float(rng.choice([0.1, 0.2, 0.25, 0.5, 1.0, 1.25, 1.5]))
+    wide = os.environ.get("GRT_STRESS_WIDE", "")     # soak runs: "1" band anywhere, "2" also grids, pressures, levels
+    if wide == "2":
+        dw = float(rng.choice([0.05, 0.1, 0.25, 0.5, 1.0, 2.0, 5.0]))
     npts = int(rng.integers(150, 900))
     w0 = float(np.round(rng.choice([1.0, 300.0, 2000.0, 9000.0, 30000.0]) + rng.uniform(0, 50), 2))
-    if os.environ.get("GRT_STRESS_WIDE"):       # soak runs: band positions anywhere, log-uniform
+    if wide:
         w0 = float(np.round(10.0 ** rng.uniform(0.0, 4.69), 2))
     span = npts * dw
     if w0 + span > 50000.0:
         w0 = 50000.0 - span
     nlines = int(rng.integers(50, 6000))
-    V = int(rng.integers(4, 15))
+    V = int(rng.integers(4, 15)) if wide != "2" else int(rng.integers(4, 40))
     band = Band(str(tmp_path), w0, w0 + span, dw, nlines, seed=int(rng.integers(1, 10**6)), sw=w0 > 3000.0,
                 with_cfc=w0 < 3000.0)
     col = syn.profile(int(rng.integers(0, 50)), V)
-    col["p"] = col["p"] * float(rng.choice([0.3, 1.0, 1.0, 2.5]))
+    col["p"] = col["p"] * (float(rng.choice([0.3, 1.0, 1.0, 2.5])) if os.environ.get("GRT_STRESS_WIDE", "") != "2" else float(10.0 ** rng.uniform(-1.5, 0.7)))
     col["t"] = np.clip(col["t"] + float(rng.uniform(-40, 30)), 150.0, 340.0)
     tile = int(rng.choice([0, 0, 64, 128, 256, 512]))
     nslice = int(rng.choice([0, 0, 1, 2, 5]))
