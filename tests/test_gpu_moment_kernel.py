@@ -45,6 +45,10 @@ def check(band, device, oracle, lib, col, **kw):
     e_two, e_forms = tau_close(two, want), tau_close(two, mp)
     print(f"moment kernel vs oracle {e_mp:.2e}; ring kernel vs oracle {e_ring:.2e}; moment vs ring {e_between:.2e}; "
           f"two-pass vs oracle {e_two:.2e}, vs one-pass {e_forms:.2e}")
+    if os.environ.get("GRT_STRESS_STRICT"):             # soak runs: the reference-order form on the same case
+        e_strict = tau_close(run(band, device, col, 0, **kw), want)
+        print(f"reference-order form vs oracle {e_strict:.2e}")
+        assert e_strict < 1e-11
     assert e_mp < FAST_TOL
     assert e_ring < FAST_TOL
     assert e_two < FAST_TOL
