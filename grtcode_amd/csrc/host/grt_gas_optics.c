@@ -1368,30 +1368,44 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
                 a->tree_levels = levels;
                 a->nslice = 1;
                 double const w_top = a->w0 + ((double)a->nw + (double)fsteps)*a->wres;
-                if (im->tile == 0)
+                /* Cell tiles and moments per cell, in order of preference (measured on 0.001-0.01 cm-1, 10^6 lines):
+                   two cells per line and more -- tiles of 1 024 cells (3 workgroups per CU), moments added straight to
+                   global memory lane by lane, twelve of them (half the near field in the pressure-broadened layers);
+                   denser lines -- tiles of 512 cells (256 below half a cell per line), eight moments reduced in
+                   registers and kept in LDS.  Each falls back to the other, then to narrower tiles, where the
+                   first pass's tile + 2*halo accumulators do not fit LDS. */
+                uint64_t const per_line = a->lines.n > 0 ? a->nw/a->lines.n : a->nw;
+                int sparse_tile = 1024;
+                while ((uint64_t)sparse_tile < 128*per_line && sparse_tile < 2048) sparse_tile <<= 1;
+                int const dense_tile = 2*a->nw >= a->lines.n ? 512 : 256;
+                int cand[8], ncand = 0;
+                if (im->tile != 0)
                 {
-                    /* sparse lines (a fraction of a line per cell): cell tiles wide enough to give each of a
-                       workgroup's four waves its 64 lines a few times over */
-                    uint64_t const per_line = a->lines.n > 0 ? a->nw/a->lines.n : a->nw;
-                    a->tile = 256;
-                    while ((uint64_t)a->tile < 512*per_line && a->tile < 4096) a->tile <<= 1;
-                    while ((uint64_t)a->tile > a->nw && a->tile > 64) a->tile >>= 1;
+                    cand[ncand++] = im->tile;
                 }
-                /* tiles of more than 512 cells add their moments straight to global memory, lane by lane, and
-                   afford twelve of them: half the near field in the pressure-broadened layers.  The first pass
-                   keeps tile + 2*halo accumulators in LDS: narrower cell tiles where that is too much. */
-                for (;;)
+                else if (per_line >= 2)
                 {
+                    cand[ncand++] = sparse_tile; cand[ncand++] = 1024; cand[ncand++] = dense_tile;
+                    cand[ncand++] = 256; cand[ncand++] = 128; cand[ncand++] = 64;
+                }
+                else
+                {
+                    cand[ncand++] = dense_tile; cand[ncand++] = 1024; cand[ncand++] = 256;
+                    cand[ncand++] = 128; cand[ncand++] = 64;
+                }
+                for (int k = 0; k < ncand; ++k)
+                {
+                    a->tile = cand[k];
+                    while ((uint64_t)a->tile > a->nw && a->tile > 64) a->tile >>= 1;
                     a->mom_terms = a->tile > 512 ? 12 : 8;
                     a->halo = near_halo_bound(go, ncol, w_top, a->wres, grt_gas_optics_moment_separation(a->mom_terms));
                     a->rcap = a->halo;
                     a->gmom_stride = grt_gas_optics_moment_floats(a->nw, a->tree_levels, a->mom_terms);
                     a->gmom = (float *)8;       /* (any non-null value: the question is about sizes) */
-                    if (im->tile != 0 || a->tile <= 64 || grt_gas_optics_mp_applicable(a))
+                    if (grt_gas_optics_mp_applicable(a))
                     {
                         break;
                     }
-                    a->tile >>= 1;
                 }
             }
             a->gmom_stride = grt_gas_optics_moment_floats(a->nw, a->tree_levels, a->mom_terms);

@@ -60,8 +60,8 @@ def test_0p005_beyond_the_single_level_kernels(tmp_path, oracle, lib, device, ti
     band = Band(str(tmp_path), 2000.0, 2030.0, 0.005, 1500)
     info = check(band, device, oracle, lib, syn.profile(4, 7), tile=tile)
     assert info["tree_levels"] == 10 and info["halo"] > 50
-    # four cells per line: the automatic tile is 2 048 cells, moments straight to global memory, twelve of them
-    assert (info["moments"], info["tile"]) == ((12, 2048) if tile == 0 else (8, tile)), info
+    # four cells per line: the automatic tile is 1 024 cells, moments straight to global memory, twelve of them
+    assert (info["moments"], info["tile"]) == ((12, 1024) if tile == 0 else (8, tile)), info
 
 
 def test_high_pressure_wide_lorentz_lines(tmp_path, oracle, lib, device):
@@ -106,12 +106,24 @@ def test_no_lines_at_all_leaves_the_continua(tmp_path, oracle, lib, device):
 
 
 def test_near_field_wider_than_the_window_falls_back(tmp_path, oracle, lib, device):
-    """0.04 cm-1 (625 points a side) under 40 atm: the moment bound asks for a near field beyond the window, so
-    the tree form does not apply and the library falls back to the forms that treat the whole window as near."""
+    """0.04 cm-1 (625 points a side) under 100 atm: the moment bound asks for a near field beyond the window even with
+    twelve moments, so the tree form does not apply and the library falls back to the forms that treat the whole
+    window as near."""
+    band = Band(str(tmp_path), 500.0, 560.0, 0.04, 1500)
+    col = syn.profile(3, 7)
+    col["p"] = col["p"] * 100.0
+    check(band, device, oracle, lib, col, tree=False)
+
+
+def test_wide_lorentz_lines_take_twelve_moments_where_eight_do_not_fit(tmp_path, oracle, lib, device):
+    """The same grid under 40 atm: with eight moments the near field (7.8 |z|max) is wider than the window, with twelve
+    (3.95 |z|max) it fits -- the library prefers the sparse-line form (tiles of 1 024 cells, moments straight to global
+    memory) to falling back, dense lines or not."""
     band = Band(str(tmp_path), 500.0, 560.0, 0.04, 1500)
     col = syn.profile(3, 7)
     col["p"] = col["p"] * 40.0
-    check(band, device, oracle, lib, col, tree=False)
+    info = check(band, device, oracle, lib, col)
+    assert info["moments"] == 12 and info["tile"] == 1024, info
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("GRT_STRESS_FIRST", 0)),
