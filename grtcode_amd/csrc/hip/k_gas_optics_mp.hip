@@ -112,16 +112,22 @@ __device__ __forceinline__ float row_sum_transposed(float const (&m)[8], bool b3
 // class of formula (voigt_class), so that a batch of 64 points runs ONE formula with all lanes busy:
 // evaluated unsorted, a batch pays for every formula present in it (~4x the work of the usual mix).
 constexpr int kClasses = 3;
-constexpr int kMpQueue = 96;    // entries per (class, wave): batches of 64 leave at most 63 behind (64 and 128 measured slower)
+// entries per (class, wave): batches of 64 leave at most 63 behind.  96 where lines are dense (1 cm-1: 64 and 128 both
+// measured slower); 64 in the tree form, whose first pass is short of LDS (0.001 cm-1: four workgroups per CU instead
+// of three, 42 -> 39 ms) and whose pushes mostly come as full batches of one class
+constexpr int kMpQueue = 96;
+constexpr int kMpQueueTree = 64;
 
+template <int CAP>
 struct MpQueue
 {
-    float amp[kClasses][kWaves][kMpQueue];      // S(T)*N_s of the line (fp32: 6e-8 of that line's value)
-    float xi[kClasses][kWaves][kMpQueue];
-    float y[kClasses][kWaves][kMpQueue];
-    float repwid[kClasses][kWaves][kMpQueue];
-    float far[kClasses][kWaves][kMpQueue];      // the Lorentzian the moments supply at this point (beyond R), to be taken back
-    unsigned short idx[kClasses][kWaves][kMpQueue];   // accumulator index f - F0
+    static constexpr int capacity = CAP;
+    float amp[kClasses][kWaves][CAP];      // S(T)*N_s of the line (fp32: 6e-8 of that line's value)
+    float xi[kClasses][kWaves][CAP];
+    float y[kClasses][kWaves][CAP];
+    float repwid[kClasses][kWaves][CAP];
+    float far[kClasses][kWaves][CAP];      // the Lorentzian the moments supply at this point (beyond R), to be taken back
+    unsigned short idx[kClasses][kWaves][CAP];   // accumulator index f - F0
 };
 
 // (a call, not inline code: the lines that need it -- exponents that are not hundredths -- are rare, and its registers
@@ -221,8 +227,8 @@ __device__ int near_radius(GrtGasOpticsArgs const &a, double const *lay, double 
     return *use_moments ? R : fsteps;
 }
 
-template <int CLASS>
-__device__ __forceinline__ void drain_class(double *acc, MpQueue const *q, int wave, int first, int count, int lane)
+template <int CLASS, typename Queue>
+__device__ __forceinline__ void drain_class(double *acc, Queue const *q, int wave, int first, int count, int lane)
 {
     for (int i = first + lane; i < first + count; i += 64)
     {
@@ -250,7 +256,8 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int const fsteps = (int)fsteps_ll;
     double *acc = reinterpret_cast<double *>(smem);                               // [nacc]
-    MpQueue *nq = reinterpret_cast<MpQueue *>(smem + sizeof(double)*nacc);
+    using Queue = MpQueue<TREE ? kMpQueueTree : kMpQueue>;
+    Queue *nq = reinterpret_cast<Queue *>(smem + sizeof(double)*nacc);
     long long *range = reinterpret_cast<long long *>(nq + 1);                     // [2]
     double *ms_l = reinterpret_cast<double *>(range + 2);                         // [num_slots][4]
     double *q_l = ms_l + 4*a.lay.num_slots;                                       // [num_slots][GRT_MAX_ISO]
@@ -582,7 +589,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                             continue;
                         }
                         int const npush = __popcll(mk);
-                        if (qcount[q] + npush > kMpQueue)
+                        if (qcount[q] + npush > Queue::capacity)
                         {
                             drain(q, 0, qcount[q]);
                             qcount[q] = 0;
@@ -1233,9 +1240,9 @@ void launch_tree(hipStream_t s, GrtGasOpticsArgs const &b, long long fsteps, int
                        tree_lds_bytes(b.tile, b.lay.num_slots, ntab), s, b, fsteps, shift, ntab);
 }
 
-size_t mp_lds_bytes(int nacc, int ncell, int fsteps, int num_slots)
+size_t mp_lds_bytes(int nacc, int ncell, int fsteps, int num_slots, bool tree = false)
 {
-    return sizeof(double)*nacc + sizeof(MpQueue) + 2*sizeof(long long) + sizeof(double)*(num_slots*(4 + GRT_MAX_ISO) + kPowTable)
+    return sizeof(double)*nacc + (tree ? sizeof(MpQueue<kMpQueueTree>) : sizeof(MpQueue<kMpQueue>)) + 2*sizeof(long long) + sizeof(double)*(num_slots*(4 + GRT_MAX_ISO) + kPowTable)
            + sizeof(float)*((size_t)kMom*ncell + fsteps + 1);
 }
 
@@ -1276,7 +1283,7 @@ extern "C" int grt_gas_optics_mp_applicable(GrtGasOpticsArgs const *a)
                && a->gmom_stride >= level_offset(a->nw, a->tree_levels + 1, terms)
                && level_offset(a->nw, a->tree_levels + 1, terms) < 0xffffffffull
                && a->tile + 2*a->halo <= 65535
-               && mp_lds_bytes(a->tile + 2*a->halo, direct ? 0 : a->tile, 0, a->lay.num_slots) <= 64*1024
+               && mp_lds_bytes(a->tile + 2*a->halo, direct ? 0 : a->tile, 0, a->lay.num_slots, true) <= 64*1024
                && tree_lds_bytes(a->tile, a->lay.num_slots, (a->tile + 2*a->halo)/a->tile + 2) <= 64*1024;
     }
     if (fsteps > 4096)
@@ -1364,7 +1371,7 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
         }
         int slot = a->profile_tag ? grt_profile_begin(stream, a->profile_tag) : -1;
         int const ncell = (tree && a->tile > kDirectTile) ? 0 : a->tile;
-        size_t const lds = mp_lds_bytes(nacc, ncell, 0, a->lay.num_slots);
+        size_t const lds = mp_lds_bytes(nacc, ncell, 0, a->lay.num_slots, tree);
         if (wide)
         {
             hipLaunchKernelGGL((gas_optics_mp_kernel<true, true, kMomWide>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
