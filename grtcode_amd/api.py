@@ -135,10 +135,10 @@ set_cia_ppmv calculate_optical_depth get_num_molecules inittips_d Q
 create_longwave destroy_longwave calculate_lw_fluxes
 create_shortwave destroy_shortwave calculate_sw_fluxes rayleigh_scattering
 create_solar_flux destroy_solar_flux disort_shortwave
-grt_tips_load grt_tips_reset grt_tips_is_table grt_sizeof grt_add_molecule_lines grt_gas_optics_tune grt_gas_optics_last_launch grt_hitran_index_stats
+grt_tips_load grt_tips_reset grt_tips_is_table grt_tips_source grt_sizeof grt_add_molecule_lines grt_gas_optics_tune grt_gas_optics_last_launch grt_hitran_index_stats
 grt_optical_depth_batch grt_pipeline_create grt_pipeline_destroy grt_pipeline_run grt_pipeline_sync
 grt_pipeline_stream grt_pipeline_views grt_device_malloc grt_device_free grt_device_to_host
-grt_host_to_device grt_debug_line_prep grt_profile_enable grt_profile_read
+grt_host_to_device grt_debug_line_prep grt_debug_partition_functions grt_profile_enable grt_profile_read
 grt_err_begin grt_err_frame grt_log grt_gmalloc grt_gfree grt_gmemset grt_gmemcpy
 """.split()
 
@@ -339,6 +339,13 @@ class GasOpticsObject:
                                                ws.ctypes.data_as(C.POINTER(C.c_int64)),
                                                we.ctypes.data_as(C.POINTER(C.c_int64))))
         return dict(slot=slot, v0=v0, vnn=f[0], snn=f[1], gamma=f[2], alpha=f[3], win_s=ws, win_e=we)
+
+    def debug_partition_functions(self, p_mb, t):
+        """1/Q(T_layer, iso) as the device's column state holds it: [num_molecules][L][18]."""
+        p_mb, t = _f64(p_mb).copy(), _f64(t).copy()
+        q = np.zeros((self.c.num_molecules, self.num_levels - 1, 18))
+        check(self.lib.grt_debug_partition_functions(C.byref(self.c), _dp(p_mb), _dp(t), _dp(q)))
+        return q
 
     def destroy(self):
         check(self.lib.destroy_gas_optics(C.byref(self.c)))

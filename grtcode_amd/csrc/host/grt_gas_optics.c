@@ -66,15 +66,29 @@ static int host_lines_reserve(GrtHostLines *l, uint64_t cap)
     return GRTCODE_SUCCESS;
 }
 
-/* parse_HITRAN_file.c:372-384: S <- S * Q(296)/(e^{c2 E/296} (1 - e^{c2 nu/296})) */
-static void rescale_strengths(int mol_id, GrtHostLines *l)
+/* parse_HITRAN_file.c:372-384: S <- S * Q(296)/(e^{c2 E/296} (1 - e^{c2 nu/296})).  The host keeps the
+   tabulated 296 K strengths; this factor is applied when the device store is built (upload_lines), with
+   the partition sums of the provider current at that moment (grt_tips.c), so that a table loaded after
+   add_molecule() is never mixed with strengths scaled by another provider. */
+void grt_rescale_strengths(int mol_id, uint64_t n, uint8_t const *iso, double const *v0, float const *en,
+                           double *s0)
 {
     fp_t const tref = 296.f;
     fp_t const c2 = -1.4387686f;
-    for (uint64_t i = 0; i < l->n; ++i)
+    fp_t q296[GRT_MAX_ISO + 1];
+    for (int k = 1; k <= GRT_MAX_ISO; ++k)
     {
-        fp_t const en = l->en[i];
-        l->s0[i] *= Q(mol_id, tref, l->iso[i])/(exp(c2*en/tref)*(1.f - exp(c2*l->v0[i]/tref)));
+        q296[k] = -1.;
+    }
+    for (uint64_t i = 0; i < n; ++i)
+    {
+        int const k = iso[i];
+        if (q296[k] < 0.)
+        {
+            q296[k] = Q(mol_id, tref, k);
+        }
+        fp_t const e = en[i];
+        s0[i] *= q296[k]/(exp(c2*e/tref)*(1.f - exp(c2*v0[i]/tref)));
     }
 }
 
@@ -413,8 +427,7 @@ int grt_parse_hitran(char const *path, int mol_id, double w0, double wn, GrtHost
             }
         }
     }
-    rescale_strengths(mol_id, out);
-    return GRTCODE_SUCCESS;
+    return GRTCODE_SUCCESS;      /* strengths as tabulated: see grt_rescale_strengths */
 }
 
 /* Two-column (or 1+k column) CSV -> values on the spectral grid: column 0 = wavenumber,
@@ -776,7 +789,6 @@ EXTERN int grt_add_molecule_lines(GasOptics_t *gas_optics, int molecule_id, uint
         lines.nexp[k] = (float)nexp[j];
         lines.delta[k] = (float)delta[j];
     }
-    rescale_strengths(molecule_id, &lines);
     int const rc = register_molecule(gas_optics, molecule_id, &lines, w0, wn);
     grt_free_host_lines(&lines);
     GRT_TRY(rc);
@@ -1000,6 +1012,18 @@ static int upload_lines(GasOptics_t *go, SortKey const *keys, uint64_t total, Gr
         if (h->yself[j] > st->yself_max[keys[k].slot]) st->yself_max[keys[k].slot] = h->yself[j];
         if (fabs((double)h->nexp[j]) > st->nmax) st->nmax = fabs((double)h->nexp[j]);
     }
+    /* strengths: tabulated -> the reference's pre-scaled form, molecule by molecule (runs of equal slot
+       are not contiguous in a merged store, so go line by line through a one-element view) */
+    {
+        uint64_t k = 0;
+        while (k < total)
+        {
+            uint64_t e = k + 1;
+            while (e < total && slot[e] == slot[k]) ++e;
+            grt_rescale_strengths(go->mols[slot[k]].id, e - k, iso + k, v0 + k, en + k, s0 + k);
+            k = e;
+        }
+    }
     int rc = grt_dev_alloc(go->device, block, bytes);
     void *s = grt_dev_stream(go->device);
     if (rc == GRTCODE_SUCCESS) rc = grt_dev_upload(go->device, *block, host, bytes, s);
@@ -1033,6 +1057,7 @@ static int build_store(GasOptics_t *go)
     if (total == 0)
     {
         im->store_dirty = 0;
+        im->store_tips_generation = grt_tips_generation();
         return GRTCODE_SUCCESS;
     }
     SortKey *keys = malloc(sizeof(SortKey)*total);
@@ -1072,6 +1097,7 @@ static int build_store(GasOptics_t *go)
     /* expose the device arrays through the public struct of the FIRST molecule only as
        documentation of where they live; per-molecule views do not exist in a merged store */
     im->store_dirty = 0;
+    im->store_tips_generation = grt_tips_generation();
     GRT_INFO("Line store: %zu lines, %zu bytes on device %d.", (size_t)total, bytes, go->device);
     return GRTCODE_SUCCESS;
 }
@@ -1117,8 +1143,9 @@ int grt_gas_optics_prepare(GasOptics_t *go, int ncol)
     GRT_REQUIRE_PTR(go);
     GRT_REQUIRE_PTR(go->impl);
     GrtGasOpticsImpl *im = impl_of(go);
-    if (im->store_dirty)
+    if (im->store_dirty || im->store_tips_generation != grt_tips_generation())
     {
+        /* (a partition-sum table loaded or dropped since the store was built changes Q(296) in every strength) */
         GRT_TRY(build_store(go));
     }
     if (go->optical_depth_method != line_sample && im->bins_block == NULL)
@@ -1570,6 +1597,8 @@ EXTERN int calculate_optical_depth(GasOptics_t * const gas_optics, fp_t * const 
     GRT_TRY(compare_spectral_grids(&gas_optics->grid, &optics->grid, &same));
     GRT_REQUIRE_EQ(same, 1);
     GRT_TRY(grt_gas_optics_prepare(gas_optics, 1));
+    /* the pinned column-state buffer may still be feeding a batch upload (grt_optical_depth_batch is asynchronous) */
+    GRT_TRY(grt_gas_optics_wait_staging(gas_optics));
     GrtGasOpticsImpl *im = impl_of(gas_optics);
     GRT_TRY(grt_column_state(gas_optics, pressure, temperature, gas_optics->x, gas_optics->x_cfc,
                              gas_optics->x_cia, im->colstate_h));
@@ -1659,9 +1688,11 @@ EXTERN int grt_debug_line_prep(GasOptics_t *gas_optics, fp_t *pressure, fp_t *te
     Device_t const dev = gas_optics->device;
     int const L = gas_optics->num_layers;
     void *s = grt_dev_stream(dev);
+    GRT_TRY(grt_gas_optics_wait_staging(gas_optics));
     GRT_TRY(grt_column_state(gas_optics, pressure, temperature, gas_optics->x, gas_optics->x_cfc,
                              gas_optics->x_cia, im->colstate_h));
     GRT_TRY(grt_dev_upload(dev, im->colstate_d, im->colstate_h, sizeof(double)*im->layout.stride, s));
+    GRT_TRY(grt_dev_event_record(dev, &im->colstate_uploaded, s));
     size_t const cells = (size_t)L*N;
     double *d = NULL;
     GRT_TRY(grt_dev_alloc(dev, (void **)&d, sizeof(double)*cells*6));
@@ -1682,5 +1713,30 @@ EXTERN int grt_debug_line_prep(GasOptics_t *gas_optics, fp_t *pressure, fp_t *te
     if (rc == GRTCODE_SUCCESS) rc = grt_dev_sync(dev, s);
     grt_dev_free(dev, d);
     GRT_TRY(rc);
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN int grt_debug_partition_functions(GasOptics_t *gas_optics, fp_t *pressure, fp_t *temperature, double *q_out)
+{
+    GRT_REQUIRE_PTR(gas_optics);
+    GRT_REQUIRE_PTR(gas_optics->impl);
+    GRT_REQUIRE_PTR(pressure);
+    GRT_REQUIRE_PTR(temperature);
+    GRT_REQUIRE_PTR(q_out);
+    GRT_TRY(grt_gas_optics_prepare(gas_optics, 1));
+    GRT_TRY(grt_gas_optics_wait_staging(gas_optics));
+    GrtGasOpticsImpl *im = impl_of(gas_optics);
+    Device_t const dev = gas_optics->device;
+    void *s = grt_dev_stream(dev);
+    GRT_TRY(grt_column_state(gas_optics, pressure, temperature, gas_optics->x, gas_optics->x_cfc,
+                             gas_optics->x_cia, im->colstate_h));
+    GRT_TRY(grt_dev_upload(dev, im->colstate_d, im->colstate_h, sizeof(double)*im->layout.stride, s));
+    GRT_TRY(grt_dev_event_record(dev, &im->colstate_uploaded, s));
+    size_t const count = (size_t)gas_optics->num_molecules*(size_t)gas_optics->num_layers*GRT_MAX_ISO;
+    if (count > 0)
+    {
+        GRT_TRY(grt_dev_download(dev, q_out, im->colstate_d + im->layout.off_q, sizeof(double)*count, s));
+    }
+    GRT_TRY(grt_dev_sync(dev, s));
     return GRTCODE_SUCCESS;
 }

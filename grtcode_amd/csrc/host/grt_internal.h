@@ -73,6 +73,7 @@ typedef struct GrtGasOpticsImpl
 {
     GrtHostLines host[NUM_MOLS];   /* by slot (order of add_molecule) */
     int store_dirty;               /* merged device store must be (re)built */
+    unsigned long store_tips_generation;   /* partition-sum provider the store's strengths were scaled with */
     GrtLineStore store;            /* device SoA, sorted by centre */
     void *store_block;             /* single device allocation backing `store` */
     /* sweep methods only: one store per molecule (each sorted by centre), prep/sort scratch, bin arrays */
@@ -111,6 +112,8 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
 /* loaders */
 int grt_parse_hitran(char const *path, int mol_id, double w0, double wn, GrtHostLines *out);
 void grt_free_host_lines(GrtHostLines *l);
+void grt_rescale_strengths(int mol_id, uint64_t n, uint8_t const *iso, double const *v0, float const *en, double *s0);
+unsigned long grt_tips_generation(void);   /* bumped by grt_tips_load / grt_tips_reset */
 int grt_load_table_on_grid(char const *path, int expect_cols, SpectralGrid_t const *grid,
                            fp_t *out /* host [n], zero-filled then interpolated */);
 

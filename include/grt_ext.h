@@ -14,14 +14,21 @@
 
 /* ---- partition sums (replaces gas-optics/src/tips2017.c, a missing blob) ----------
  * Q(mol,T,iso) is served from a user-supplied table when one is loaded, otherwise from
- * a documented analytic surrogate Q296(mol) * (T/296)^beta (beta = 1 for linear
- * molecules, 1.5 otherwise).  Only ratios Q(296)/Q(T) reach the optical depths
- * (parse_HITRAN_file.c:382 x kernels.c:62,85).
+ * a closed-form model: classical rotor x harmonic oscillators,
+ * Q296(mol,iso) * (T/296)^beta * Qvib(T)/Qvib(296) (beta = 1 for linear molecules, 1.5
+ * otherwise; within 0.1 % of the five TIPS-2017 values of test_tips2017.c:34-65), with a
+ * warning on stderr the first time a molecule is served that way.  Only ratios Q(296)/Q(T)
+ * reach the optical depths (parse_HITRAN_file.c:382 x kernels.c:62,85).
  * Table file: CSV with header, rows "mol_id,iso,T,Q", T ascending per (mol,iso);
- * linear interpolation in T, clamped at the ends. */
+ * linear interpolation in T, clamped at the ends.  Loading or dropping a table re-scales the
+ * line strengths of every gas-optics object at its next calculation (the 296 K strengths are
+ * kept as tabulated; Q(296) is applied when the device line store is built).
+ * grt_tips_source: 0 = table, 1 = rotor x oscillators, 2 = rotor alone (no fundamentals
+ * tabulated for that molecule), -1 = ids out of range. */
 EXTERN int grt_tips_load(char const *path);
 EXTERN int grt_tips_reset(void);
 EXTERN int grt_tips_is_table(void);
+EXTERN int grt_tips_source(int mol_id, int iso);
 
 /* ---- HITRAN line parameters: parse once ------------------------------------------
  * The first add_molecule on a .par file indexes every molecule's records in memory (later calls, any molecule,
@@ -130,5 +137,11 @@ EXTERN int grt_debug_line_prep(GasOptics_t *gas_optics, fp_t *pressure, fp_t *te
                                uint64_t *num_lines, uint8_t *slot, double *v0, double *vnn,
                                double *snn, double *gamma, double *alpha, int64_t *win_s,
                                int64_t *win_e);
+
+/* ---- parity hook: the 1/Q(T, iso) block of one column's state as the DEVICE holds it (the path of
+ * calc_partition_functions, kernels.c:52-66: evaluated on the host per layer and isotopologue, shipped inside the
+ * column state, read by the line kernels as q[slot][layer][iso-1]).  q_out: host [num_molecules][L][GRT_MAX_ISO = 18],
+ * zero beyond a molecule's isotopologue count. */
+EXTERN int grt_debug_partition_functions(GasOptics_t *gas_optics, fp_t *pressure, fp_t *temperature, double *q_out);
 
 #endif

@@ -11,6 +11,8 @@ input/expected arrays into tests/golden/reference_test_vectors.json:
                                       CIRC case-1 profile (55 levels) and n/pavg/tavg/ps/ns references
   gas-optics/test/test_tips2017.c     Q(mol, 275.234324 K, iso 1) for H2O, CO2, CH4, N2O, O3
 
+The 50 partition sums among them are also written as tests/golden/tips_pins.csv in grt_tips_load's format.
+
 Only data (numbers) is kept; run where /root/reference is mounted:  python tests/golden/harvest_reference_vectors.py
 """
 import json
@@ -36,6 +38,28 @@ def c_arrays(src):
         if vals and name not in out:
             out[name] = vals
     return out
+
+
+def write_tips_pins(vec):
+    """tests/golden/tips_pins.csv: every partition sum the reference's tests hold, as a table grt_tips_load
+    reads (rows mol_id,iso,T,Q; T ascending per (mol,iso)): Q = 1/q_ref for H2O isotopologues 1-9 at the five
+    layer temperatures of test_kernels.c (:180-189, printed to 6 digits) and the five absolute values of
+    test_tips2017.c:34-65."""
+    ids = dict(H2O=1, CO2=2, O3=3, N2O=4, CH4=6)
+    k = vec["test_kernels"]
+    rows = []
+    niso, temps = k["num_isotopologues"], k["layer_temperature"]
+    for i, T in enumerate(temps):
+        for iso in range(niso):
+            rows.append((1, iso + 1, T, repr(1.0 / k["q_ref"][i * niso + iso])))
+    t = vec["test_tips2017"]
+    for name, q in t["Q"].items():
+        rows.append((ids[name], t["isotopologue"], t["temperature"], repr(q)))
+    rows.sort(key=lambda r: (r[0], r[1], r[2]))
+    with open(os.path.join(HERE, "tips_pins.csv"), "w") as f:
+        f.write("mol_id,iso,T,Q\n")
+        for m, iso, T, q in rows:
+            f.write("%d,%d,%r,%s\n" % (m, iso, T, q))
 
 
 def main():
@@ -92,6 +116,7 @@ def main():
         "source": "gas-optics/test/test_tips2017.c", "temperature": temp, "isotopologue": 1,
         "Q": {m.group(1): float(m.group(2)) for m in re.finditer(r"helper\((\w+),\s*(" + NUM + r")\)", tips)},
     }
+    write_tips_pins(vec)
     for k, v in vec.items():
         sizes = {a: len(b) for a, b in v.items() if isinstance(b, list)}
         print(k, sizes)

@@ -20,7 +20,7 @@ class Band:
     """A spectral band with synthetic lines + tables written to `root` in the reference's file formats."""
 
     def __init__(self, root, w0, wn, dw, nlines, mols=MOL_ORDER, seed=20261003, sw=False,
-                 with_ctm=True, with_cfc=True, with_cia=True, line_range=None):
+                 with_ctm=True, with_cfc=True, with_cia=True, line_range=None, iso_mix=True):
         os.makedirs(root, exist_ok=True)
         self.root, self.w0, self.wn, self.dw = root, w0, wn, dw
         self.nw = int(np.ceil((wn - w0) / dw)) + 1
@@ -30,6 +30,11 @@ class Band:
         tot = sum(share.values())
         raw = {m: syn.line_list(m, max(int(round(nlines * share[m] / tot)), 0 if nlines == 0 else 1), lo, hi, seed)
                for m in self.mols} if nlines > 0 else {m: syn.line_list(m, 0, lo, hi, seed) for m in self.mols}
+        if iso_mix:
+            # every isotopologue the molecule has (HITRAN codes 1-9, '0' = 10, 'A'.. = 11..): q[iso-1] lookups on the
+            # device are then visible to every parity case (round 1 had iso = 1 throughout)
+            for m, ln in raw.items():
+                ln["iso"] = (1 + (np.arange(ln["v0"].size) * 7 + m) % MOLTAB[m][1]).astype(np.int32)
         self.par = os.path.join(root, "lines.par")
         syn.write_hitran_par(self.par, raw)
         self.lines = syn.read_back_par_values(raw)      # what a loader parses back (raw 296 K strengths)
@@ -87,19 +92,21 @@ class Band:
             go.set_cia_ppmv(1, col["ppmv"][syn.O2])
 
     # -- the checker ------------------------------------------------------------------- #
-    def oracle_inputs(self, orc, lib, col):
+    def oracle_inputs(self, orc, lib, col, qfunc=None):
         """Everything orc.gas_optics / Ref.gas_optics need for one column.  1/Q and Q(296) come
         from the product's provider through the C ABI (the reference's tips2017.c is missing),
-        so parity isolates everything else."""
+        so parity isolates everything else -- or from `qfunc(mol, T, iso)`, an independent
+        evaluation of the partition sums, where a test checks the provider path itself."""
+        Q = qfunc if qfunc is not None else lib.Q
         p_atm = col["p"] * np.float64(np.float32(0.000986923))
         _, _, tavg = orc.layer_means(p_atm, col["t"])
         mols = []
         for m in self.mols:
             ln = dict(self.lines[m])
             niso = MOLTAB[m][1]
-            q296 = np.array([lib.Q(m, 296.0, int(i)) for i in ln["iso"]])
+            q296 = np.array([Q(m, 296.0, int(i)) for i in ln["iso"]])
             ln["s0"] = orc.rescale_strengths(ln["s0"], ln["en"], ln["v0"], q296) if ln["v0"].size else ln["s0"]
-            q = np.array([[1.0 / lib.Q(m, float(T), k + 1) for k in range(niso)] for T in tavg])
+            q = np.array([[1.0 / Q(m, float(T), k + 1) for k in range(niso)] for T in tavg])
             mols.append(dict(id=m, num_iso=niso, mass=mol_mass(m), lines=ln, x=col["ppmv"][m] * 1e-6, q=q,
                              h2o_ctm=int(m == syn.H2O and self.with_ctm), o3_ctm=int(m == syn.O3 and self.with_ctm)))
         kw = dict(mols=mols)
@@ -115,8 +122,8 @@ class Band:
             kw["cias"] = [(x[a], x[b], self.table_on_grid(orc, name)) for a, b, name in CIA_PAIRS]
         return kw
 
-    def oracle_tau(self, checker, orc, lib, col, method=None):
-        kw = self.oracle_inputs(orc, lib, col)
+    def oracle_tau(self, checker, orc, lib, col, method=None, qfunc=None):
+        kw = self.oracle_inputs(orc, lib, col, qfunc)
         if method is not None:
             kw["method"] = method
         return checker.gas_optics(col["p"], col["t"], self.w0, self.dw, self.nw, **kw)

@@ -145,9 +145,14 @@ def test_hitran_reader_matches_written_records(lib, oracle, tmp_path):
         assert np.array_equal(got["v0"], w["v0"][keep]) and np.array_equal(got["iso"], w["iso"][keep])
         for k in ("yair", "yself", "en", "nexp", "delta"):
             assert np.array_equal(got[k].astype(np.float64), w[k][keep]), k
+        # the reader keeps the tabulated 296 K strengths; the factor of parse_HITRAN_file.c:372-384 is applied when
+        # the device store is built (grt_rescale_strengths), with whatever partition sums are current then
+        assert np.array_equal(got["s0"], w["s0"][keep])
         q296 = np.array([lib.Q(mol, 296.0, int(i)) for i in w["iso"][keep]])
-        s_want = oracle.rescale_strengths(w["s0"][keep], w["en"][keep], w["v0"][keep], q296)   # parse_HITRAN_file.c:372-384
-        assert np.array_equal(got["s0"], s_want)
+        s_want = oracle.rescale_strengths(w["s0"][keep], w["en"][keep], w["v0"][keep], q296)
+        s_got = got["s0"].copy()
+        lib.grt_rescale_strengths(mol, C.c_uint64(n), hl.iso, hl.v0, hl.en, s_got.ctypes.data_as(c_double_p))
+        assert np.array_equal(s_got, s_want)
         lib.grt_free_host_lines(C.byref(hl))
     bad = tmp_path / "short.par"
     bad.write_text(" 11  500.000000 1.000E-25\n")
@@ -265,7 +270,10 @@ def test_partition_sum_table_plug_in(lib, tmp_path):
     p.write_text("mol,iso,T,Q\n1,1,200,100.0\n1,1,300,180.0\n2,1,200,200.0\n2,1,300,290.0\n")
     assert lib.grt_tips_load(str(p).encode()) == 0 and lib.grt_tips_is_table() == 1
     assert lib.Q(1, 250.0, 1) == 140.0 and lib.Q(1, 150.0, 1) == 100.0 and lib.Q(1, 400.0, 1) == 180.0
-    assert lib.Q(3, 250.0, 1) == pytest.approx(3483.7 * (250.0 / 296.0) ** 1.5)     # species absent from the table
+    # species absent from the table: the built-in model, classical rotor x harmonic oscillators (grt_tips.c)
+    c2, modes = 1.4387769, (1103.1, 700.9, 1042.1)
+    qv = lambda T: np.prod([1.0 / (1.0 - np.exp(-c2 * nu / T)) for nu in modes])
+    assert lib.Q(3, 250.0, 1) == pytest.approx(3483.71 * (250.0 / 296.0) ** 1.5 * qv(250.0) / qv(296.0), rel=1e-6)
     (tmp_path / "bad.csv").write_text("mol,iso,T,Q\n1,1,300,1\n1,1,200,2\n")
     assert lib.grt_tips_load(str(tmp_path / "bad.csv").encode()) == api.VALUE_ERR
     assert lib.grt_tips_reset() == 0 and lib.Q(1, 250.0, 1) == base

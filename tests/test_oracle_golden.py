@@ -81,18 +81,6 @@ def test_layer_means_against_test_curtis_godson_c(oracle, vec):
     assert rel(ps, v["ps_ref"]) < 1e-7 and rel(ns, v["ns_ref"]) < 1e-7
 
 
-def test_tips_values_are_recorded_but_unpinned(vec, lib):
-    """tips2017.c is a missing blob: the product's analytic surrogate is NOT expected to reproduce the
-    five TIPS-2017 values; they are kept so a real table can be validated (grt_tips_load).  The
-    surrogate must at least be within a few percent for the principal isotopologues."""
-    v = vec["test_tips2017"]
-    ids = dict(H2O=1, CO2=2, O3=3, N2O=4, CH4=6)
-    assert set(v["Q"]) == set(ids)
-    for name, want in v["Q"].items():
-        got = lib.Q(ids[name], v["temperature"], 1)
-        assert abs(got / want - 1.0) < 0.15, (name, got, want)
-
-
 # ---- 2. committed outputs of the reference's own C ---------------------------------------- #
 def test_voigt_bit_exact_vs_fixture(oracle, fx):
     alpha = float(fx["voigt_alpha"])
