@@ -25,84 +25,63 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector
 
 
-def cpu_baseline(wl_args, thin_lw=1, thin_sw=1):
+def cpu_baseline(lw_grid, sw_grid, lw_lines, sw_lines, thin_lw=1, thin_sw=1):
     """Reference OpenMP path (oracle/_ref, the reference's own C) -- or our restatement when the
-    prebuilt reference library is absent -- timed on a bounded sample: one column, full LW+SW grids
-    and solvers, line lists thinned by 1/thin; gas-optics time is scaled back by `thin`."""
-    from oracle.bindings import Oracle, Ref, ref_available
+    prebuilt reference library is absent -- timed on a bounded sample: column 0 of the bench's own
+    workload, full LW+SW grids and solvers (line lists thinned by 1/thin only if asked; gas-optics time
+    is then scaled back by `thin`).  Returns (the cpu_baseline object of the bench line, the checker's
+    tau and fluxes of that column per band -- what the GPU's column 0 is compared with)."""
+    from oracle import reference_column as RC
     from grtcode_amd import api, synthetic as syn, workload as W
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from scenario import MOLTAB, mol_mass
-    cores = min(os.cpu_count() or 1, 16)
-    os.environ["OMP_NUM_THREADS"] = str(cores)
-    kind = "reference" if ref_available(omp=True) else "port"
-    chk = Ref(omp=True) if kind == "reference" else Oracle()
-    orc = Oracle()
+    cores = RC.set_omp_threads(min(os.cpu_count() or 1, 16))
+    kind, chk, orc = RC.checker(omp=True)
+    if kind != "reference":
+        cores = 1                       # the restatement is a scalar port
     lib = api.load_library()
     col = syn.profile(0, W.NUM_LEVELS)
-    p_atm = col["p"] * np.float64(np.float32(0.000986923))
-    _, _, tavg = orc.layer_means(p_atm, col["t"])
     total = 0.0
-    detail = {}
-    for band, grid, nlines, thin, seed, sw in (("lw", W.LW_GRID, W.LW_LINES, thin_lw, 20261003, False),
-                                               ("sw", W.SW_GRID, W.SW_LINES, thin_sw, 20261004, True)):
-        w0, wn, dw = grid
-        nw = int(np.ceil((wn - w0) / dw)) + 1
-        lines = W.band_lines(nlines, grid, seed)
-        t = syn.tables(sw=sw)
-        on_grid = lambda name: orc.interp_to_grid(w0, dw, nw, *t[name])
-        mols = []
-        for m in W.MOL_ORDER:
-            ln = {k: v[::thin] for k, v in lines[m].items()}
-            niso = MOLTAB[m][1]
-            q296 = np.array([lib.Q(m, 296.0, int(i)) for i in ln["iso"]])
-            ln["s0"] = orc.rescale_strengths(ln["s0"], ln["en"], ln["v0"], q296)
-            q = np.array([[1.0 / lib.Q(m, float(T), k + 1) for k in range(niso)] for T in tavg])
-            mols.append(dict(id=m, num_iso=niso, mass=mol_mass(m), lines=ln, x=col["ppmv"][m] * 1e-6, q=q,
-                             h2o_ctm=int(m == syn.H2O), o3_ctm=int(m == syn.O3)))
-        kw = dict(mols=mols,
-                  h2o_coefs=[on_grid(k) for k in ("h2o_foreign_296", "h2o_self_296", "h2o_foreign_t", "h2o_self_t")],
-                  o3_xs=on_grid("o3_ctm"),
-                  cfcs=[(col["cfc_ppmv"][0] * 1e-6, on_grid("cfc11")), (col["cfc_ppmv"][1] * 1e-6, on_grid("cfc12"))],
-                  cias=[(col["ppmv"][syn.N2 if a == 0 else syn.O2] * 1e-6, col["ppmv"][syn.N2 if b == 0 else syn.O2] * 1e-6,
-                         on_grid(name)) for a, b, name in W.CIA_PAIRS])
-        t0 = time.perf_counter()
-        tau_gas = chk.gas_optics(col["p"], col["t"], w0, dw, nw, **kw)
-        t_gas = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        L = W.NUM_LEVELS - 1
-        if kind == "reference":
-            g = chk.grid(w0, wn, dw)
-            tr, om, gg = chk.rayleigh(g, L, col["p"])
-            z = np.zeros_like(tau_gas)
-            tau, omega, gsum = chk.add_optics(g, [tau_gas, tr], [z, om], [z, gg])
-            if not sw:
-                up, dn = chk.lw_fluxes(g, col["t_surf"], col["t_layer"], col["t"], tau, omega, np.full(nw, 0.98))
-            else:
-                solar = orc.normalize_solar(w0, dw, on_grid("solar"))
-                up, dn = chk.sw_fluxes(g, omega, gsum, tau, col["mu0"], 0.5, np.full(nw, 0.2), np.full(nw, 0.2),
-                                       col["tsi"], solar)
-        else:
-            tr, om, gg = chk.rayleigh(L, col["p"], w0, dw, nw)
-            z = np.zeros_like(tau_gas)
-            tau, omega, gsum = chk.add_optics([tau_gas, tr], [z, om], [z, gg])
-            if not sw:
-                up, dn = chk.lw_fluxes(w0, dw, col["t_surf"], col["t_layer"], col["t"], tau, omega, np.full(nw, 0.98))
-            else:
-                solar = orc.normalize_solar(w0, dw, on_grid("solar"))
-                up, dn = chk.sw_fluxes(omega, gsum, tau, col["mu0"], 0.5, np.full(nw, 0.2), np.full(nw, 0.2),
-                                       col["tsi"], solar)
-        for r in (up[0], up[-1], dn[0], dn[-1]):
-            orc.integrate_row(r, dw)
-        t_rest = time.perf_counter() - t0
-        detail[band] = dict(gas_optics_s_sample=round(t_gas, 3), rest_s=round(t_rest, 3), thin=thin)
-        total += t_gas * thin + t_rest
-    return {"value": 1.0 / total, "unit": "columns/s", "cores": cores, "kind": kind,
+    detail, bands = {}, {}
+    for band, grid, nlines, thin, seed, sw in (("lw", lw_grid, lw_lines, thin_lw, 20261003, False),
+                                               ("sw", sw_grid, sw_lines, thin_sw, 20261004, True)):
+        r = RC.band_column(kind, chk, orc, lib.Q, col, grid, W.band_lines(nlines, grid, seed), syn.tables(sw=sw),
+                           W.MOL_ORDER, MOLTAB, mol_mass, W.CIA_PAIRS, sw, thin=thin)
+        detail[band] = dict(gas_optics_s_sample=round(r["t_gas"], 3), rest_s=round(r["t_rest"], 3), thin=thin)
+        total += r["t_gas"] * thin + r["t_rest"]
+        bands[band] = r
+    base = {"value": 1.0 / total, "unit": "columns/s", "cores": cores, "kind": kind,
             "sample": ("1 column of the bench workload at full size (LW+SW at 1 cm-1, 60 layers, all lines)"
                        if thin_lw == 1 and thin_sw == 1 else
                        f"1 column, LW+SW at 1 cm-1, 60 layers, line lists thinned 1/{thin_lw} (LW) and 1/{thin_sw} (SW); "
                        f"gas-optics time scaled back by the thinning factor, all other stages at full size"),
             "seconds_per_column_est": round(total, 2), "detail": detail}
+    return base, bands
+
+
+def parity_of_column0(wl, fluxes, bands, kind):
+    """The GPU's column 0 of the last timed step against the CPU checker's column 0 (same inputs): the twelve
+    integrated fluxes [W m-2] and the spectral gas optical depths of both bands."""
+    from oracle.reference_column import tau_metrics
+    from grtcode_amd import api, workload as W
+    L = W.NUM_LEVELS - 1
+    out = {"kind": kind, "column": 0, "tolerance_w_m2": 1e-3}
+    want = np.concatenate([bands["lw"]["integ"], bands["sw"]["integ"]])
+    out["max_abs_flux_diff_w_m2"] = float(np.abs(fluxes[0] - want).max())
+    out["flux_diff_w_m2"] = {k: float(fluxes[0, i] - want[i]) for k, i in
+                             (("rlut", 0), ("rlus", 1), ("rlds", 4), ("rsut", 6), ("rsus", 7), ("rsdt", 9), ("rsds", 10))}
+    worst = {"of_layer_max": 0.0, "pointwise_rel": 0.0, "transmission": 0.0}
+    for bi, band in enumerate(("lw", "sw")):
+        nw = bands[band]["nw"]
+        got = api.device_to_host(wl.device, wl.pipe.views(bi)["tau_gas"], (L, nw))
+        m = tau_metrics(got, bands[band]["tau_gas"])
+        out["tau_" + band] = m
+        worst = {k: max(worst[k], m[k]) for k in worst}
+    out["max_tau_err_of_layer_max"] = worst["of_layer_max"]
+    out["max_tau_err_pointwise_rel"] = worst["pointwise_rel"]
+    out["max_transmission_err"] = worst["transmission"]
+    out["ok"] = bool(out["max_abs_flux_diff_w_m2"] <= out["tolerance_w_m2"])
+    return out
 
 
 def main():
@@ -241,7 +220,13 @@ def main():
                                    "rsut": fluxes[0, 6], "rsdt": fluxes[0, 9], "rsds": fluxes[0, 10]},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args)
+            line["cpu_baseline"], ref_bands = cpu_baseline(lw_grid, sw_grid, args.lw_lines or W.LW_LINES,
+                                                           args.sw_lines or W.SW_LINES)
+            line["parity"] = parity_of_column0(wl, fluxes, ref_bands, line["cpu_baseline"]["kind"])
+            if not line["parity"]["ok"]:
+                sys.stderr.write("bench.py: PARITY FAILURE, no result line: " + json.dumps(line["parity"]) + "\n")
+                wl.destroy()
+                raise SystemExit(3)
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         print(json.dumps(line), flush=True)

@@ -37,17 +37,45 @@ def profile(col=0, num_levels=61):
                 cfc_ppmv={0: np.full(V, 2.3e-4), 1: np.full(V, 5.2e-4)})
 
 
-def line_list(mol_id, n, w0, wn, seed=20261003):
+#: Band structure of the "physically scaled" line lists: per absorber a floor and Gaussian bands
+#: (centre [cm-1], width [cm-1], amplitude) multiplying the uniformly drawn strengths, so that the synthetic
+#: atmosphere has windows and bands where the real one does (H2O rotation band / 6.3 um / near-infrared bands,
+#: CO2 15 and 4.3 um, O3 9.6 um, CH4 7.7 um, N2O, CO, the O2 A band) instead of being black everywhere:
+#: outgoing longwave ~250-300 W m-2, surface shortwave ~0.7 of the incoming (cf. the LBLRTM numbers quoted by
+#: circ/src/basic-circ-test.c:447-495).  The SURVEY §8(d) list (physical=False) stays the bench workload.
+PHYSICAL_BANDS = {
+    H2O: (1e-6, [(100.0, 180.0, 1.0), (1595.0, 130.0, 0.5), (3750.0, 200.0, 2.0), (5350.0, 200.0, 2.0), (7250.0, 200.0, 2.0),
+                 (8800.0, 200.0, 0.3), (10600.0, 200.0, 0.3), (12200.0, 200.0, 0.03), (13800.0, 200.0, 0.03)]),
+    CO2: (1e-8, [(667.0, 35.0, 1.0), (2349.0, 40.0, 3.0), (960.0, 30.0, 1e-4), (1064.0, 30.0, 1e-4), (3700.0, 60.0, 0.1),
+                 (5000.0, 80.0, 0.01), (6300.0, 80.0, 1e-3)]),
+    O3: (1e-6, [(1042.0, 30.0, 5.0), (701.0, 25.0, 0.3), (2110.0, 30.0, 0.1)]),
+    N2O: (1e-6, [(1285.0, 25.0, 10.0), (2224.0, 25.0, 100.0), (589.0, 20.0, 3.0)]),
+    CO: (1e-6, [(2143.0, 40.0, 30.0)]),
+    CH4: (1e-6, [(1306.0, 50.0, 1.0), (3019.0, 60.0, 1.0), (4300.0, 100.0, 0.3), (6000.0, 100.0, 0.05)]),
+    O2: (1e-10, [(1556.0, 50.0, 1e-7), (13120.0, 30.0, 1e-3), (14500.0, 30.0, 1e-4)]),
+}
+
+
+def physical_envelope(mol_id, v0):
+    floor, bands = PHYSICAL_BANDS[mol_id]
+    e = np.full(v0.shape, floor)
+    for c, w, a in bands:
+        e += a * np.exp(-0.5 * ((v0 - c) / w) ** 2)
+    return e
+
+
+def line_list(mol_id, n, w0, wn, seed=20261003, physical=False):
     """Synthetic line parameters for one molecule, sorted by centre.
 
     yair/yself/en/n/delta carry f32-representable values because the reference
-    reads those columns through a float (parse_HITRAN_file.c:197-212)."""
+    reads those columns through a float (parse_HITRAN_file.c:197-212).
+    physical=True: strengths follow PHYSICAL_BANDS (windows and bands) instead of being uniform over the band."""
     rng = np.random.default_rng(seed + 7919 * mol_id)
     f32 = lambda a: a.astype(np.float32).astype(np.float64)
     v0 = np.sort(np.round(rng.uniform(w0, wn, n), 6))
     return dict(
         v0=v0,
-        s0=10.0 ** rng.uniform(-27.0, -20.0, n),
+        s0=10.0 ** rng.uniform(-27.0, -20.0, n) * (physical_envelope(mol_id, v0) if physical else 1.0),
         yair=f32(np.round(rng.uniform(0.02, 0.10, n), 4)),
         yself=f32(np.round(rng.uniform(0.1, 0.5, n), 3)),
         en=f32(np.round(rng.uniform(0.0, 4000.0, n), 4)),
@@ -57,9 +85,9 @@ def line_list(mol_id, n, w0, wn, seed=20261003):
     )
 
 
-def band_line_lists(total_lines, w0, wn, seed=20261003):
+def band_line_lists(total_lines, w0, wn, seed=20261003, physical=False):
     """Per-molecule line lists for one band with the LINE_SHARE split."""
-    return {m: line_list(m, max(int(round(total_lines * s)), 1), w0, wn, seed)
+    return {m: line_list(m, max(int(round(total_lines * s)), 1), w0, wn, seed, physical)
             for m, s in LINE_SHARE.items()}
 
 

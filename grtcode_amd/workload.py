@@ -35,8 +35,8 @@ def write_tables(root, sw):
     return files, t
 
 
-def band_lines(total, grid, seed):
-    lists = syn.band_line_lists(total, grid[0], grid[1], seed)
+def band_lines(total, grid, seed, physical=False):
+    lists = syn.band_line_lists(total, grid[0], grid[1], seed, physical)
     return {m: lists[m] for m in MOL_ORDER}
 
 
@@ -56,13 +56,14 @@ class G1Workload:
     """Both bands of the headline configuration, resident on one device."""
 
     def __init__(self, device, max_columns, lw_lines=LW_LINES, sw_lines=SW_LINES, num_levels=NUM_LEVELS,
-                 lw_grid=LW_GRID, sw_grid=SW_GRID, root=None, fast=0, tile=0, lw_nslice=0):
+                 lw_grid=LW_GRID, sw_grid=SW_GRID, root=None, fast=0, tile=0, lw_nslice=0, physical=False):
         self.root = root or tempfile.mkdtemp(prefix="grt_g1_")
         self.device, self.num_levels = device, num_levels
         self.lw_files, _ = write_tables(self.root, sw=False)
         self.sw_files, _ = write_tables(self.root, sw=True)
-        self.lw_lines = band_lines(lw_lines, lw_grid, 20261003)
-        self.sw_lines = band_lines(sw_lines, sw_grid, 20261004)
+        self.physical = physical      # strengths with band structure (synthetic.PHYSICAL_BANDS) instead of SURVEY §8(d)'s uniform draw
+        self.lw_lines = band_lines(lw_lines, lw_grid, 20261003, physical)
+        self.sw_lines = band_lines(sw_lines, sw_grid, 20261004, physical)
         self.go_lw, self.grid_lw = build_band(device, lw_grid, self.lw_lines, self.lw_files, num_levels)
         self.go_sw, self.grid_sw = build_band(device, sw_grid, self.sw_lines, self.sw_files, num_levels)
         if fast or tile or lw_nslice:

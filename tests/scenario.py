@@ -20,7 +20,7 @@ class Band:
     """A spectral band with synthetic lines + tables written to `root` in the reference's file formats."""
 
     def __init__(self, root, w0, wn, dw, nlines, mols=MOL_ORDER, seed=20261003, sw=False,
-                 with_ctm=True, with_cfc=True, with_cia=True, line_range=None, iso_mix=True):
+                 with_ctm=True, with_cfc=True, with_cia=True, line_range=None, iso_mix=True, physical=False):
         os.makedirs(root, exist_ok=True)
         self.root, self.w0, self.wn, self.dw = root, w0, wn, dw
         self.nw = int(np.ceil((wn - w0) / dw)) + 1
@@ -28,7 +28,7 @@ class Band:
         lo, hi = line_range or (w0, wn)
         share = {m: syn.LINE_SHARE[m] for m in self.mols}
         tot = sum(share.values())
-        raw = {m: syn.line_list(m, max(int(round(nlines * share[m] / tot)), 0 if nlines == 0 else 1), lo, hi, seed)
+        raw = {m: syn.line_list(m, max(int(round(nlines * share[m] / tot)), 0 if nlines == 0 else 1), lo, hi, seed, physical)
                for m in self.mols} if nlines > 0 else {m: syn.line_list(m, 0, lo, hi, seed) for m in self.mols}
         if iso_mix:
             # every isotopologue the molecule has (HITRAN codes 1-9, '0' = 10, 'A'.. = 11..): q[iso-1] lookups on the
@@ -131,3 +131,32 @@ class Band:
 
 def rel_err(a, b, floor=1e-300):
     return np.max(np.abs(a - b) / np.maximum(np.abs(b), floor))
+
+
+def full_column(kind, chk, orc, lib, band, col, lw, emis=None, alb=None, solar=None, user_level=-1, qfunc=None):
+    """One band of one column through a CPU checker -- `kind` "reference" (oracle.bindings.Ref: the reference's own
+    compiled C) or "port" (our restatement) -- in driver.c's order: gas optics, Rayleigh, add_optics, solver,
+    trapezoid.  Returns spectral tau_gas/tau/omega/g, flux_up/down [V][n] and the six integrated fluxes in the
+    pipeline's order."""
+    L = col["p"].size - 1
+    tau_gas = band.oracle_tau(chk, orc, lib, col, qfunc=qfunc)
+    z = np.zeros_like(tau_gas)
+    if kind == "reference":
+        g = chk.grid(band.w0, band.wn, band.dw)
+        tr, om_r, g_r = chk.rayleigh(g, L, col["p"])
+        tau, omega, gg = chk.add_optics(g, [tau_gas, tr], [z, om_r], [z, g_r])
+        if lw:
+            up, dn = chk.lw_fluxes(g, col["t_surf"], col["t_layer"], col["t"], tau, omega, emis)
+        else:
+            up, dn = chk.sw_fluxes(g, omega, gg, tau, col["mu0"], 0.5, alb, alb, col["tsi"], solar)
+    else:
+        tr, om_r, g_r = chk.rayleigh(L, col["p"], band.w0, band.dw, band.nw)
+        tau, omega, gg = chk.add_optics([tau_gas, tr], [z, om_r], [z, g_r])
+        if lw:
+            up, dn = chk.lw_fluxes(band.w0, band.dw, col["t_surf"], col["t_layer"], col["t"], tau, omega, emis)
+        else:
+            up, dn = chk.sw_fluxes(omega, gg, tau, col["mu0"], 0.5, alb, alb, col["tsi"], solar)
+    rows = [up[0], up[-1], up[user_level] if user_level >= 0 else None,
+            dn[0], dn[-1], dn[user_level] if user_level >= 0 else None]
+    integ = np.array([orc.integrate_row(r, band.dw) if r is not None else 0.0 for r in rows])
+    return dict(tau_gas=tau_gas, tau=tau, omega=omega, g=gg, up=up, dn=dn, integ=integ)

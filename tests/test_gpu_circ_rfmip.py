@@ -5,7 +5,7 @@
   grids, column prepared exactly as circ/src/basic-circ-test.c does (pressure-interpolated ppmv :51-66,
   cos(SZA) :118-120, TSI/cosz :122-124).  Spectroscopy is synthetic (no HITRAN data ships with the
   reference), so the LBLRTM numbers quoted there are only an order-of-magnitude check.
-* an RFMIP-IRF-sized batch: 100 columns x 61 levels through the batched pipeline in chunks.
+* RFMIP-IRF as BASELINE.json states it (config 3): 100 columns x 61 levels, LW and SW at 1 cm-1, production form.
 """
 import json
 import os
@@ -74,13 +74,25 @@ def test_circ_case1_lw_sw_full_grids(tmp_path, oracle, lib, device, fast):
     go_sw.destroy()
 
 
-def test_rfmip_sized_batch_100_columns_61_levels(tmp_path, oracle, lib, device):
-    V, ncol, chunk = 61, 100, 32
-    band = Band(str(tmp_path), 500.0, 900.0, 1.0, 4000)
-    go, grid = band.gas_optics(device, V, from_file=False)
-    go.tune(fast=1)
-    emis = np.full(band.nw, 0.98)
-    pipe = api.Pipeline(go, None, chunk, -1, emis, None, None)
+def test_rfmip_irf_100_columns_61_levels_lw_and_sw_production_form(tmp_path, oracle, lib, device):
+    """BASELINE.json config 3 as stated: 100 columns x 61 levels, LW AND SW on the full 1 cm-1 grids (1-3250, 1-50000),
+    production form (fast = 3), through the batched pipeline in chunks of 50; every tenth column (10 columns) against
+    the CPU checker (the reference's own C where oracle/_ref is there).  Line list with band structure, so the fluxes
+    depend on tau (OLR ~ 280, not a black atmosphere)."""
+    from oracle import reference_column as RC
+    from scenario import full_column
+    kind, chk, orc = RC.checker(omp=True)
+    RC.set_omp_threads(min(os.cpu_count() or 1, 16))
+    V, ncol, chunk = 61, 100, 50
+    lwb = Band(str(tmp_path / "lw"), 1.0, 3250.0, 1.0, 30000, physical=True)
+    swb = Band(str(tmp_path / "sw"), 1.0, 50000.0, 1.0, 30000, sw=True, physical=True)
+    go_lw, grid_lw = lwb.gas_optics(device, V, from_file=False)
+    go_sw, grid_sw = swb.gas_optics(device, V, from_file=False)
+    go_lw.tune(fast=3)
+    go_sw.tune(fast=3)
+    emis, alb = np.full(lwb.nw, 0.98), np.full(swb.nw, 0.2)
+    solar = api.create_solar_flux(grid_sw, swb.files["solar"])
+    pipe = api.Pipeline(go_lw, go_sw, chunk, -1, emis, alb, solar)
     cols = [syn.profile(c, V) for c in range(ncol)]
     got = np.zeros((ncol, api.GRT_FLUXES_PER_COLUMN))
     for first in range(0, ncol, chunk):
@@ -88,10 +100,18 @@ def test_rfmip_sized_batch_100_columns_61_levels(tmp_path, oracle, lib, device):
         gcols, keep = api.make_columns(part, MOL_ORDER, cfc_order=(0, 1))
         pipe.run(gcols)
         got[first: first + len(part)] = pipe.fluxes(len(part))
-    for c in range(0, ncol, 7):                                     # every 7th column against the oracle
-        w = oracle_column(oracle, lib, band, cols[c], True, emis)
-        assert np.max(np.abs(got[c, :6] - w["integ"])) < 1e-3
-    assert np.all(np.isfinite(got[:, :6])) and np.all(got[:, 0] > 0)
+    assert go_lw.last_launch()["fast"] == 3 and go_sw.last_launch()["fast"] == 3
+    worst = 0.0
+    checked = list(range(3, ncol, 10))
+    assert len(checked) == 10
+    for c in checked:
+        for bi, (band, lw) in enumerate(((lwb, True), (swb, False))):
+            w = full_column(kind, chk, orc, lib, band, cols[c], lw, emis, alb, solar)
+            worst = max(worst, np.max(np.abs(got[c, bi * 6: bi * 6 + 6] - w["integ"])))
+    print(f"config 3 (100 x 61, LW+SW @1 cm-1, fast=3): worst integrated-flux difference over 10 columns {worst:.2e} W m-2 ({kind})")
+    assert worst < 1e-3
+    assert np.all(np.isfinite(got)) and np.all(got[:, 0] > 100.0) and np.all(got[:, 10] > 100.0)
     assert len({round(x, 6) for x in got[:, 0]}) == ncol            # every column really got its own profile
     pipe.destroy()
-    go.destroy()
+    go_lw.destroy()
+    go_sw.destroy()
