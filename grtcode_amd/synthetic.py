@@ -41,12 +41,12 @@ def profile(col=0, num_levels=61):
 #: (centre [cm-1], width [cm-1], amplitude) multiplying the uniformly drawn strengths, so that the synthetic
 #: atmosphere has windows and bands where the real one does (H2O rotation band / 6.3 um / near-infrared bands,
 #: CO2 15 and 4.3 um, O3 9.6 um, CH4 7.7 um, N2O, CO, the O2 A band) instead of being black everywhere:
-#: outgoing longwave ~250-300 W m-2, surface shortwave ~0.7 of the incoming (cf. the LBLRTM numbers quoted by
+#: outgoing longwave 270 W m-2, surface shortwave 0.68 of the incoming on column 0 of the full-size lists (cf. the LBLRTM numbers quoted by
 #: circ/src/basic-circ-test.c:447-495).  The SURVEY §8(d) list (physical=False) stays the bench workload.
 PHYSICAL_BANDS = {
-    H2O: (1e-6, [(100.0, 180.0, 1.0), (1595.0, 130.0, 0.5), (3750.0, 200.0, 2.0), (5350.0, 200.0, 2.0), (7250.0, 200.0, 2.0),
-                 (8800.0, 200.0, 0.3), (10600.0, 200.0, 0.3), (12200.0, 200.0, 0.03), (13800.0, 200.0, 0.03)]),
-    CO2: (1e-8, [(667.0, 35.0, 1.0), (2349.0, 40.0, 3.0), (960.0, 30.0, 1e-4), (1064.0, 30.0, 1e-4), (3700.0, 60.0, 0.1),
+    H2O: (1e-6, [(100.0, 170.0, 0.6), (1595.0, 120.0, 0.4), (3750.0, 180.0, 0.7), (5350.0, 180.0, 0.7), (7250.0, 180.0, 0.7),
+                 (8800.0, 180.0, 0.1), (10600.0, 180.0, 0.1), (12200.0, 180.0, 0.01), (13800.0, 180.0, 0.01)]),
+    CO2: (1e-8, [(667.0, 30.0, 1.0), (2349.0, 40.0, 3.0), (960.0, 30.0, 1e-4), (1064.0, 30.0, 1e-4), (3700.0, 60.0, 0.1),
                  (5000.0, 80.0, 0.01), (6300.0, 80.0, 1e-3)]),
     O3: (1e-6, [(1042.0, 30.0, 5.0), (701.0, 25.0, 0.3), (2110.0, 30.0, 0.1)]),
     N2O: (1e-6, [(1285.0, 25.0, 10.0), (2224.0, 25.0, 100.0), (589.0, 20.0, 3.0)]),

@@ -3,7 +3,7 @@ at the sizes the bench runs, and of the integer windows through the production k
 
   * the bench's own workload (SURVEY §8d grid G1: 1.0 M + 1.5 M lines, 60 layers, LW 1-3250 + SW 1-50000 cm-1 at
     1 cm-1), one column, fast = 3 and fast = 0, against the reference's own C (oracle/_ref, OpenMP) -- on the SURVEY
-    line list and on the physically scaled one (synthetic.PHYSICAL_BANDS: OLR ~283, surface SW ~0.70 of TOA), because
+    line list and on the physically scaled one (synthetic.PHYSICAL_BANDS: OLR ~270 W m-2, surface SW ~0.68 of TOA), because
     the SURVEY list makes a nearly black atmosphere whose fluxes barely depend on tau;
   * three tau metrics (of the layer maximum -- the round-1 one --, pointwise relative, transmission) and spectral fluxes
     point by point (a driver without -integrated writes spectra: driver.c:285-356), worst cases recorded in
@@ -28,7 +28,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # stated bounds; the measured worst cases are written to gpurun_out/parity_full_g1.json
 BOUNDS = {
     0: dict(of_layer_max=1e-11, pointwise_rel=1e-9, transmission=1e-12, flux=1e-6, spectral_flux_rel=1e-10),
-    3: dict(of_layer_max=2e-6, pointwise_rel=5e-5, transmission=2e-6, flux=1e-3, spectral_flux_rel=5e-6),
+    # fast = 3, pointwise / transmission: the one deliberate departure -- Humlicek region 1 is carried by the cell moments
+    # beyond a line's XLIM0, where the reference switches back to the Lorentzian with a jump of 1.5/XLIM0^2 = 1e-4 of the
+    # line's value there; on the SURVEY list (strengths so large that even far wings of the thinnest layers reach tau ~ 1)
+    # that shows as <= 1e-4 pointwise and <= 1e-4/e in transmission; on the physically scaled list both are ~1e-6 and 2e-7
+    3: dict(of_layer_max=2e-6, pointwise_rel=1.2e-4, transmission=4e-5, flux=1e-3, spectral_flux_rel=5e-6),
 }
 
 
@@ -55,7 +59,7 @@ def test_full_g1_column_against_reference(lib, device, physical):
     want = np.concatenate([ref["lw"]["integ"], ref["sw"]["integ"]])
     if physical:
         assert 250.0 < want[0] < 300.0                     # outgoing longwave, W m-2
-        assert 0.6 < want[10] / want[9] < 0.8              # shortwave reaching the surface / incoming
+        assert 0.62 < want[10] / want[9] < 0.75            # shortwave reaching the surface / incoming
     (gcols, keep), _ = wl.columns(0, 1)
     L, V = W.NUM_LEVELS - 1, W.NUM_LEVELS
     report = {"checker": kind, "reference_fluxes_w_m2": want.tolist()}

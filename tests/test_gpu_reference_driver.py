@@ -1,0 +1,146 @@
+"""SURVEY §8(f)-1 / VERDICT r1 #4: the reference's OWN framework/src/driver.c -- main(), command line, column loop,
+optics combination, flux integration -- compiled unchanged where it lies, linked against this library, run on the GPU.
+
+oracle/_ref/grtcode_driver = driver.c + the reference's utilities/src/argparse.c (both unchanged) + examples/driver_app.c
+(ours: the five driver.h:165-203 callbacks on flat text, CIRC column semantics of circ/src/basic-circ-test.c) +
+libclouds.a (entry points only) + libgrtcode_hip.so; built by oracle/Makefile in the container, shipped prebuilt.
+
+CIRC case 1 (circ/src/circ1.h numbers from tests/golden) plus a perturbed second column, synthetic spectroscopy:
+the fluxes main() writes must equal the oracle's for the same files -- <= 1e-6 W m-2 in the reference-order form an
+unchanged caller gets by default, <= 1e-3 W m-2 with GRT_GAS_OPTICS_FAST=3 in the environment.
+"""
+import copy
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from grtcode_amd import api, synthetic as syn
+from scenario import Band
+from test_gpu_c_driver import write_column
+from test_gpu_circ_rfmip import NAME, circ1_column
+from test_gpu_pipeline import oracle_column
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "oracle", "_ref", "grtcode_driver")
+needs_driver = pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref/grtcode_driver not built (needs /root/reference at build time)")
+
+
+def second_column(v):
+    w = copy.deepcopy(v)
+    w["level_temperature"] = [t + 3.0 for t in v["level_temperature"]]
+    w["layer_temperature"] = [t + 3.0 for t in v["layer_temperature"]]
+    w["surface_temperature"] = v["surface_temperature"] + 2.0
+    w["solar_zenith_angle_deg"] = 30.0
+    w["abundance"] = dict(v["abundance"], H2O=[0.7 * x for x in v["abundance"]["H2O"]])
+    return w
+
+
+def as_column(v):
+    """The column the driver builds from a dump (basic-circ-test.c semantics) as the checker wants it."""
+    p, pl = np.array(v["level_pressure_mb"]), np.array(v["layer_pressure_mb"])
+    L = pl.size
+
+    def to_levels(ab):
+        ab = np.array(ab)
+        out = np.zeros(L + 1)
+        out[0], out[L] = ab[0] * 1e6, ab[L - 1] * 1e6
+        for i in range(1, L):
+            out[i] = (ab[i - 1] + (ab[i] - ab[i - 1]) * (p[i] - pl[i - 1]) / (pl[i] - pl[i - 1])) * 1e6
+        return out
+    from scenario import MOL_ORDER
+    ppmv = {m: to_levels(v["abundance"][NAME[m]]) for m in MOL_ORDER}
+    ppmv[syn.N2] = np.full(L + 1, 0.781e6)
+    mu0 = float(np.cos(2.0 * np.pi * v["solar_zenith_angle_deg"] / 360.0))
+    return dict(p=p, t=np.array(v["level_temperature"]), t_layer=np.array(v["layer_temperature"]),
+                t_surf=v["surface_temperature"], ppmv=ppmv, mu0=mu0, tsi=v["toa_solar_irradiance"] / mu0,
+                cfc_ppmv={0: to_levels(v["abundance"]["CFC11"]), 1: to_levels(v["abundance"]["CFC12"])})
+
+
+def parse_output(path):
+    out = {}
+    for line in open(path):
+        if line.startswith("#"):
+            continue
+        t, c, name, count, *vals = line.split()
+        assert int(count) == len(vals)
+        out[(int(c), name)] = np.array([float(x) for x in vals])
+    return out
+
+
+@needs_driver
+def test_reference_driver_without_gpu_fails_cleanly(tmp_path):
+    """No CPU fallback: where no GPU exists the unchanged driver stops at create_device with the library's error text."""
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is present")
+    (tmp_path / "c.txt").write_text("column:\nlevel_pressure: 1 500 1000\nlevel_temperature: 220 250 288\nlayer_pressure: 250 750\n"
+                                    "layer_temperature: 235 270\nsurface_temperature: 289\nsolar_zenith_angle: 40\ntoa_solar_irradiance: 900\n")
+    r = subprocess.run([DRIVER, "none.par", "none.csv", str(tmp_path / "c.txt"), "-o", str(tmp_path / "o.txt")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0
+    assert "Error" in r.stderr
+
+
+@needs_driver
+@pytest.mark.gpu
+def test_unchanged_reference_driver_main_matches_oracle(tmp_path, oracle, lib):
+    col1, v1 = circ1_column()
+    v2 = second_column(v1)
+    cols = [col1, as_column(v2)]
+    user_level, albedo, emissivity = 20, 0.196, 0.97
+    swb = Band(str(tmp_path / "data"), 1.0, 20000.0, 2.0, 20000, sw=True)
+    lwb = Band(str(tmp_path / "lw_view"), 1.0, 3250.0, 0.5, 0, sw=True)
+    lwb.par, lwb.h2o_dir, lwb.files, lwb.tab = swb.par, swb.h2o_dir, swb.files, swb.tab
+    lwb.lines = {}
+    for m, ln in swb.lines.items():                     # the loader keeps w0 <= v0 <= wn (parse_HITRAN_file.c:340)
+        keep = (ln["v0"] >= lwb.w0) & (ln["v0"] <= lwb.wn)
+        lwb.lines[m] = {k: a[keep] for k, a in ln.items()}
+    dump = str(tmp_path / "columns.txt")
+    with open(dump, "w") as f:
+        for k, v in enumerate((v1, v2)):
+            f.write("column: %d\n" % k)
+            write_column(str(tmp_path / "one.txt"), v)
+            f.write(open(str(tmp_path / "one.txt")).read())
+    base = [DRIVER, swb.par, swb.files["solar"], dump, *("-" + NAME[m] for m in swb.mols),
+            "-h2o-ctm", swb.h2o_dir, "-o3-ctm", swb.files["o3_ctm"], "-CFC-11", swb.files["cfc11"], "-CFC-12", swb.files["cfc12"],
+            "-N2-N2", swb.files["cia_n2n2"], "-O2-N2", swb.files["cia_o2n2"], "-O2-O2", swb.files["cia_o2o2"],
+            "-a", repr(albedo), "-e", repr(emissivity), "-flux-at-level", str(user_level + 1),
+            "-w-lw", "1", "-W-lw", "3250", "-r-lw", "0.5", "-w-sw", "1", "-W-sw", "20000", "-r-sw", "2"]
+
+    def run(extra, env_extra, name):
+        out = str(tmp_path / name)
+        r = subprocess.run(base + extra + ["-o", out], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, **env_extra))
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+        return parse_output(out)
+
+    grid_sw = api.create_spectral_grid(swb.w0, swb.wn, swb.dw)
+    solar = api.create_solar_flux(grid_sw, swb.files["solar"])
+    emis, alb = np.full(lwb.nw, emissivity), np.full(swb.nw, albedo)
+    want = [(oracle_column(oracle, lib, lwb, c, True, emis, alb, solar, user_level),
+             oracle_column(oracle, lib, swb, c, False, emis, alb, solar, user_level)) for c in cols]
+    names = (("rlutcsaf", 0, 0), ("rluscsaf", 0, 1), ("rlucsaf_user_level", 0, 2), ("rldscsaf", 0, 4), ("rldcsaf_user_level", 0, 5),
+             ("rsutcsaf", 1, 0), ("rsuscsaf", 1, 1), ("rsucsaf_user_level", 1, 2), ("rsdtcsaf", 1, 3), ("rsdscsaf", 1, 4),
+             ("rsdcsaf_user_level", 1, 5))
+    for env, tol in (({}, 1e-6), ({"GRT_GAS_OPTICS_FAST": "3"}, 1e-3)):
+        got = run(["-integrated"], env, "integrated.txt")
+        worst = 0.0
+        for c in range(2):
+            for name, band, k in names:
+                assert got[(c, name)].size == 1
+                worst = max(worst, abs(got[(c, name)][0] - want[c][band]["integ"][k]))
+            assert np.array_equal(got[(c, "level_pressure")], cols[c]["p"])
+            assert got[(c, "surface_temperature")][0] == cols[c]["t_surf"]
+            assert np.allclose(got[(c, "h2o_vmr")], cols[c]["ppmv"][syn.H2O], rtol=1e-14)
+        print(f"reference driver.c main(), {env or 'default (reference order)'}: worst integrated flux difference {worst:.2e} W m-2")
+        assert worst < tol
+    # one column only (-x/-X as run-rfmip-irf.sh shards: GRTworkflow/run-rfmip-irf.sh:121-122), spectral output
+    got = run(["-x", "1", "-X", "1"], {}, "spectral.txt")
+    w = want[1]
+    assert got[(0, "rlutcsaf")].size == lwb.nw and got[(0, "rsdscsaf")].size == swb.nw
+    assert np.max(np.abs(got[(0, "rlutcsaf")] - w[0]["up"][0])) < 1e-10 * np.abs(w[0]["up"]).max()
+    assert np.max(np.abs(got[(0, "rldscsaf")] - w[0]["dn"][-1])) < 1e-10 * np.abs(w[0]["dn"]).max()
+    assert np.max(np.abs(got[(0, "rsdscsaf")] - w[1]["dn"][-1])) < 1e-10 * np.abs(w[1]["dn"]).max()
+    assert np.max(np.abs(got[(0, "rsutcsaf")] - w[1]["up"][0])) < 1e-10 * np.abs(w[1]["dn"]).max()
+    assert np.max(np.abs(got[(0, "rlucsaf_user_level")] - w[0]["up"][user_level])) < 1e-10 * np.abs(w[0]["up"]).max()
