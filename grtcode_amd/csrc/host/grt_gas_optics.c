@@ -107,7 +107,7 @@ static int fixed_field(char const *rec, int off, int len, char *buf)
    w0 <= nu <= wn in `out` (one bucket).  mol_id == 0: every molecule's records, unfiltered, into
    out[molecule - 1] (NUM_MOLS buckets; records of unknown molecule numbers are skipped) -- the parse-once
    index below.  Strengths are left as tabulated (296 K). */
-static int scan_hitran(char const *path, int mol_id, double w0, double wn, GrtHostLines *out)
+static int scan_hitran(char const *path, int mol_id, double w0, double wn, GrtHostLines *out, uint64_t *bad_line)
 {
     FILE *fp = NULL;
     GRT_TRY(open_file(&fp, path, "r"));
@@ -144,38 +144,71 @@ static int scan_hitran(char const *path, int mol_id, double w0, double wn, GrtHo
             if ((rc = host_lines_reserve(o, cap[bucket])) != GRTCODE_SUCCESS) break;
         }
         uint64_t const k = o->n;
+        /* the record's own fields.  One molecule at a time (the reference's behaviour) a field that does not
+           parse is an error; in index mode it is an error only for whoever asks for THAT molecule later
+           (parse_HITRAN_file.c:300-313 never looks at the fields of another molecule's records), so the
+           record is skipped and its line number remembered */
+        int frc = GRTCODE_SUCCESS;
         off = fixed_field(line, off, 1, buf);
         int iso = 0;
         if (buf[0] == '0') iso = 10;
         else if (buf[0] >= 'A' && buf[0] <= 'Z') iso = buf[0] - 'A' + 11;
-        else if ((rc = to_int(buf, &iso)) != GRTCODE_SUCCESS) break;
-        if (iso < 1 || iso > GRT_MAX_ISO)
+        else frc = to_int(buf, &iso);
+        if (frc == GRTCODE_SUCCESS && (iso < 1 || iso > GRT_MAX_ISO))
         {
             grt_err_begin(GRTCODE_VALUE_ERR, __FILE__, __LINE__, "isotopologue %d on line %zu of %s"
                           " is outside 1-%d.", iso, lineno, path, GRT_MAX_ISO);
-            rc = GRTCODE_VALUE_ERR;
-            break;
+            frc = GRTCODE_VALUE_ERR;
         }
-        o->iso[k] = (uint8_t)iso;
         double d;
-        off = fixed_field(line, off, 12, buf);
-        if ((rc = to_double(buf, &d)) != GRTCODE_SUCCESS) break;
-        o->v0[k] = d;
-        off = fixed_field(line, off, 10, buf);
-        if ((rc = to_double(buf, &d)) != GRTCODE_SUCCESS) break;
-        o->s0[k] = d;
-        off += 10;                                     /* Einstein A: unused */
-        float *f32dst[5] = {&o->yair[k], &o->yself[k], &o->en[k], &o->nexp[k], &o->delta[k]};
-        int const width[5] = {5, 5, 10, 4, 8};
-        for (int c = 0; c < 5 && rc == GRTCODE_SUCCESS; ++c)
+        if (frc == GRTCODE_SUCCESS)
         {
-            off = fixed_field(line, off, width[c], buf);
-            if ((rc = to_double(buf, &d)) == GRTCODE_SUCCESS)
+            o->iso[k] = (uint8_t)iso;
+            off = fixed_field(line, off, 12, buf);
+            frc = to_double(buf, &d);
+            o->v0[k] = d;
+        }
+        if (frc == GRTCODE_SUCCESS)
+        {
+            off = fixed_field(line, off, 10, buf);
+            frc = to_double(buf, &d);
+            o->s0[k] = d;
+        }
+        if (frc == GRTCODE_SUCCESS)
+        {
+            off += 10;                                     /* Einstein A: unused */
+            float *f32dst[5] = {&o->yair[k], &o->yself[k], &o->en[k], &o->nexp[k], &o->delta[k]};
+            int const width[5] = {5, 5, 10, 4, 8};
+            for (int c = 0; c < 5 && frc == GRTCODE_SUCCESS; ++c)
             {
-                *f32dst[c] = (float)d;                 /* parse_HITRAN_file.c:197-212 */
+                off = fixed_field(line, off, width[c], buf);
+                if ((frc = to_double(buf, &d)) == GRTCODE_SUCCESS)
+                {
+                    *f32dst[c] = (float)d;                 /* parse_HITRAN_file.c:197-212 */
+                }
             }
         }
-        if (rc != GRTCODE_SUCCESS) break;
+        if (frc == GRTCODE_SUCCESS && !(isfinite(o->v0[k]) && isfinite(o->s0[k])))
+        {
+            grt_err_begin(GRTCODE_VALUE_ERR, __FILE__, __LINE__, "non-finite line centre or strength on line %zu"
+                          " of %s.", lineno, path);
+            frc = GRTCODE_VALUE_ERR;
+        }
+        if (frc != GRTCODE_SUCCESS)
+        {
+            if (mol_id == 0 && bad_line != NULL)
+            {
+                if (bad_line[bucket] == 0)
+                {
+                    bad_line[bucket] = lineno;
+                    GRT_WARN("record %zu of %s (molecule %d) does not parse; requests for that molecule will fail.",
+                             lineno, path, mol);
+                }
+                continue;
+            }
+            rc = frc;
+            break;
+        }
         if (mol_id == 0 || (w0 < 0 && wn < 0) || (o->v0[k] >= w0 && o->v0[k] <= wn))
         {
             o->n++;
@@ -210,6 +243,8 @@ typedef struct HitranIndex
     long long size, mtime;
     unsigned long stamp;
     GrtHostLines mol[NUM_MOLS];
+    uint64_t bad_line[NUM_MOLS];   /* first record of a molecule the parser refused (0: none): a request for THAT
+                                      molecule re-scans the file and fails like the reference; others are served */
 } HitranIndex;
 static HitranIndex g_hitran_index[2];
 static unsigned long g_hitran_stamp = 0;
@@ -218,13 +253,16 @@ static long long g_hitran_stats[3];     /* requests served from memory, index fi
 /* On-disk copy of the index (GRT_HITRAN_CACHE_DIR=<directory> in the environment): one binary file per
    (.par path, size, modification time), the arrays of every molecule as they sit in memory.  A later
    process reads that instead of parsing text: a few hundred MB of %12lf fields become a few reads. */
-#define GRT_IDX_MAGIC "GRTIDX01"
+#define GRT_IDX_MAGIC "GRTIDX02"
 typedef struct IndexHeader
 {
     char magic[8];
     long long size, mtime;
     uint64_t num_mols, path_hash;
+    uint64_t max_iso, record_bytes;    /* GRT_MAX_ISO and the bytes per line of the arrays below: a build with other limits re-parses */
+    uint64_t checksum;                 /* FNV-1a over every array, in file order */
     uint64_t n[NUM_MOLS];
+    uint64_t bad_line[NUM_MOLS];       /* first record of that molecule the text parser refused (0: none) */
 } IndexHeader;
 
 static uint64_t fnv1a(char const *str)
@@ -250,6 +288,33 @@ static int index_file_name(char const *par, long long size, long long mtime, cha
 
 static size_t const g_idx_width[8] = {sizeof(double), sizeof(double), sizeof(float), sizeof(float), sizeof(float),
                                       sizeof(float), sizeof(float), sizeof(uint8_t)};
+#define GRT_IDX_RECORD_BYTES (2*sizeof(double) + 5*sizeof(float) + sizeof(uint8_t))
+
+static uint64_t fnv1a_bytes(uint64_t h, void const *data, size_t bytes)
+{
+    unsigned char const *p = data;
+    for (size_t i = 0; i < bytes; ++i)
+    {
+        h = (h ^ p[i])*1099511628211ull;
+    }
+    return h;
+}
+
+static uint64_t index_checksum(GrtHostLines *mol)
+{
+    uint64_t h = 1469598103934665603ull;
+    for (int m = 0; m < NUM_MOLS; ++m)
+    {
+        void *a[8];
+        a[0] = mol[m].v0; a[1] = mol[m].s0; a[2] = mol[m].yair; a[3] = mol[m].yself; a[4] = mol[m].en;
+        a[5] = mol[m].nexp; a[6] = mol[m].delta; a[7] = mol[m].iso;
+        for (int k = 0; k < 8 && mol[m].n > 0; ++k)
+        {
+            h = fnv1a_bytes(h, a[k], g_idx_width[k]*mol[m].n);
+        }
+    }
+    return h;
+}
 static void idx_arrays(GrtHostLines *l, void *a[8])
 {
     a[0] = l->v0; a[1] = l->s0; a[2] = l->yair; a[3] = l->yself; a[4] = l->en; a[5] = l->nexp; a[6] = l->delta;
@@ -257,7 +322,8 @@ static void idx_arrays(GrtHostLines *l, void *a[8])
 }
 
 /* 1 when the index was read from its file; 0 when there is none (or it does not match: the caller scans). */
-static int index_read(char const *file, char const *par, long long size, long long mtime, GrtHostLines *mol)
+static int index_read(char const *file, char const *par, long long size, long long mtime, GrtHostLines *mol,
+                      uint64_t *bad_line)
 {
     FILE *fp = fopen(file, "rb");
     if (fp == NULL)
@@ -266,7 +332,8 @@ static int index_read(char const *file, char const *par, long long size, long lo
     }
     IndexHeader h;
     int ok = fread(&h, sizeof(h), 1, fp) == 1 && memcmp(h.magic, GRT_IDX_MAGIC, 8) == 0 && h.size == size
-             && h.mtime == mtime && h.num_mols == NUM_MOLS && h.path_hash == fnv1a(par);
+             && h.mtime == mtime && h.num_mols == NUM_MOLS && h.path_hash == fnv1a(par)
+             && h.max_iso == GRT_MAX_ISO && h.record_bytes == GRT_IDX_RECORD_BYTES;
     for (int m = 0; m < NUM_MOLS && ok; ++m)
     {
         if (h.n[m] == 0)
@@ -284,6 +351,20 @@ static int index_read(char const *file, char const *par, long long size, long lo
     }
     ok = ok && fgetc(fp) == EOF;        /* nothing may follow the last array */
     fclose(fp);
+    /* the file is trusted no further than the text would be: same bytes as written (checksum), isotopologue codes
+       inside the range the kernels index 1/Q with, finite centres and strengths */
+    ok = ok && index_checksum(mol) == h.checksum;
+    for (int m = 0; m < NUM_MOLS && ok; ++m)
+    {
+        for (uint64_t k = 0; k < mol[m].n && ok; ++k)
+        {
+            ok = mol[m].iso[k] >= 1 && mol[m].iso[k] <= GRT_MAX_ISO && isfinite(mol[m].v0[k]) && isfinite(mol[m].s0[k]);
+        }
+    }
+    if (ok)
+    {
+        memcpy(bad_line, h.bad_line, sizeof(h.bad_line));
+    }
     if (!ok)
     {
         for (int m = 0; m < NUM_MOLS; ++m)
@@ -296,7 +377,8 @@ static int index_read(char const *file, char const *par, long long size, long lo
 
 /* Best effort: a cache that cannot be written is not an error.  Written under a temporary name and renamed,
    so that a reader never sees half a file. */
-static void index_write(char const *file, char const *par, long long size, long long mtime, GrtHostLines *mol)
+static void index_write(char const *file, char const *par, long long size, long long mtime, GrtHostLines *mol,
+                        uint64_t const *bad_line)
 {
     char tmp[DIR_PATH_LEN + 64];
     if (snprintf(tmp, sizeof(tmp), "%s.%ld.tmp", file, (long)getpid()) >= (int)sizeof(tmp))
@@ -312,9 +394,12 @@ static void index_write(char const *file, char const *par, long long size, long 
     memset(&h, 0, sizeof(h));
     memcpy(h.magic, GRT_IDX_MAGIC, 8);
     h.size = size; h.mtime = mtime; h.num_mols = NUM_MOLS; h.path_hash = fnv1a(par);
+    h.max_iso = GRT_MAX_ISO; h.record_bytes = GRT_IDX_RECORD_BYTES;
+    h.checksum = index_checksum(mol);
     for (int m = 0; m < NUM_MOLS; ++m)
     {
         h.n[m] = mol[m].n;
+        h.bad_line[m] = bad_line[m];
     }
     int ok = fwrite(&h, sizeof(h), 1, fp) == 1;
     for (int m = 0; m < NUM_MOLS && ok; ++m)
@@ -364,7 +449,8 @@ static int hitran_index(char const *path, HitranIndex **out)
     victim->stamp = 0;
     char file[DIR_PATH_LEN + 64];
     int const on_disk = index_file_name(path, (long long)st.st_size, mtime, file, sizeof(file));
-    if (on_disk && index_read(file, path, (long long)st.st_size, mtime, victim->mol))
+    memset(victim->bad_line, 0, sizeof(victim->bad_line));
+    if (on_disk && index_read(file, path, (long long)st.st_size, mtime, victim->mol, victim->bad_line))
     {
         GRT_INFO("Read the index of %s from %s.", path, file);
         g_hitran_stats[1]++;
@@ -372,11 +458,11 @@ static int hitran_index(char const *path, HitranIndex **out)
     else
     {
         GRT_INFO("Indexing HITRAN line parameters of every molecule in %s.", path);
-        GRT_TRY(scan_hitran(path, 0, 0., 0., victim->mol));
+        GRT_TRY(scan_hitran(path, 0, 0., 0., victim->mol, victim->bad_line));
         g_hitran_stats[2]++;
         if (on_disk)
         {
-            index_write(file, path, (long long)st.st_size, mtime, victim->mol);
+            index_write(file, path, (long long)st.st_size, mtime, victim->mol, victim->bad_line);
         }
     }
     GRT_TRY(copy_str(victim->path, path, DIR_PATH_LEN));
@@ -405,12 +491,18 @@ int grt_parse_hitran(char const *path, int mol_id, double w0, double wn, GrtHost
     if (mol_id < 1 || mol_id > NUM_MOLS || (env != NULL && env[0] == '0'))
     {
         GRT_INFO("Reading HITRAN line parameters for molecule %d from %s.", mol_id, path);
-        GRT_TRY(scan_hitran(path, mol_id, w0, wn, out));
+        GRT_TRY(scan_hitran(path, mol_id, w0, wn, out, NULL));
     }
     else
     {
         HitranIndex *idx = NULL;
         GRT_TRY(hitran_index(path, &idx));
+        if (idx->bad_line[mol_id - 1] != 0)
+        {
+            /* this molecule has a record the parser refused: scan for it alone, which fails there as the reference does */
+            GRT_TRY(scan_hitran(path, mol_id, w0, wn, out, NULL));
+            return GRTCODE_SUCCESS;
+        }
         GrtHostLines const *src = &idx->mol[mol_id - 1];
         if (src->n > 0)
         {
@@ -666,6 +758,7 @@ static int register_molecule(GasOptics_t *go, int molecule_id, GrtHostLines *lin
     GRT_MESG("Using %s (%zu lines in range %e - %e [1/cm]).", mol->name,
              (size_t)mol->line_params.num_lines, w0, wn);
 
+    int rc_ctm = GRTCODE_SUCCESS;
     if (molecule_id == H2O && go->use_h2o_ctm)
     {
         /* water_vapor_continuum.c:49-64 file names, :57-64 column counts */
@@ -688,16 +781,34 @@ static int register_molecule(GasOptics_t *go, int molecule_id, GrtHostLines *lin
             }
         }
         free(host);
-        GRT_TRY(rc);
+        rc_ctm = rc;
         go->h2o_cc.num_wpoints = go->grid.n;
         go->h2o_cc.device = go->device;
     }
     if (molecule_id == O3 && go->use_o3_ctm)
     {
         GRT_MESG("Using the %s continuum.", mol->name);
-        GRT_TRY(add_linear_table(go, go->o3_ctm_file, 0, index, &go->o3_cc.cross_section));
+        rc_ctm = add_linear_table(go, go->o3_ctm_file, 0, index, &go->o3_cc.cross_section);
         go->o3_cc.num_wpoints = go->grid.n;
         go->o3_cc.device = go->device;
+    }
+    if (rc_ctm != GRTCODE_SUCCESS)
+    {
+        /* a continuum file that does not load leaves no half-registered molecule behind */
+        grt_err_frame(__FILE__, __LINE__);
+        grt_free_host_lines(&im->host[index]);
+        if (molecule_id == H2O)
+        {
+            grt_dev_free(go->device, im->h2o_tables);
+            im->h2o_tables = NULL;
+            free(go->h2o_cc.coefs);
+            go->h2o_cc.coefs = NULL;
+            go->h2o_cc.num_wpoints = 0;
+        }
+        go->molecule_bit_field &= ~((uint64_t)1 << (molecule_id - 1));
+        go->num_molecules--;
+        memset(mol, 0, sizeof(*mol));
+        return rc_ctm;
     }
     return GRTCODE_SUCCESS;
 }

@@ -40,6 +40,8 @@ struct GrtPipeline
     double *emis_d, *albedo_d, *solar_d;
 };
 
+static void grt_pipeline_release(GrtPipeline_t **pipeline);
+
 static int band_alloc(GrtPipeline_t *p, GrtBand *b, GasOptics_t *gas)
 {
     memset(b, 0, sizeof(*b));
@@ -65,6 +67,10 @@ static int band_alloc(GrtPipeline_t *p, GrtBand *b, GasOptics_t *gas)
     GRT_TRY(grt_dev_zero(p->device, b->zero_row, sizeof(double)*b->n, s));
     /* row table: up TOA, up surface, up user, down TOA, down surface, down user (driver.c:272-280) */
     double **rows_h = malloc(sizeof(double *)*C*6);
+    if (rows_h == NULL)
+    {
+        GRT_FAIL(GRTCODE_NULL_ERR, "out of host memory for the row table of %zu columns.", C);
+    }
     for (size_t c = 0; c < C; ++c)
     {
         double *up = b->flux_up + c*V*b->n, *dn = b->flux_down + c*V*b->n;
@@ -83,25 +89,9 @@ static int band_alloc(GrtPipeline_t *p, GrtBand *b, GasOptics_t *gas)
     return GRTCODE_SUCCESS;
 }
 
-EXTERN int grt_pipeline_create(GrtPipeline_t **pipeline, GasOptics_t *lw_gas, GasOptics_t *sw_gas,
-                               int max_columns, int user_level, fp_t const *emissivity,
-                               fp_t const *albedo, fp_t const *solar_flux)
+static int pipeline_build(GrtPipeline_t *p, GasOptics_t *lw_gas, GasOptics_t *sw_gas, int max_columns,
+                          fp_t const *emissivity, fp_t const *albedo, fp_t const *solar_flux)
 {
-    GRT_REQUIRE_PTR(pipeline);
-    GRT_REQUIRE_RANGE(max_columns, 1, 65535);
-    GasOptics_t *any = lw_gas ? lw_gas : sw_gas;
-    GRT_REQUIRE_PTR(any);
-    if (lw_gas && sw_gas)
-    {
-        GRT_REQUIRE_EQ(lw_gas->device, sw_gas->device);
-        GRT_REQUIRE_EQ(lw_gas->num_levels, sw_gas->num_levels);
-    }
-    GRT_REQUIRE_RANGE(user_level, -1, any->num_levels - 1);
-    GrtPipeline_t *p = calloc(1, sizeof(*p));
-    p->device = any->device;
-    p->max_cols = max_columns;
-    p->num_levels = any->num_levels;
-    p->user_level = user_level;
     GRT_TRY(grt_dev_require(p->device));
     GRT_TRY(band_alloc(p, &p->band[0], lw_gas));
     GRT_TRY(band_alloc(p, &p->band[1], sw_gas));
@@ -140,31 +130,73 @@ EXTERN int grt_pipeline_create(GrtPipeline_t **pipeline, GasOptics_t *lw_gas, Ga
         GRT_TRY(grt_dev_upload(p->device, p->solar_d, solar_flux, sizeof(double)*sw_gas->grid.n, s));
     }
     GRT_TRY(grt_dev_sync(p->device, s));
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN int grt_pipeline_create(GrtPipeline_t **pipeline, GasOptics_t *lw_gas, GasOptics_t *sw_gas,
+                               int max_columns, int user_level, fp_t const *emissivity,
+                               fp_t const *albedo, fp_t const *solar_flux)
+{
+    GRT_REQUIRE_PTR(pipeline);
+    GRT_REQUIRE_RANGE(max_columns, 1, 65535);
+    GasOptics_t *any = lw_gas ? lw_gas : sw_gas;
+    GRT_REQUIRE_PTR(any);
+    if (lw_gas && sw_gas)
+    {
+        GRT_REQUIRE_EQ(lw_gas->device, sw_gas->device);
+        GRT_REQUIRE_EQ(lw_gas->num_levels, sw_gas->num_levels);
+    }
+    GRT_REQUIRE_RANGE(user_level, -1, any->num_levels - 1);
+    GrtPipeline_t *p = calloc(1, sizeof(*p));
+    if (p == NULL)
+    {
+        GRT_FAIL(GRTCODE_NULL_ERR, "out of host memory for the pipeline object.%s", "");
+    }
+    p->device = any->device;
+    p->max_cols = max_columns;
+    p->num_levels = any->num_levels;
+    p->user_level = user_level;
+    /* one way out: whatever a failing step leaves allocated (GBs of HBM per band) goes back through destroy */
+    int const rc = pipeline_build(p, lw_gas, sw_gas, max_columns, emissivity, albedo, solar_flux);
+    if (rc != GRTCODE_SUCCESS)
+    {
+        grt_err_frame(__FILE__, __LINE__);
+        GrtPipeline_t *dead = p;
+        grt_pipeline_release(&dead);
+        return rc;
+    }
     *pipeline = p;
     return GRTCODE_SUCCESS;
+}
+
+/* Frees everything a (possibly half-built) pipeline holds; never touches the error text of a failure in flight. */
+static void grt_pipeline_release(GrtPipeline_t **pipeline)
+{
+    GrtPipeline_t *p = *pipeline;
+    for (int b = 0; b < 2; ++b)
+    {
+        grt_dev_free(p->device, p->band[b].tau_gas);
+        grt_dev_free(p->device, p->band[b].rows_d);
+    }
+    grt_dev_free(p->device, p->small_d);
+    grt_host_free_pinned(p->small_h);
+    grt_dev_event_destroy(p->device, &p->small_uploaded);
+    grt_dev_free(p->device, p->emis_d);
+    grt_dev_free(p->device, p->albedo_d);
+    grt_dev_free(p->device, p->solar_d);
+    free(p);
+    *pipeline = NULL;
 }
 
 EXTERN int grt_pipeline_destroy(GrtPipeline_t **pipeline)
 {
     GRT_REQUIRE_PTR(pipeline);
-    GrtPipeline_t *p = *pipeline;
-    if (p == NULL)
+    if (*pipeline == NULL)
     {
         return GRTCODE_SUCCESS;
     }
-    for (int b = 0; b < 2; ++b)
-    {
-        GRT_TRY(grt_dev_free(p->device, p->band[b].tau_gas));
-        GRT_TRY(grt_dev_free(p->device, p->band[b].rows_d));
-    }
-    GRT_TRY(grt_dev_free(p->device, p->small_d));
-    GRT_TRY(grt_host_free_pinned(p->small_h));
-    GRT_TRY(grt_dev_event_destroy(p->device, &p->small_uploaded));
-    GRT_TRY(grt_dev_free(p->device, p->emis_d));
-    GRT_TRY(grt_dev_free(p->device, p->albedo_d));
-    GRT_TRY(grt_dev_free(p->device, p->solar_d));
-    free(p);
-    *pipeline = NULL;
+    GRT_TRY(grt_dev_sync((*pipeline)->device, grt_dev_stream((*pipeline)->device)));
+    grt_pipeline_release(pipeline);
     return GRTCODE_SUCCESS;
 }
 

@@ -237,6 +237,19 @@ def test_hitran_index_on_disk(lib, tmp_path, monkeypatch):
     assert [b - a for a, b in zip(s2, stats())][1:] == [0, 1]         # scanned again ...
     assert idx[0].read_bytes() == blob                                # ... and the index rewritten
     assert all(np.array_equal(first[k], third[k]) for k in first)
+    # a same-length index file with one byte changed (an isotopologue code out of range, a flipped strength bit) fails
+    # its checksum / content checks and is not trusted either (the kernels index 1/Q by that code)
+    for pos in (len(blob) - 3, len(blob) // 2):
+        bad = bytearray(blob)
+        bad[pos] = 200 if pos == len(blob) - 3 else bad[pos] ^ 0x10
+        idx[0].write_bytes(bytes(bad))
+        read(files[1], syn.CO2)
+        read(files[2], syn.CO2)
+        s3 = stats()
+        fourth = read(files[0], syn.CO2)
+        assert [b - a for a, b in zip(s3, stats())][1:] == [0, 1]
+        assert idx[0].read_bytes() == blob
+        assert all(np.array_equal(first[k], fourth[k]) for k in first)
     # without the variable nothing is written
     monkeypatch.delenv("GRT_HITRAN_CACHE_DIR")
     lists = {syn.H2O: syn.line_list(syn.H2O, 20, 50.0, 2500.0, seed=3)}
@@ -244,6 +257,36 @@ def test_hitran_index_on_disk(lib, tmp_path, monkeypatch):
     syn.write_hitran_par(path, lists)
     read(path, syn.H2O)
     assert len(list(cache.glob("*.grtidx"))) == 3
+
+
+def test_bad_record_of_another_molecule_does_not_fail_the_one_asked_for(lib, tmp_path, monkeypatch):
+    """The reference looks only at the records of the molecule it was asked for (parse_HITRAN_file.c:300-313); the
+    parse-once index reads every molecule's records, so a field that does not parse is held against its own molecule
+    only: other molecules load, that molecule fails like a scan for it alone does."""
+    lists = {m: syn.line_list(m, 40, 100.0, 900.0) for m in (syn.H2O, syn.CO2, syn.CH4)}
+    path = str(tmp_path / "lines.par")
+    syn.write_hitran_par(path, lists)
+    text = open(path).read().splitlines(keepends=True)
+    k = next(i for i, ln in enumerate(text) if ln.startswith(" 6"))            # a CH4 record: break its strength field
+    text[k] = text[k][:15] + "  NOT-A-NUM" [:10].ljust(10) + text[k][25:]
+    assert len(text[k]) == 161
+    open(path, "w").write("".join(text))
+    for cache in ("1", "0"):
+        monkeypatch.setenv("GRT_HITRAN_CACHE", cache)
+        for mol, want in ((syn.H2O, 0), (syn.CO2, 0), (syn.CH4, api.VALUE_ERR)):
+            hl = HostLines()
+            assert lib.grt_parse_hitran(path.encode(), mol, C.c_double(100.0), C.c_double(900.0), C.byref(hl)) == want, (cache, mol)
+            if want == 0:
+                assert hl.n == 40
+                lib.grt_free_host_lines(C.byref(hl))
+    # an isotopologue code the kernels could not index is refused for its molecule as well
+    text[k] = (" 6" + "Z" + text[k][3:15] + " 1.000E-25" + text[k][25:])
+    open(path, "w").write("".join(text))
+    monkeypatch.setenv("GRT_HITRAN_CACHE", "1")
+    hl = HostLines()
+    assert lib.grt_parse_hitran(path.encode(), syn.H2O, C.c_double(100.0), C.c_double(900.0), C.byref(hl)) == 0
+    lib.grt_free_host_lines(C.byref(hl))
+    assert lib.grt_parse_hitran(path.encode(), syn.CH4, C.c_double(100.0), C.c_double(900.0), C.byref(hl)) == api.VALUE_ERR
 
 
 def test_table_loader_and_solar_flux(lib, oracle, tmp_path):
