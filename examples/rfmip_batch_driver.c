@@ -21,8 +21,16 @@
  * Usage:  rfmip_batch_driver HITRAN.par SOLAR.csv COLUMNS.bin [-h2o-ctm DIR] [-o3-ctm FILE] [-CFC-11 FILE ppmv]
  *             [-CFC-12 FILE ppmv] [-N2-N2 FILE] [-O2-N2 FILE] [-O2-O2 FILE] [-w-lw W0 -W-lw WN -r-lw DW]
  *             [-w-sw W0 -W-sw WN -r-sw DW] [-chunk N] [-fast 0|1|2|3] [-d DEVICE]
+ *             [-ranks N -rank K -rendezvous DIR [-transport rccl|files]]
  * Output: one line per column "col <i>: rlut rlus rldt rlds rsut rsus rsdt rsds" [W m-2] (zeros for the shortwave
  * of night columns).
+ *
+ * Several GPUs of one node: start one process per GPU with the same arguments plus -ranks N -rank K (K = 0..N-1,
+ * normally with -d K) and a directory all of them see.  Every rank computes its contiguous block of the columns
+ * (grt_multi_shard -- the in-node form of run-rfmip-irf.sh's -x/-X fan-out, GRTworkflow/run-rfmip-irf.sh:103-132) and
+ * one gather brings the flux blocks to rank 0, which prints all columns: ncclGather over xGMI (-transport rccl, the
+ * default) or per-rank files in the rendezvous directory (-transport files: the reference's per-shard outputs +
+ * combiner in one step; also how several ranks share one GPU in tests).
  */
 #include <math.h>
 #include <stdio.h>
@@ -201,7 +209,24 @@ int main(int argc, char **argv)
     check(grt_pipeline_create(&pipe_night, &lbl[0], NULL, chunk, -1, emissivity, NULL, NULL));
     fp_t *fluxes_dev;
     check(grt_device_malloc(device, (void **)&fluxes_dev, sizeof(fp_t)*chunk*GRT_FLUXES_PER_COLUMN));
-    fp_t *fluxes = calloc((size_t)ncol*GRT_FLUXES_PER_COLUMN, sizeof(fp_t));
+    /* this rank's block of the columns */
+    int const world = (int)number(argc, argv, "-ranks", 1.), rank = (int)number(argc, argv, "-rank", 0.);
+    int shard_first = 0, shard_count = ncol;
+    GrtMulti_t *multi = NULL;
+    if (world > 1)
+    {
+        char const *dir = option(argc, argv, "-rendezvous", 1), *tr = option(argc, argv, "-transport", 1);
+        if (dir == NULL)
+        {
+            fprintf(stderr, "-ranks needs -rendezvous DIR\n");
+            return EXIT_FAILURE;
+        }
+        check(grt_multi_create(&multi, tr != NULL && strcmp(tr, "files") == 0 ? GRT_MULTI_FILES : GRT_MULTI_RCCL, device,
+                               rank, world, dir));
+        check(grt_multi_shard(ncol, rank, world, &shard_first, &shard_count));
+    }
+    int const per_rank = (ncol + world - 1)/world;
+    fp_t *fluxes = calloc((size_t)per_rank*world*GRT_FLUXES_PER_COLUMN, sizeof(fp_t));
     fp_t *host = malloc(sizeof(fp_t)*chunk*GRT_FLUXES_PER_COLUMN);
     /* day and night columns go through different pipelines; keep chunks contiguous in each class */
     for (int night = 0; night < 2; ++night)
@@ -209,7 +234,7 @@ int main(int argc, char **argv)
         int *ids = malloc(sizeof(int)*ncol), n = 0;
         for (int c = 0; c < ncol; ++c)
         {
-            if ((mu[c] <= 0.) == (night == 1)) ids[n++] = c;
+            if (c >= shard_first && c < shard_first + shard_count && (mu[c] <= 0.) == (night == 1)) ids[n++] = c;
         }
         for (int first = 0; first < n; first += chunk)
         {
@@ -244,7 +269,39 @@ int main(int argc, char **argv)
         }
         free(ids);
     }
-    for (int c = 0; c < ncol; ++c)
+    if (multi != NULL)
+    {
+        /* one gather of the [columns][12] blocks to rank 0 */
+        fp_t *local = fluxes + (size_t)shard_first*GRT_FLUXES_PER_COLUMN;
+        char const *tr = option(argc, argv, "-transport", 1);
+        if (tr != NULL && strcmp(tr, "files") == 0)
+        {
+            fp_t *all = rank == 0 ? calloc((size_t)per_rank*world*GRT_FLUXES_PER_COLUMN, sizeof(fp_t)) : NULL;
+            check(grt_multi_gather_fluxes(multi, local, ncol, all, 0));
+            if (rank == 0)
+            {
+                memcpy(fluxes, all, sizeof(fp_t)*(size_t)ncol*GRT_FLUXES_PER_COLUMN);
+                free(all);
+            }
+        }
+        else
+        {
+            size_t const block = sizeof(fp_t)*(size_t)per_rank*GRT_FLUXES_PER_COLUMN;
+            fp_t *local_dev = NULL, *all_dev = NULL;
+            check(grt_device_malloc(device, (void **)&local_dev, block));
+            if (rank == 0) check(grt_device_malloc(device, (void **)&all_dev, block*world));
+            if (shard_count > 0) check(grt_host_to_device(device, local_dev, local, sizeof(fp_t)*(size_t)shard_count*GRT_FLUXES_PER_COLUMN));
+            check(grt_multi_gather_fluxes(multi, local_dev, ncol, all_dev, 1));
+            check(grt_pipeline_sync(pipe_day));            /* the gather runs on the library stream */
+            if (rank == 0) check(grt_device_to_host(device, fluxes, all_dev, sizeof(fp_t)*(size_t)ncol*GRT_FLUXES_PER_COLUMN));
+            check(grt_device_free(device, local_dev));
+            check(grt_device_free(device, all_dev));
+        }
+        double seconds = 0.;
+        check(grt_multi_max(multi, &seconds));             /* everybody is done before anybody tears down */
+        check(grt_multi_destroy(&multi));
+    }
+    for (int c = 0; c < ncol && rank == 0; ++c)
     {
         fp_t const *x = fluxes + (size_t)c*GRT_FLUXES_PER_COLUMN;
         printf("col %d: %.15e %.15e %.15e %.15e %.15e %.15e %.15e %.15e\n", c, x[0], x[1], x[3], x[4], x[6], x[7], x[9], x[10]);

@@ -19,7 +19,7 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 SO = os.path.join(LIB, "libgrtcode_hip.so")
 
 HOST_SRC = ["grt_error.c", "grt_util.c", "grt_grid.c", "grt_device.c", "grt_optics.c", "grt_tips.c",
-            "grt_gas_optics.c", "grt_solvers.c", "grt_pipeline.c", "grt_clouds.c"]
+            "grt_gas_optics.c", "grt_solvers.c", "grt_pipeline.c", "grt_multi.c", "grt_clouds.c"]
 NOT_IN_SO = {"grt_clouds"}      # libclouds.a only: a maintainer links the reference's own libclouds.a in its place
 HIP_SRC = ["k_gas_optics.hip", "k_gas_optics_mp.hip", "k_gas_optics_sweep.hip", "k_optics.hip", "k_longwave.hip", "k_shortwave.hip"]
 
@@ -30,7 +30,7 @@ ARCHIVES = {
     "liblongwave.a": ["k_longwave"],
     "libshortwave.a": ["k_shortwave"],
     # solvers' host entry points and the batched pipeline reference both bands
-    "libgrtcode_hip_ext.a": ["grt_solvers", "grt_pipeline"],
+    "libgrtcode_hip_ext.a": ["grt_solvers", "grt_pipeline", "grt_multi"],
     # the reference's cloud-optics archive name: entry points only (SURVEY §8 f-4 is not built), so that
     # framework/src/driver.c links unchanged
     "libclouds.a": ["grt_clouds"],
@@ -78,7 +78,7 @@ def build(force=False, verbose=False):
     if force or any(_newer(o, SO) for o in objs):
         _run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] +
              [o for o in objs if os.path.basename(o)[:-2] not in NOT_IN_SO] +
-             [f"-L{ROCM}/lib", "-lamdhip64", "-lm", f"-Wl,-rpath,{ROCM}/lib"])
+             [f"-L{ROCM}/lib", "-lamdhip64", "-lm", "-ldl", f"-Wl,-rpath,{ROCM}/lib"])
         for name, members in ARCHIVES.items():
             path = os.path.join(LIB, name)
             if os.path.exists(path):

@@ -115,6 +115,27 @@ EXTERN void *grt_pipeline_stream(GrtPipeline_t *pipeline);
 EXTERN int grt_pipeline_views(GrtPipeline_t *pipeline, int band, fp_t **tau_gas, fp_t **tau,
                               fp_t **omega, fp_t **g, fp_t **flux_up, fp_t **flux_down);
 
+/* ---- columns across the GPUs of one node ------------------------------------
+ * One process per GPU; contiguous ceil-sized column blocks; one gather of the [columns][GRT_FLUXES_PER_COLUMN]
+ * flux blocks to rank 0.  The reference fans out processes with -x/-X column ranges and merges per-shard files
+ * afterwards (GRTworkflow/run-rfmip-irf.sh:103-148); this is that scheme inside one node.
+ * transport GRT_MULTI_RCCL: ncclGather over xGMI on the library stream (device pointers, asynchronous; the
+ * communicator id travels through `rendezvous_dir`, a directory all ranks see); GRT_MULTI_FILES: per-rank files in
+ * `rendezvous_dir` assembled by rank 0 (host or device pointers, synchronous) -- the reference's own scheme, and the
+ * way the multi-rank path runs where there is no GPU.  GRT_MULTI_TIMEOUT [s] bounds every wait (default 600). */
+enum grt_multi_transport { GRT_MULTI_RCCL = 0, GRT_MULTI_FILES = 1 };
+typedef struct GrtMulti GrtMulti_t;
+/* rank's block of a num_columns-column set: [first, first + count), count <= ceil(num_columns/world), 0 for ranks beyond the end */
+EXTERN int grt_multi_shard(int num_columns, int rank, int world, int *first, int *count);
+EXTERN int grt_multi_create(GrtMulti_t **multi, int transport, Device_t device, int rank, int world,
+                            char const *rendezvous_dir);
+EXTERN int grt_multi_destroy(GrtMulti_t **multi);
+/* local: this rank's [count][12] block; all (rank 0 only): room for world*ceil(num_columns/world) rows, the first
+   num_columns of which are the columns in order (short blocks are padded, so no sizes are exchanged). */
+EXTERN int grt_multi_gather_fluxes(GrtMulti_t *multi, fp_t const *local, int num_columns, fp_t *all, int on_device);
+EXTERN int grt_multi_broadcast(GrtMulti_t *multi, void *buffer_dev, size_t bytes);   /* RCCL only: replicate from rank 0 */
+EXTERN int grt_multi_max(GrtMulti_t *multi, double *value);    /* barrier + maximum over the ranks (timing brackets) */
+
 /* ---- HIP-event timing of individual kernels on the library stream -------------------
  * Tags: 1 = line-by-line kernel on a grid of <= 10 000 points (longwave band at 1 cm-1),
  * 2 = line-by-line kernel on a larger grid (shortwave band), 3 = LW solver, 4 = SW solver,

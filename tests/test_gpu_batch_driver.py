@@ -96,3 +96,43 @@ def test_batched_c_driver_matches_oracle(tmp_path, oracle, lib):
             assert np.all(got[c][4:] == 0.0)                          # night: no shortwave (driver.c:706)
     print(f"batched C driver, {ncol} columns: worst flux difference {worst:.2e} W m-2")
     assert worst < 1e-4
+
+    # ---- the same run as THREE ranks (one process each, sharing this GPU), 7 columns -> blocks of 3, 3, 1, flux blocks
+    # gathered to rank 0 through the library's C entry points grt_multi_* (SURVEY §8e).  File transport here: RCCL wants
+    # one GPU per rank (below: RCCL at world size 1).
+    rdv = tmp_path / "rdv"
+    rdv.mkdir()
+    procs = [subprocess.Popen(args + ["-ranks", "3", "-rank", str(k), "-rendezvous", str(rdv), "-transport", "files"],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              env=dict(os.environ, GRT_MULTI_TIMEOUT="300")) for k in range(3)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    for k, p in enumerate(procs):
+        assert p.returncode == 0, (k, outs[k][1][-2000:])
+    sharded = {}
+    for line in outs[0][0].splitlines():
+        if line.startswith("col "):
+            head, vals = line.split(":")
+            sharded[int(head.split()[1])] = np.array([float(x) for x in vals.split()])
+    assert sorted(sharded) == list(range(ncol))
+    assert not any(l.startswith("col ") for k in (1, 2) for l in outs[k][0].splitlines())     # only rank 0 reports
+    for c in range(ncol):
+        assert np.max(np.abs(sharded[c] - got[c])) < 1e-7          # a column's fluxes do not depend on its shard (atomics: ~1e-9)
+
+    # ---- RCCL transport, world size 1: communicator through the rendezvous directory, ncclGather on the library stream
+    rdv1 = tmp_path / "rdv1"
+    rdv1.mkdir()
+    r = subprocess.run(args + ["-ranks", "1", "-rank", "0", "-rendezvous", str(rdv1)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]                      # (-ranks 1: no communicator is made)
+    from grtcode_amd import multi
+    import ctypes as C
+    m = multi.Multi(multi.RCCL, 0, 0, 1, str(rdv1))
+    assert (rdv1 / "rccl_unique_id.bin").stat().st_size == 128
+    block = np.arange(5 * 12, dtype=np.float64).reshape(5, 12)
+    src, dst = api.DeviceBuffer(0, block.nbytes), api.DeviceBuffer(0, block.nbytes)
+    api.check(lib.grt_host_to_device(0, src.ptr, block.ctypes.data_as(C.c_void_p), block.nbytes))
+    m.gather_fluxes(src.ptr.value, 5, dst.ptr.value, True)
+    assert m.max(3.25) == 3.25                                       # (synchronises the stream)
+    assert np.array_equal(dst.to_host((5, 12)), block)
+    m.destroy()
+    src.free()
+    dst.free()
