@@ -7,8 +7,11 @@ synthetic columns.  A step = one batch of COLS columns per GPU through the whole
 (host prologue -> line-by-line tau -> Rayleigh+combine -> LW/SW solver -> spectral integration
 -> [N>1] RCCL gather of the 12 integrated fluxes per column to rank 0).  Line lists and tables
 are resident in HBM before the timed region; per-column inputs are 61-level host profiles.
-Weak scaling: every rank processes its own COLS columns per step (columns shard with no
-data-path collective other than that final gather).
+Weak scaling (default): every rank processes its own COLS columns per step (columns shard with no
+data-path collective other than that final gather).  Strong scaling (--columns N, e.g. 100 for
+BASELINE.json's RFMIP-IRF config, 1800 for the replicated set): a step is the whole fixed set of N
+columns, sharded over the ranks in ceil-sized contiguous blocks (100 over 8 GPUs: 13 x 7 + 9), each
+rank running its block in chunks of COLS.
 """
 import argparse
 import json
@@ -93,6 +96,8 @@ def main():
     ap.add_argument("--fast", type=int, default=int(os.environ.get("GRT_BENCH_FAST", 3)),
                     help="3: fused form, far wings by cell moments, two passes (production); 1: the same in one pass; "
                          "2: fused form, ring kernel; 0: reference operation order")
+    ap.add_argument("--columns", type=int, default=0, help="strong scaling: a step is this fixed number of columns, sharded "
+                    "over the ranks (0: weak scaling, --cols columns per GPU per step)")
     ap.add_argument("--tile", type=int, default=0, help="exploration only: wavenumbers (cells) per workgroup of the line kernel")
     ap.add_argument("--lw-nslice", type=int, default=0, help="exploration only: line slices per tile of the longwave launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -125,25 +130,41 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     device = api.create_device(local_rank)
+    if world > 1:
+        # the line lists are drawn once (rank 0) and shared through a cache directory instead of once per rank
+        os.environ.setdefault("GRT_LINES_CACHE", os.path.join(os.environ.get("TMPDIR", "/tmp"), f"grt_lines_cache_{os.getuid()}"))
+        if rank != 0:
+            dist.barrier()
     lw_grid = (W.LW_GRID[0], W.LW_GRID[1], args.lw_dw or W.LW_GRID[2])
     sw_grid = (W.SW_GRID[0], W.SW_GRID[1], args.sw_dw or W.SW_GRID[2])
     wl = W.G1Workload(device, args.cols, lw_lines=args.lw_lines or W.LW_LINES,
                       sw_lines=args.sw_lines or W.SW_LINES, fast=args.fast, lw_grid=lw_grid, sw_grid=sw_grid, tile=args.tile, lw_nslice=args.lw_nslice)
-    first, count = multi.shard(world * args.cols, rank, world)      # weak scaling: args.cols columns per rank
-    (gcols, keep), _ = wl.columns(first, count)
-    out = torch.zeros(args.cols, api.GRT_FLUXES_PER_COLUMN, dtype=torch.float64, device="cuda")
+    if world > 1 and rank == 0:
+        dist.barrier()                                              # the lists are in the cache: the other ranks may build
+    strong = args.columns > 0
+    total_per_step = args.columns if strong else world * args.cols
+    first, count = multi.shard(total_per_step, rank, world)         # weak scaling: args.cols columns per rank
+    per = -(-total_per_step // world)
+    # this rank's block, in chunks of at most args.cols columns (one chunk in weak mode)
+    chunks = []
+    for lo in range(0, count, args.cols):
+        n = min(args.cols, count - lo)
+        (gc, keep), _ = wl.columns(first + lo, n)
+        chunks.append((lo, n, gc, keep))
+    out = torch.zeros(max(per, 1), api.GRT_FLUXES_PER_COLUMN, dtype=torch.float64, device="cuda")
     use_dist = world > 1 or force_dist
     gathered = [torch.zeros_like(out) for _ in range(world)] if (use_dist and rank == 0) else None
     stream = torch.cuda.ExternalStream(wl.pipe.stream(), device=torch.device("cuda", local_rank))
+    row_bytes = 8 * api.GRT_FLUXES_PER_COLUMN
+    result = {}
 
     def step():
-        wl.pipe.run(gcols, out.data_ptr())
+        for lo, n, gc, _ in chunks:
+            wl.pipe.run(gc, out.data_ptr() + lo * row_bytes)
         if use_dist:
             with torch.cuda.stream(stream):      # RCCL gather ordered after the kernels, no host sync
-                if world > 1:
-                    multi.gather_fluxes(out, rank, world, gathered)
-                else:
-                    dist.gather(out, gathered, dst=0)
+                result["all"] = multi.gather_fluxes(out[:count], rank, world, gathered, num_columns=total_per_step) if world > 1 \
+                    else (dist.gather(out, gathered, dst=0), gathered[0])[1]
 
     def barrier():
         wl.pipe.sync()
@@ -172,11 +193,12 @@ def main():
         # algorithmic bytes of the dominant kernel (line-by-line tau, SW-band launch), per launch:
         # SURVEY.md §8(d) terms it owns: 60 B/line once per column + per wavenumber 8*C_tab table
         # reads + 8*L tau written once (C_tab = 4 H2O + 1 O3 + 2 CFC + 3 CIA = 10 tables)
-        bytes_gas = lambda nlines, n: args.cols * (60.0 * nlines + n * (8.0 * 10 + 8.0 * L))
+        cols_launch = count / max(len(chunks), 1)          # columns per line-kernel launch on this rank (= --cols in weak mode)
+        bytes_gas = lambda nlines, n: cols_launch * (60.0 * nlines + n * (8.0 * 10 + 8.0 * L))
         dom_ms = ms[2][0] / max(ms[2][1], 1)
         achieved = bytes_gas(S["sw"], n_sw) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         fsteps = int(np.ceil(25.0 / sw_grid[2]))
-        points = lambda nlines: float(L) * nlines * (2 * fsteps + 1) * args.cols      # Voigt evaluations per launch
+        points = lambda nlines: float(L) * nlines * (2 * fsteps + 1) * cols_launch    # Voigt evaluations per launch
         valu_flop = 12.0 * points(S["sw"])                                            # ~12 flop far-wing point
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -187,16 +209,17 @@ def main():
                     traffic = tj["gas_optics_sw"]["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
-        total_cols = world * args.cols * args.steps
+        total_cols = total_per_step * args.steps
         line_kernel = "gas_optics_mp_kernel" if args.fast in (1, 3) else "gas_optics_kernel"
         line = {
             "metric": "columns/sec (60-layer, 1 cm\u207b\u00b9 LBL, LW+SW)", "value": total_cols / elapsed, "unit": "columns/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "SURVEY §8d grid G1: LW 1-3250 + SW 1-50000 cm-1 @1 cm-1, 60 layers, 7 absorbers, "
                                    f"{S['lw']} LW + {S['sw']} SW synthetic lines, H2O/O3 continua, 2 CFC, 3 CIA, clear sky, "
                                    "integrated fluxes",
-                       "columns_per_gpu_per_step": args.cols, "fast": args.fast,
+                       "columns_per_gpu_per_step": args.cols if not strong else None,
+                       "columns_per_step": total_per_step, "chunk_columns": args.cols, "fast": args.fast,
                        "arithmetic": {0: "reference operation order", 1: "fused form, far wings by cell moments",
                                       2: "fused form, every window point in the ring",
                                       3: "fused form, far wings by cell moments, two passes"}.get(args.fast, str(args.fast)),

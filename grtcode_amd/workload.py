@@ -36,8 +36,23 @@ def write_tables(root, sw):
 
 
 def band_lines(total, grid, seed, physical=False):
+    """The band's synthetic line lists.  With GRT_LINES_CACHE=<directory> in the environment they are generated once
+    and kept there as .npz (atomic write), so that the ranks of a multi-GPU run do not each draw 2.5 M lines again."""
+    cache = os.environ.get("GRT_LINES_CACHE")
+    path = None
+    if cache:
+        os.makedirs(cache, exist_ok=True)
+        path = os.path.join(cache, f"lines_{total}_{grid[0]:g}_{grid[1]:g}_{seed}_{int(physical)}.npz")
+        if os.path.exists(path):
+            with np.load(path) as z:
+                return {m: {k: z[f"{m}_{k}"] for k in ("v0", "s0", "yair", "yself", "en", "nexp", "delta", "iso")} for m in MOL_ORDER}
     lists = syn.band_line_lists(total, grid[0], grid[1], seed, physical)
-    return {m: lists[m] for m in MOL_ORDER}
+    out = {m: lists[m] for m in MOL_ORDER}
+    if path is not None:
+        tmp = f"{path}.{os.getpid()}.tmp.npz"
+        np.savez(tmp, **{f"{m}_{k}": v for m, ln in out.items() for k, v in ln.items()})
+        os.replace(tmp, path)
+    return out
 
 
 def build_band(device, grid_spec, lines, files, num_levels=NUM_LEVELS, method=api.LINE_SAMPLE):
