@@ -62,6 +62,63 @@ def cpu_baseline(lw_grid, sw_grid, lw_lines, sw_lines, thin_lw=1, thin_sw=1):
     return base, bands
 
 
+def fine_grid_column(wl, dw, reps, compare_layers=0):
+    """One longwave column (1-3250 cm-1, the bench's 1.0 M lines, 60 layers) on a fine grid through the production form
+    -- SURVEY §8(d) grids G2 (0.1 cm-1) and G3 (0.001 cm-1: BASELINE.json's "~3M-wavenumber" grid, n = 3 249 001, windows
+    of 50 001 points) -- timed with HIP events on the library stream.  compare_layers > 0: the cell hierarchy against the
+    ring kernel (every window point evaluated) on a column of that many layers."""
+    from grtcode_amd import api, synthetic as syn, workload as W
+    grid_spec = (W.LW_GRID[0], W.LW_GRID[1], dw)
+    go, grid = W.build_band(wl.device, grid_spec, wl.lw_lines, wl.lw_files, W.NUM_LEVELS)
+    col = syn.profile(0, W.NUM_LEVELS)
+
+    def set_column(g, c):
+        for m in W.MOL_ORDER:
+            g.set_molecule_ppmv(m, c["ppmv"][m])
+        g.set_cfc_ppmv(0, c["cfc_ppmv"][0])
+        g.set_cfc_ppmv(1, c["cfc_ppmv"][1])
+        g.set_cia_ppmv(0, c["ppmv"][syn.N2])
+        g.set_cia_ppmv(1, c["ppmv"][syn.O2])
+    set_column(go, col)
+    go.tune(fast=3)
+    opt = api.OpticsObject(W.NUM_LEVELS - 1, grid, wl.device)
+    go.calculate_optical_depth(col["p"], col["t"], opt)          # warm-up (allocations)
+    for t in (1, 2, 6, 7):
+        api.profile_read(t, reset=True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        go.calculate_optical_depth(col["p"], col["t"], opt)
+    wall = (time.perf_counter() - t0) / reps
+    tags = {t: api.profile_read(t, reset=True) for t in (1, 2, 6, 7)}
+    kern_ms = sum(v[0] for v in tags.values()) / reps
+    info = go.last_launch()
+    L, n = W.NUM_LEVELS - 1, int(grid.n)
+    fsteps = int(np.ceil(25.0 / dw))
+    out = {"dw": dw, "n": n, "lines": wl.total_lines["lw"], "ms_per_column": kern_ms, "columns_per_s": 1e3 / kern_ms,
+           "wall_ms_per_column": 1e3 * wall, "ran": {k: info[k] for k in ("fast", "tile", "tree_levels", "halo", "moments")},
+           "voigt_points_per_column": float(L) * wl.total_lines["lw"] * (2 * fsteps + 1),
+           # SURVEY §8(d): B_band = 60 S + n (8 C_tab + 48 L + 16 V), C_tab = 11 in the longwave
+           "hbm_algorithmic_gb_per_s": (60.0 * wl.total_lines["lw"] + n * (88.0 + 48.0 * L + 16.0 * (L + 1))) / (kern_ms * 1e-3) / 1e9}
+    opt.destroy()
+    go.destroy()
+    if compare_layers:
+        V = compare_layers + 1
+        go, grid = W.build_band(wl.device, grid_spec, wl.lw_lines, wl.lw_files, V)
+        c = syn.profile(0, V)
+        set_column(go, c)
+        opt = api.OpticsObject(V - 1, grid, wl.device)
+        taus = {}
+        for fast in (3, 2):
+            go.tune(fast=fast)
+            go.calculate_optical_depth(c["p"], c["t"], opt)
+            taus[fast] = opt.read()[0]
+        scale = np.abs(taus[2]).max(axis=1, keepdims=True)
+        out["tree_vs_ring"] = {"layers": compare_layers, "max_diff_of_layer_max": float(np.max(np.abs(taus[3] - taus[2]) / scale))}
+        opt.destroy()
+        go.destroy()
+    return out
+
+
 def parity_of_column0(wl, fluxes, bands, kind):
     """The GPU's column 0 of the last timed step against the CPU checker's column 0 (same inputs): the twelve
     integrated fluxes [W m-2] and the spectral gas optical depths of both bands."""
@@ -101,6 +158,7 @@ def main():
     ap.add_argument("--tile", type=int, default=0, help="exploration only: wavenumbers (cells) per workgroup of the line kernel")
     ap.add_argument("--lw-nslice", type=int, default=0, help="exploration only: line slices per tile of the longwave launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the reference-order and fine-grid measurements after the timed region")
     ap.add_argument("--lw-lines", type=int, default=None)
     ap.add_argument("--sw-lines", type=int, default=None)
     ap.add_argument("--lw-dw", type=float, default=None, help="exploration only: longwave grid spacing (default 1 cm-1)")
@@ -128,6 +186,7 @@ def main():
     force_dist = os.environ.get("GRT_BENCH_FORCE_DIST") == "1"
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     device = api.create_device(local_rank)
     if world > 1:
@@ -242,6 +301,38 @@ def main():
             "sample_fluxes_col0": {"rlut": fluxes[0, 0], "rlus": fluxes[0, 1], "rlds": fluxes[0, 4],
                                    "rsut": fluxes[0, 6], "rsdt": fluxes[0, 9], "rsds": fluxes[0, 10]},
         }
+        # the solvers (fused form: Rayleigh + optics combination + solver + spectral trapezoid in one kernel).  HBM view
+        # with SURVEY a19/a20's algorithmic bytes of the materialised interface (1 944 / 2 440 B per wavenumber) and with
+        # what the fused kernels must move (tau_gas once + the per-wavenumber tables); the shortwave kernel is
+        # fp64-VALU work (two delta-Eddington solutions per layer and sweep: ~27 divisions, 14 exp)
+        sol = {}
+        for name, tag, n, surv, fused_b in (("lw", 3, n_lw, 16.0 * L + 8 + 16.0 * V, 8.0 * L + 8), ("sw", 4, n_sw, 24.0 * L + 24 + 16.0 * V, 8.0 * L + 24)):
+            if ms[tag][1]:
+                t = ms[tag][0] / ms[tag][1] * 1e-3
+                sol[name] = {"avg_launch_ms": t * 1e3, "columns_per_launch": cols_launch,
+                             "algorithmic_bytes_survey": surv * n * cols_launch, "achieved_gb_per_s_survey": surv * n * cols_launch / t / 1e9,
+                             "frac_hbm_survey": surv * n * cols_launch / t / 1e9 / HBM_PEAK_GBS,
+                             "compulsory_bytes_fused": fused_b * n * cols_launch, "achieved_gb_per_s_fused": fused_b * n * cols_launch / t / 1e9}
+        line["roofline_solvers"] = dict(sol, bound="valu_fp64 (shortwave), latency (longwave: 26 000 threads)", peak=HBM_PEAK_GBS, unit="GB/s")
+        if world == 1 and not args.no_extras:
+            # what an unchanged caller of calculate_optical_depth gets: the reference-order form (fast = 0)
+            wl.go_lw.tune(fast=0, tile=args.tile, nslice=args.lw_nslice)
+            wl.go_sw.tune(fast=0, tile=args.tile)
+            step()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                step()
+            barrier()
+            line["reference_order_columns_per_s"] = 2 * total_per_step / (time.perf_counter() - t0)
+            wl.go_lw.tune(fast=args.fast, tile=args.tile, nslice=args.lw_nslice)
+            wl.go_sw.tune(fast=args.fast, tile=args.tile)
+            step()                              # column 0 of the production form back in the buffers (parity below)
+            barrier()
+            fluxes = out.cpu().numpy()
+            if args.lw_dw is None and args.lw_lines is None:
+                line["fine_grid"] = {"G2_lw_0.1cm-1": fine_grid_column(wl, 0.1, 4),
+                                     "G3_lw_0.001cm-1": fine_grid_column(wl, 0.001, 2, compare_layers=12)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"], ref_bands = cpu_baseline(lw_grid, sw_grid, args.lw_lines or W.LW_LINES,
                                                            args.sw_lines or W.SW_LINES)

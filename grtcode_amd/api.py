@@ -136,7 +136,7 @@ create_longwave destroy_longwave calculate_lw_fluxes
 create_shortwave destroy_shortwave calculate_sw_fluxes rayleigh_scattering
 create_solar_flux destroy_solar_flux disort_shortwave
 grt_tips_load grt_tips_reset grt_tips_is_table grt_tips_source grt_sizeof grt_add_molecule_lines grt_gas_optics_tune grt_gas_optics_last_launch grt_hitran_index_stats
-grt_optical_depth_batch grt_pipeline_create grt_pipeline_destroy grt_pipeline_run grt_pipeline_sync
+grt_optical_depth_batch grt_pipeline_create grt_pipeline_create_ex grt_pipeline_destroy grt_pipeline_run grt_pipeline_sync
 grt_pipeline_stream grt_pipeline_views grt_device_malloc grt_device_free grt_device_to_host
 grt_host_to_device grt_debug_line_prep grt_debug_partition_functions grt_profile_enable grt_profile_read
 grt_multi_shard grt_multi_create grt_multi_destroy grt_multi_gather_fluxes grt_multi_broadcast grt_multi_max
@@ -414,17 +414,20 @@ def make_columns(cols, mol_order, cfc_order=(), num_levels=None):
 
 
 class Pipeline:
-    def __init__(self, lw_gas, sw_gas, max_columns, user_level, emissivity, albedo, solar):
+    def __init__(self, lw_gas, sw_gas, max_columns, user_level, emissivity, albedo, solar, spectral=True):
+        """spectral=True keeps tau/omega/g and the spectral fluxes (views(): what parity tests read);
+        spectral=False is the production form of grt_pipeline_create: fused solvers, integrated fluxes only."""
         self.lib = load_library()
+        self.spectral = spectral
         self.p = C.c_void_p()
         self.device = (lw_gas or sw_gas).device
         e = _f64(emissivity) if emissivity is not None else None
         a = _f64(albedo) if albedo is not None else None
         s = _f64(solar) if solar is not None else None
-        check(self.lib.grt_pipeline_create(C.byref(self.p), C.byref(lw_gas.c) if lw_gas else None,
-                                           C.byref(sw_gas.c) if sw_gas else None, max_columns, user_level,
-                                           _dp(e) if e is not None else None, _dp(a) if a is not None else None,
-                                           _dp(s) if s is not None else None))
+        check(self.lib.grt_pipeline_create_ex(C.byref(self.p), C.byref(lw_gas.c) if lw_gas else None,
+                                              C.byref(sw_gas.c) if sw_gas else None, max_columns, user_level,
+                                              _dp(e) if e is not None else None, _dp(a) if a is not None else None,
+                                              _dp(s) if s is not None else None, int(spectral)))
         self.out = DeviceBuffer(self.device, 8 * GRT_FLUXES_PER_COLUMN * max_columns)
         self.max_columns = max_columns
 
@@ -443,6 +446,9 @@ class Pipeline:
 
     def views(self, band):
         ptrs = [C.c_void_p() for _ in range(6)]
+        if not self.spectral:
+            check(self.lib.grt_pipeline_views(self.p, band, C.byref(ptrs[0]), *([None] * 5)))
+            return {"tau_gas": ptrs[0].value}
         check(self.lib.grt_pipeline_views(self.p, band, *[C.byref(p) for p in ptrs]))
         return dict(zip(("tau_gas", "tau", "omega", "g", "flux_up", "flux_down"), [p.value for p in ptrs]))
 

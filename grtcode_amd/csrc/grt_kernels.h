@@ -147,12 +147,21 @@ typedef struct GrtLwArgs
     uint64_t optics_stride;
     double const *t_layers, *t_levels, *t_surf;
     double const *emis; uint64_t emis_stride;
-    double *flux_up, *flux_down;    /* [ncol][V][nw] or NULL when only integrating */
+    double *flux_up, *flux_down;    /* [ncol][V][nw]; NULL in the fused form: nothing spectral is stored */
     uint64_t flux_stride;
-    double *integrated;             /* optional [ncol][6]: up TOA, up SFC, up USER, dn TOA, dn SFC, dn USER */
     int user_level;                 /* -1: none */
+    /* Fused clear-sky form (driver.c:360-424 + 285-356 with -integrated in one kernel): tau_gas != NULL makes the
+       kernel form Rayleigh (rayleigh.c:38-39) and the two-object combination (optics.c:138-145) per layer in
+       registers from tau_gas [ncol][L][nw] (column stride optics_stride) and the air columns n_layer [ncol][L],
+       and leave only the trapezoid partial sums of the six output rows (up TOA, up surface, up user, down TOA,
+       down surface, down user) at partials[(c*6 + k)*nblocks + block]; grt_launch_reduce_partials finishes. */
+    double const *tau_gas, *n_layer;
+    double *partials;
 } GrtLwArgs;
 int grt_launch_lw(void *stream, GrtLwArgs const *a);
+unsigned grt_solver_blocks(uint64_t nw);     /* workgroups along the spectrum of one solver launch (size of `partials`) */
+int grt_launch_reduce_partials(void *stream, double const *partials, int nrows, unsigned nblocks,
+                               double *out, int group, int out_stride, int out_offset);
 
 /* shortwave.c:410-453 */
 typedef struct GrtSwArgs
@@ -167,8 +176,13 @@ typedef struct GrtSwArgs
     double const *alb_dir, *alb_dif; uint64_t alb_stride;
     double const *tsi;              /* [ncol] */
     double const *solar;            /* [nw] */
-    double *flux_up, *flux_down; uint64_t flux_stride;
-    double *integrated; int user_level;
+    double *flux_up, *flux_down; uint64_t flux_stride;   /* NULL in the fused form */
+    int user_level;
+    /* fused clear-sky form, as in GrtLwArgs; the downward-beam reflectances of the first sweep are parked in
+       park [ncol][2][V][nw] instead of the output rows */
+    double const *tau_gas, *n_layer;
+    double w0;
+    double *partials, *park;
 } GrtSwArgs;
 int grt_launch_sw(void *stream, GrtSwArgs const *a);
 

@@ -17,6 +17,7 @@
 #include <math.h>
 #include <stdint.h>
 #include "../grt_kernels.h"
+#include "optics_dev.h"
 
 #pragma clang fp contract(off)
 
@@ -57,6 +58,10 @@ __device__ __forceinline__ double extinction(double c1, double tau)
     return exp(e);
 }
 
+// FUSED: the clear-sky tail of the pipeline in one kernel -- Rayleigh and the two-object optics combination are formed
+// per layer in registers from tau_gas (same expressions, same order as clear_sky_kernel: identical values), nothing
+// spectral is written, and the six integrated output rows leave as per-block trapezoid partial sums.
+template <bool FUSED>
 __global__ __launch_bounds__(kBlock) void lw_kernel(GrtLwArgs a)
 {
     double const c1[4] = {-14.402613260847248, -3.0302159969901132,
@@ -65,27 +70,51 @@ __global__ __launch_bounds__(kBlock) void lw_kernel(GrtLwArgs a)
                           1.3726594476601073, 1.0169418413757783};     // longwave.c:165-168
     uint64_t const i = (uint64_t)blockIdx.x*kBlock + threadIdx.x;
     int const col = blockIdx.y;
-    if (i >= a.nw)
+    bool const live = i < a.nw;
+    if (!FUSED && !live)
     {
         return;
     }
+    uint64_t const ii = live ? i : a.nw - 1;      // (fused form: idle lanes of the last block follow along, weight 0)
     int const V = a.num_levels;
     int const L = V - 1;
-    double const w = a.w0 + i*a.dw;                                      // longwave.c:246
-    double const *tau = a.tau + (uint64_t)col*a.optics_stride + i;
-    double const *omega = a.omega ? a.omega + (uint64_t)col*a.optics_stride + i : nullptr;
+    double const w = a.w0 + ii*a.dw;                                     // longwave.c:246
+    double const *tau = (FUSED ? a.tau_gas : a.tau) + (uint64_t)col*a.optics_stride + ii;
+    double const *omega = (!FUSED && a.omega) ? a.omega + (uint64_t)col*a.optics_stride + ii : nullptr;
+    double const *nl = FUSED ? a.n_layer + (uint64_t)col*L : nullptr;
     double const *tl = a.t_layers + (uint64_t)col*L;
     double const *tv = a.t_levels + (uint64_t)col*V;
-    double const emis = a.emis[(uint64_t)col*a.emis_stride + i];
-    double *fu = a.flux_up + (uint64_t)col*a.flux_stride + i;
-    double *fd = a.flux_down + (uint64_t)col*a.flux_stride + i;
+    double const emis = a.emis[(uint64_t)col*a.emis_stride + ii];
+    double *fu = FUSED ? nullptr : a.flux_up + (uint64_t)col*a.flux_stride + ii;
+    double *fd = FUSED ? nullptr : a.flux_down + (uint64_t)col*a.flux_stride + ii;
+    int const user = a.user_level;
+    double out[6] = {0., 0., 0., 0., 0., 0.};     // up TOA, up surface, up user, down TOA, down surface, down user
 
-    double I[4] = {0., 0., 0., 0.};
-    fd[0] = 0.;                                                          // longwave.c:171
-    for (int j = 0; j < L; ++j)
+    // absorption optical depth of layer j: tau (1 - omega)  (longwave.c:252)
+    auto layer_tau = [&](int j) -> double
     {
         uint64_t const o = (uint64_t)j*a.nw;
-        double const t = omega ? tau[o]*(1. - omega[o]) : tau[o]*(1. - 0.);   // longwave.c:252
+        if (FUSED)
+        {
+            double t, om, gg;
+            clear_sky_combine(tau[o], rayleigh_tau(w, nl[j]), t, om, gg);
+            return t*(1. - om);
+        }
+        return omega ? tau[o]*(1. - omega[o]) : tau[o]*(1. - 0.);
+    };
+
+    double I[4] = {0., 0., 0., 0.};
+    if (!FUSED)
+    {
+        fd[0] = 0.;                                                      // longwave.c:171
+    }
+    if (FUSED && user == 0)
+    {
+        out[5] = 0.;
+    }
+    for (int j = 0; j < L; ++j)
+    {
+        double const t = layer_tau(j);
         double const val = effective_planck(planck(tl[j], w), planck(tv[j + 1], w), t);
         double f = 0.;
 #pragma unroll
@@ -96,7 +125,15 @@ __global__ __launch_bounds__(kBlock) void lw_kernel(GrtLwArgs a)
             I[s] = p + I[s]*ext;
             f += c2[s]*I[s];                                             // longwave.c:195
         }
-        fd[(uint64_t)(j + 1)*a.nw] = f;
+        if (FUSED)
+        {
+            out[4] = j + 1 == L ? f : out[4];
+            out[5] = j + 1 == user ? f : out[5];
+        }
+        else
+        {
+            fd[(uint64_t)(j + 1)*a.nw] = f;
+        }
     }
     double const bs = planck(a.t_surf[col], w);
     double f = 0.;
@@ -106,11 +143,18 @@ __global__ __launch_bounds__(kBlock) void lw_kernel(GrtLwArgs a)
         I[s] = emis*bs + (1 - emis)*I[s];                                // longwave.c:202
         f += c2[s]*I[s];
     }
-    fu[(uint64_t)L*a.nw] = f;
+    if (FUSED)
+    {
+        out[1] = f;
+        out[2] = user == L ? f : out[2];
+    }
+    else
+    {
+        fu[(uint64_t)L*a.nw] = f;
+    }
     for (int j = L - 1; j >= 0; --j)
     {
-        uint64_t const o = (uint64_t)j*a.nw;
-        double const t = omega ? tau[o]*(1. - omega[o]) : tau[o]*(1. - 0.);
+        double const t = layer_tau(j);
         double const val = effective_planck(planck(tl[j], w), planck(tv[j], w), t);
         double g = 0.;
 #pragma unroll
@@ -121,19 +165,52 @@ __global__ __launch_bounds__(kBlock) void lw_kernel(GrtLwArgs a)
             I[s] = p + I[s]*ext;
             g += c2[s]*I[s];
         }
-        fu[o] = g;
+        if (FUSED)
+        {
+            out[0] = j == 0 ? g : out[0];
+            out[2] = j == user ? g : out[2];
+        }
+        else
+        {
+            fu[(uint64_t)j*a.nw] = g;
+        }
+    }
+    if (FUSED)
+    {
+        // driver.c:302-326: sum 0.5 (f_i + f_{i+1}) dw over the grid = sum weight_i f_i
+        double const wt = !live ? 0. : ((i == 0 || i + 1 == a.nw) ? 0.5*a.dw : a.dw);
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+        {
+            out[k] *= wt;
+        }
+        block_partials<6, kBlock>(out, a.partials, (uint64_t)col*6, gridDim.x, blockIdx.x);
     }
 }
 
 } // namespace
 
+extern "C" unsigned grt_solver_blocks(uint64_t nw)
+{
+    return (unsigned)((nw + kBlock - 1)/kBlock);
+}
+
 extern "C" int grt_launch_lw(void *stream, GrtLwArgs const *a)
 {
-    if (a->flux_up == nullptr || a->flux_down == nullptr || a->ncol < 1)
+    bool const fused = a->tau_gas != nullptr;
+    if (a->ncol < 1 || a->nw < 2 || (fused ? (a->partials == nullptr || a->n_layer == nullptr)
+                                           : (a->flux_up == nullptr || a->flux_down == nullptr)))
     {
         return (int)hipErrorInvalidValue;
     }
-    dim3 const grid((unsigned)((a->nw + kBlock - 1)/kBlock), a->ncol, 1);
-    hipLaunchKernelGGL(lw_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, *a);
+    dim3 const grid(grt_solver_blocks(a->nw), a->ncol, 1);
+    if (fused)
+    {
+        hipLaunchKernelGGL(lw_kernel<true>, grid, dim3(kBlock), 0, (hipStream_t)stream, *a);
+    }
+    else
+    {
+        hipLaunchKernelGGL(lw_kernel<false>, grid, dim3(kBlock), 0, (hipStream_t)stream, *a);
+    }
     return (int)hipGetLastError();
 }

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../grt_kernels.h"
+#include "optics_dev.h"
 
 #pragma clang fp contract(off)
 
@@ -16,13 +17,6 @@ inline unsigned grid_for(uint64_t n)
 {
     uint64_t const b = (n + kBlock - 1)/kBlock;
     return (unsigned)(b < 2048 ? (b ? b : 1) : 2048);
-}
-
-// shortwave/src/rayleigh.c:38-39
-__device__ __forceinline__ double rayleigh_tau(double w, double n)
-{
-    double const W = w*1.e-4;
-    return (n*1.e-20*W*W*W*W)/(0.268675*1.e5*(9.38076E2 - 10.8426*W*W));
 }
 
 __global__ __launch_bounds__(kBlock) void rayleigh_kernel(int L, double w0, double dw, uint64_t nw,
@@ -96,15 +90,11 @@ __global__ __launch_bounds__(kBlock) void clear_sky_kernel(int L, int ncol, doub
         uint64_t const i = r/nw;
         uint64_t const j = r - i*nw;
         double const tr = rayleigh_tau(w0 + j*dw, n_layer[c*L + i]);
-        double const tg = tau_gas[o];
-        double gs = 0., os = 0., ts = 0.;
-        gs += 0.*0.*tg;  os += 0.*tg;  ts += tg;
-        gs += 0.*1.*tr;  os += 1.*tr;  ts += tr;
-        gs /= os;
-        os /= ts;
-        g[o] = gs;
-        omega[o] = os;
-        tau[o] = ts;
+        double t, om, gg;
+        clear_sky_combine(tau_gas[o], tr, t, om, gg);
+        g[o] = gg;
+        omega[o] = om;
+        tau[o] = t;
     }
 }
 
@@ -137,7 +127,41 @@ __global__ __launch_bounds__(kBlock) void integrate_rows_kernel(double const *co
     }
 }
 
+// Second stage of the fused solvers' trapezoid: one wavefront per output row adds the blocks' partial sums in a
+// fixed order (lane-strided, then a shuffle tree): same bits every run.
+__global__ __launch_bounds__(64) void reduce_partials_kernel(double const *partials, unsigned nblocks, double *out,
+                                                             int group, int out_stride, int out_offset)
+{
+    int const r = blockIdx.x;
+    double const *p = partials + (uint64_t)r*nblocks;
+    double s = 0.;
+    for (unsigned b = threadIdx.x; b < nblocks; b += 64)
+    {
+        s += p[b];
+    }
+    for (int off = 32; off > 0; off >>= 1)
+    {
+        s += __shfl_down(s, off, 64);
+    }
+    if (threadIdx.x == 0)
+    {
+        out[(r/group)*out_stride + out_offset + (r % group)] = s;
+    }
+}
+
 } // namespace
+
+extern "C" int grt_launch_reduce_partials(void *stream, double const *partials, int nrows, unsigned nblocks,
+                                          double *out, int group, int out_stride, int out_offset)
+{
+    if (nrows < 1)
+    {
+        return 0;
+    }
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(nrows), dim3(64), 0, (hipStream_t)stream, partials, nblocks, out,
+                       group, out_stride, out_offset);
+    return (int)hipGetLastError();
+}
 
 extern "C" int grt_launch_rayleigh(void *stream, int num_layers, double w0, double dw, uint64_t nw,
                                    double const *n_layer, double *tau, double *omega, double *g)

@@ -19,6 +19,7 @@
 #include <math.h>
 #include <stdint.h>
 #include "../grt_kernels.h"
+#include "optics_dev.h"
 
 #pragma clang fp contract(off)
 
@@ -115,34 +116,58 @@ __device__ __forceinline__ LayerProps layer_props(double omega, double g, double
     return p;
 }
 
+// FUSED: the clear-sky tail in one kernel -- tau, omega, g of a layer are formed in registers from tau_gas and the
+// Rayleigh optical depth (clear_sky_combine: the expressions and order of clear_sky_kernel, identical values), the
+// first sweep's reflectances are parked in a scratch block instead of the output rows, nothing spectral is written and
+// the six integrated output rows leave as per-block trapezoid partial sums.
+template <bool FUSED>
 __global__ __launch_bounds__(kBlock) void sw_kernel(GrtSwArgs a)
 {
     uint64_t const i = (uint64_t)blockIdx.x*kBlock + threadIdx.x;
     int const col = blockIdx.y;
-    if (i >= a.nw)
+    bool const live = i < a.nw;
+    if (!FUSED && !live)
     {
         return;
     }
+    uint64_t const ii = live ? i : a.nw - 1;      // (fused form: idle lanes of the last block follow along, weight 0)
     int const V = a.num_levels;
     int const L = V - 1;
     uint64_t const nw = a.nw;
-    double const *tau = a.tau + (uint64_t)col*a.optics_stride + i;
-    double const *omega = a.omega + (uint64_t)col*a.optics_stride + i;
-    double const *g = a.g + (uint64_t)col*a.optics_stride + i;
+    double const *tau = (FUSED ? a.tau_gas : a.tau) + (uint64_t)col*a.optics_stride + ii;
+    double const *omega = FUSED ? nullptr : a.omega + (uint64_t)col*a.optics_stride + ii;
+    double const *g = FUSED ? nullptr : a.g + (uint64_t)col*a.optics_stride + ii;
+    double const *nl = FUSED ? a.n_layer + (uint64_t)col*L : nullptr;
+    double const w = FUSED ? a.w0 + ii*a.dw : 0.;
     double const mu_dir = a.mu_dir[col];
     double const mu_dif = a.mu_dif;
-    double *fu = a.flux_up + (uint64_t)col*a.flux_stride + i;
-    double *fd = a.flux_down + (uint64_t)col*a.flux_stride + i;
+    // where the first sweep parks R_dir_downward / R_dif_downward of every level
+    double *fu = FUSED ? a.park + ((uint64_t)col*2 + 0)*(uint64_t)V*nw + ii : a.flux_up + (uint64_t)col*a.flux_stride + ii;
+    double *fd = FUSED ? a.park + ((uint64_t)col*2 + 1)*(uint64_t)V*nw + ii : a.flux_down + (uint64_t)col*a.flux_stride + ii;
+    int const user = a.user_level;
+    double out[6] = {0., 0., 0., 0., 0., 0.};     // up TOA, up surface, up user, down TOA, down surface, down user
+
+    auto props_of = [&](int j) -> LayerProps
+    {
+        uint64_t const o = (uint64_t)j*nw;
+        if (FUSED)
+        {
+            double t, om, gg;
+            clear_sky_combine(tau[o], rayleigh_tau(w, nl[j]), t, om, gg);
+            return layer_props(om, gg, t, mu_dir, mu_dif);
+        }
+        return layer_props(omega[o], g[o], tau[o], mu_dir, mu_dif);
+    };
 
     // sweep 1: shortwave.c:280-294
-    double Rdir_dn = a.alb_dir[(uint64_t)col*a.alb_stride + i];
-    double Rdif_dn = a.alb_dif[(uint64_t)col*a.alb_stride + i];
+    double Rdir_dn = a.alb_dir[(uint64_t)col*a.alb_stride + ii];
+    double Rdif_dn = a.alb_dif[(uint64_t)col*a.alb_stride + ii];
     fu[(uint64_t)L*nw] = Rdir_dn;
     fd[(uint64_t)L*nw] = Rdif_dn;
     for (int j = L - 1; j >= 0; --j)
     {
         uint64_t const o = (uint64_t)j*nw;
-        LayerProps const p = layer_props(omega[o], g[o], tau[o], mu_dir, mu_dif);
+        LayerProps const p = props_of(j);
         double const A = p.Tpure;
         double const B = 1./(1. - p.Rdif*Rdif_dn);
         double const ndir = p.Rdir + (A*Rdir_dn + (p.Tdir - A)*Rdif_dn)*p.Tdif*B;
@@ -154,7 +179,7 @@ __global__ __launch_bounds__(kBlock) void sw_kernel(GrtSwArgs a)
     }
 
     // sweep 2: shortwave.c:299-329 fused, then the scalings of :401-405 and :447-451
-    double const scale = a.solar[i]*mu_dir;
+    double const scale = a.solar[ii]*mu_dir;
     double const tsi = a.tsi[col];
     double dir_beam = 1.;
     double dif_beam = 0.;
@@ -163,15 +188,24 @@ __global__ __launch_bounds__(kBlock) void sw_kernel(GrtSwArgs a)
         double dn = dir_beam;             // T[0]
         up *= scale;
         dn *= scale;
-        fu[0] = tsi*up;
-        fd[0] = tsi*dn;
+        if (FUSED)
+        {
+            out[0] = tsi*up;
+            out[3] = tsi*dn;
+            out[2] = user == 0 ? tsi*up : out[2];
+            out[5] = user == 0 ? tsi*dn : out[5];
+        }
+        else
+        {
+            fu[0] = tsi*up;
+            fd[0] = tsi*dn;
+        }
     }
     double Rup_prev2 = 0.;    // R_dif_upward[lev-2]
     double Rup_prev = 0.;     // R_dif_upward[lev-1]
     for (int lev = 1; lev < V; ++lev)
     {
-        uint64_t const o = (uint64_t)(lev - 1)*nw;
-        LayerProps const p = layer_props(omega[o], g[o], tau[o], mu_dir, mu_dif);   // layer lev-1
+        LayerProps const p = props_of(lev - 1);   // layer lev-1
         // R_dif_upward[lev-1]  (:299-306)
         Rup_prev2 = Rup_prev;
         if (lev == 1)
@@ -201,8 +235,29 @@ __global__ __launch_bounds__(kBlock) void sw_kernel(GrtSwArgs a)
         double dn = dir_beam*(1. + rdir*Rup_prev*B) + dif_beam*B;
         up *= scale;
         dn *= scale;
-        fu[ol] = tsi*up;
-        fd[ol] = tsi*dn;
+        if (FUSED)
+        {
+            out[1] = lev == L ? tsi*up : out[1];
+            out[4] = lev == L ? tsi*dn : out[4];
+            out[2] = lev == user ? tsi*up : out[2];
+            out[5] = lev == user ? tsi*dn : out[5];
+        }
+        else
+        {
+            fu[ol] = tsi*up;
+            fd[ol] = tsi*dn;
+        }
+    }
+    if (FUSED)
+    {
+        // driver.c:302-326: sum 0.5 (f_i + f_{i+1}) dw over the grid = sum weight_i f_i
+        double const wt = !live ? 0. : ((i == 0 || i + 1 == nw) ? 0.5*a.dw : a.dw);
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+        {
+            out[k] *= wt;
+        }
+        block_partials<6, kBlock>(out, a.partials, (uint64_t)col*6, gridDim.x, blockIdx.x);
     }
 }
 
@@ -210,11 +265,20 @@ __global__ __launch_bounds__(kBlock) void sw_kernel(GrtSwArgs a)
 
 extern "C" int grt_launch_sw(void *stream, GrtSwArgs const *a)
 {
-    if (a->flux_up == nullptr || a->flux_down == nullptr || a->ncol < 1)
+    bool const fused = a->tau_gas != nullptr;
+    if (a->ncol < 1 || a->nw < 2 || (fused ? (a->partials == nullptr || a->park == nullptr || a->n_layer == nullptr)
+                                           : (a->flux_up == nullptr || a->flux_down == nullptr)))
     {
         return (int)hipErrorInvalidValue;
     }
-    dim3 const grid((unsigned)((a->nw + kBlock - 1)/kBlock), a->ncol, 1);
-    hipLaunchKernelGGL(sw_kernel, grid, dim3(kBlock), 0, (hipStream_t)stream, *a);
+    dim3 const grid((unsigned)((a->nw + kBlock - 1)/kBlock), a->ncol, 1);   // == grt_solver_blocks(nw): same kBlock
+    if (fused)
+    {
+        hipLaunchKernelGGL(sw_kernel<true>, grid, dim3(kBlock), 0, (hipStream_t)stream, *a);
+    }
+    else
+    {
+        hipLaunchKernelGGL(sw_kernel<false>, grid, dim3(kBlock), 0, (hipStream_t)stream, *a);
+    }
     return (int)hipGetLastError();
 }

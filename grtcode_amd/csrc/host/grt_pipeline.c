@@ -6,11 +6,14 @@
  * -integrated, driver.c:285-356), done for a whole batch of columns with
  *   - one host prologue + one small upload per column (layer state, a few kB),
  *   - one line-by-line launch per band for the batch,
- *   - Rayleigh and the two-object optics combination fused into one streaming pass
- *     (no temporaries, no per-column allocation as in optics.c:84-124),
- *   - one solver launch per band, fluxes kept in HBM,
- *   - one wavefront-shuffle trapezoid launch per band that leaves 6 numbers per band
- *     and column on the device (ready for an RCCL gather; nothing crosses PCIe).
+ *   - one solver launch per band that forms Rayleigh and the two-object optics combination per layer
+ *     in registers from tau_gas (no tau/omega/g arrays, no per-column allocation as in optics.c:84-124),
+ *     keeps no spectral flux and leaves the trapezoid of the six output rows as per-block partial sums
+ *     (wavefront shuffles + LDS), and one tiny launch that adds the blocks in a fixed order: 6 numbers
+ *     per band and column on the device (ready for an RCCL gather; nothing crosses PCIe),
+ *   - or, for callers that want spectra (grt_pipeline_create_ex(..., keep_spectra = 1): parity tests, a
+ *     driver without -integrated), the materialised form: one streaming Rayleigh + combine pass,
+ *     solvers writing [level][wavenumber] fluxes, a row-wise trapezoid launch.
  * All work is enqueued on the device's library stream; nothing synchronises.
  */
 #include <stdlib.h>
@@ -26,12 +29,17 @@ typedef struct GrtBand
     double *flux_up, *flux_down;   /* [cols][V][n] */
     double **rows_d;       /* [cols][6] device row pointers for the trapezoid */
     double *zero_row;      /* [n] zeros: stands in for the user level when there is none */
+    /* fused form (no spectra kept): */
+    double *park;          /* shortwave: [cols][2][V][n] first-sweep reflectances */
+    double *partials;      /* [cols][6][nblocks] trapezoid partial sums */
+    unsigned nblocks;
 } GrtBand;
 
 struct GrtPipeline
 {
     Device_t device;
     int max_cols, num_levels, user_level;
+    int keep_spectra;      /* 0: fused solvers, integrated fluxes only (production); 1: tau/omega/g and fluxes materialised */
     GrtBand band[2];       /* 0: longwave, 1: shortwave */
     /* per-batch small inputs: pinned host staging + device copies */
     double *small_h, *small_d;
@@ -55,6 +63,18 @@ static int band_alloc(GrtPipeline_t *p, GrtBand *b, GasOptics_t *gas)
     size_t const L = (size_t)p->num_levels - 1, V = (size_t)p->num_levels, C = (size_t)p->max_cols;
     size_t const opt = sizeof(double)*C*L*b->n, flx = sizeof(double)*C*V*b->n;
     void *blk = NULL;
+    if (!p->keep_spectra)
+    {
+        /* fused form: tau_gas, (shortwave) the parked reflectances, the partial sums */
+        b->nblocks = grt_solver_blocks(b->n);
+        int const sw = b == &p->band[1];
+        size_t const park = sw ? 2*flx : 0, part = sizeof(double)*C*6*b->nblocks;
+        GRT_TRY(grt_dev_alloc(p->device, &blk, opt + park + part));
+        b->tau_gas = blk;
+        b->park = sw ? b->tau_gas + C*L*b->n : NULL;
+        b->partials = b->tau_gas + C*L*b->n + (sw ? 2*C*V*b->n : 0);
+        return GRTCODE_SUCCESS;
+    }
     GRT_TRY(grt_dev_alloc(p->device, &blk, 4*opt + 2*flx + sizeof(double)*b->n));
     b->tau_gas = blk;
     b->tau = b->tau_gas + C*L*b->n;
@@ -137,6 +157,14 @@ EXTERN int grt_pipeline_create(GrtPipeline_t **pipeline, GasOptics_t *lw_gas, Ga
                                int max_columns, int user_level, fp_t const *emissivity,
                                fp_t const *albedo, fp_t const *solar_flux)
 {
+    GRT_TRY(grt_pipeline_create_ex(pipeline, lw_gas, sw_gas, max_columns, user_level, emissivity, albedo, solar_flux, 0));
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN int grt_pipeline_create_ex(GrtPipeline_t **pipeline, GasOptics_t *lw_gas, GasOptics_t *sw_gas,
+                                  int max_columns, int user_level, fp_t const *emissivity,
+                                  fp_t const *albedo, fp_t const *solar_flux, int keep_spectra)
+{
     GRT_REQUIRE_PTR(pipeline);
     GRT_REQUIRE_RANGE(max_columns, 1, 65535);
     GasOptics_t *any = lw_gas ? lw_gas : sw_gas;
@@ -156,6 +184,7 @@ EXTERN int grt_pipeline_create(GrtPipeline_t **pipeline, GasOptics_t *lw_gas, Ga
     p->max_cols = max_columns;
     p->num_levels = any->num_levels;
     p->user_level = user_level;
+    p->keep_spectra = keep_spectra != 0;
     /* one way out: whatever a failing step leaves allocated (GBs of HBM per band) goes back through destroy */
     int const rc = pipeline_build(p, lw_gas, sw_gas, max_columns, emissivity, albedo, solar_flux);
     if (rc != GRTCODE_SUCCESS)
@@ -218,6 +247,11 @@ EXTERN int grt_pipeline_views(GrtPipeline_t *pipeline, int band, fp_t **tau_gas,
     GRT_REQUIRE_PTR(pipeline);
     GRT_REQUIRE_RANGE(band, 0, 1);
     GrtBand *b = &pipeline->band[band];
+    if (!pipeline->keep_spectra && (tau || omega || g || flux_up || flux_down))
+    {
+        GRT_FAIL(GRTCODE_VALUE_ERR, "this pipeline keeps no spectra (only tau_gas): create it with "
+                 "grt_pipeline_create_ex(..., keep_spectra = 1).%s", "");
+    }
     if (tau_gas) *tau_gas = b->tau_gas;
     if (tau) *tau = b->tau;
     if (omega) *omega = b->omega;
@@ -301,6 +335,48 @@ EXTERN int grt_pipeline_run(GrtPipeline_t *p, GrtColumns_t const *cols, fp_t *fl
         uint64_t const per_opt = (uint64_t)L*b->n, per_flux = (uint64_t)V*b->n;
         /* gas optics (launch.c:40-226) */
         GRT_TRY(grt_optical_depth_batch(b->gas, cols, b->tau_gas));
+        if (!p->keep_spectra)
+        {
+            /* Rayleigh, add_optics({gas, rayleigh}), solver and -integrated output (driver.c:268, 382-424, 302-326)
+               in one launch, then the fixed-order sum of its per-block partial sums */
+            int slot, krc;
+            if (bi == 0)
+            {
+                GrtLwArgs a;
+                memset(&a, 0, sizeof(a));
+                a.num_levels = V; a.ncol = C; a.w0 = grid->w0; a.dw = grid->dw; a.nw = b->n;
+                a.tau_gas = b->tau_gas; a.n_layer = p->small_d + p->off_n; a.optics_stride = per_opt;
+                a.t_layers = p->small_d + p->off_tl; a.t_levels = p->small_d + p->off_tv;
+                a.t_surf = p->small_d + p->off_ts;
+                a.emis = p->emis_d; a.emis_stride = 0;
+                a.user_level = p->user_level;
+                a.partials = b->partials;
+                slot = grt_profile_begin(s, 3);
+                krc = grt_launch_lw(s, &a);
+                grt_profile_end(s, slot);
+                GRT_TRY(grt_dev_check(krc, "longwave kernel (fused)"));
+            }
+            else
+            {
+                GrtSwArgs a;
+                memset(&a, 0, sizeof(a));
+                a.num_levels = V; a.ncol = C; a.nw = b->n; a.dw = grid->dw; a.w0 = grid->w0;
+                a.tau_gas = b->tau_gas; a.n_layer = p->small_d + p->off_n; a.optics_stride = per_opt;
+                a.mu_dir = p->small_d + p->off_mu; a.mu_dif = 0.5;        /* driver.c:110 */
+                a.alb_dir = p->albedo_d; a.alb_dif = p->albedo_d; a.alb_stride = 0;   /* driver.c:118-119 */
+                a.tsi = p->small_d + p->off_tsi; a.solar = p->solar_d;
+                a.user_level = p->user_level;
+                a.partials = b->partials; a.park = b->park;
+                slot = grt_profile_begin(s, 4);
+                krc = grt_launch_sw(s, &a);
+                grt_profile_end(s, slot);
+                GRT_TRY(grt_dev_check(krc, "shortwave kernel (fused)"));
+            }
+            GRT_TRY(grt_dev_check(grt_launch_reduce_partials(s, b->partials, C*6, b->nblocks, fluxes_dev,
+                                                             GRT_FLUXES_PER_BAND, GRT_FLUXES_PER_COLUMN,
+                                                             bi*GRT_FLUXES_PER_BAND), "flux reduction kernel"));
+            continue;
+        }
         /* Rayleigh + add_optics({gas, rayleigh}) (driver.c:268, 382-383) */
         int slot = grt_profile_begin(s, 5);
         int krc = grt_launch_clear_sky_optics(s, L, C, grid->w0, grid->dw, b->n, p->small_d + p->off_n,

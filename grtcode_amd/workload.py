@@ -71,7 +71,7 @@ class G1Workload:
     """Both bands of the headline configuration, resident on one device."""
 
     def __init__(self, device, max_columns, lw_lines=LW_LINES, sw_lines=SW_LINES, num_levels=NUM_LEVELS,
-                 lw_grid=LW_GRID, sw_grid=SW_GRID, root=None, fast=0, tile=0, lw_nslice=0, physical=False):
+                 lw_grid=LW_GRID, sw_grid=SW_GRID, root=None, fast=0, tile=0, lw_nslice=0, physical=False, spectral=False):
         self.root = root or tempfile.mkdtemp(prefix="grt_g1_")
         self.device, self.num_levels = device, num_levels
         self.lw_files, _ = write_tables(self.root, sw=False)
@@ -87,7 +87,7 @@ class G1Workload:
         self.emis = np.full(self.grid_lw.n, 0.98)
         self.albedo = np.full(self.grid_sw.n, 0.2)
         self.solar = api.create_solar_flux(self.grid_sw, self.sw_files["solar"])
-        self.pipe = api.Pipeline(self.go_lw, self.go_sw, max_columns, -1, self.emis, self.albedo, self.solar)
+        self.pipe = api.Pipeline(self.go_lw, self.go_sw, max_columns, -1, self.emis, self.albedo, self.solar, spectral=spectral)
         self.total_lines = {"lw": sum(v["v0"].size for v in self.lw_lines.values()),
                             "sw": sum(v["v0"].size for v in self.sw_lines.values())}
 

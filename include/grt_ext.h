@@ -102,6 +102,14 @@ typedef struct GrtPipeline GrtPipeline_t;
 EXTERN int grt_pipeline_create(GrtPipeline_t **pipeline, GasOptics_t *lw_gas, GasOptics_t *sw_gas,
                                int max_columns, int user_level, fp_t const *emissivity,
                                fp_t const *albedo, fp_t const *solar_flux);
+/* keep_spectra = 0 (what grt_pipeline_create does): production form -- the solvers form Rayleigh and the optics
+   combination in registers from tau_gas, keep nothing spectral and integrate in-kernel; device memory per column is
+   tau_gas (+ 2 x [levels][n] scratch in the shortwave) instead of four optics and two flux arrays.
+   keep_spectra = 1: tau, omega, g and flux_up/down are materialised as the reference's calls would leave them
+   (grt_pipeline_views; parity tests, spectral output). */
+EXTERN int grt_pipeline_create_ex(GrtPipeline_t **pipeline, GasOptics_t *lw_gas, GasOptics_t *sw_gas,
+                                  int max_columns, int user_level, fp_t const *emissivity,
+                                  fp_t const *albedo, fp_t const *solar_flux, int keep_spectra);
 EXTERN int grt_pipeline_destroy(GrtPipeline_t **pipeline);
 
 /* Enqueue the whole hot path for columns->ncol (<= max_columns) columns and write the
@@ -111,7 +119,8 @@ EXTERN int grt_pipeline_run(GrtPipeline_t *pipeline, GrtColumns_t const *columns
 EXTERN int grt_pipeline_sync(GrtPipeline_t *pipeline);
 /* The HIP stream every kernel of this device is enqueued on (for event timing). */
 EXTERN void *grt_pipeline_stream(GrtPipeline_t *pipeline);
-/* Device views of the last run's spectral arrays (for parity tests): band 0 = lw, 1 = sw. */
+/* Device views of the last run's spectral arrays (for parity tests): band 0 = lw, 1 = sw.  tau_gas always; the rest
+   only on a pipeline created with keep_spectra = 1 (GRTCODE_VALUE_ERR otherwise). */
 EXTERN int grt_pipeline_views(GrtPipeline_t *pipeline, int band, fp_t **tau_gas, fp_t **tau,
                               fp_t **omega, fp_t **g, fp_t **flux_up, fp_t **flux_down);
 

@@ -50,7 +50,7 @@ def test_full_g1_column_against_reference(lib, device, physical):
     """One column of the bench workload at FULL size, LW + SW, production form and reference-order form."""
     kind, chk, orc = RC.checker(omp=True)
     RC.set_omp_threads(min(os.cpu_count() or 1, 16))
-    wl = W.G1Workload(device, 1, physical=physical)
+    wl = W.G1Workload(device, 1, physical=physical, spectral=True)
     col = syn.profile(0, W.NUM_LEVELS)
     ref = {}
     for band, grid, lines, sw in (("lw", W.LW_GRID, wl.lw_lines, False), ("sw", W.SW_GRID, wl.sw_lines, True)):

@@ -133,3 +133,42 @@ def test_pipeline_fast_form_fluxes_within_north_star_tolerance(bands, oracle, li
     pipe.destroy()
     go_lw.destroy()
     go_sw.destroy()
+
+
+@pytest.mark.parametrize("user_level", [-1, 0, 7, 15])
+def test_fused_production_pipeline_equals_materialised_pipeline(bands, oracle, lib, device, user_level):
+    """grt_pipeline_create (production: Rayleigh + optics combination + solver + trapezoid in one kernel per band, nothing
+    spectral kept) against grt_pipeline_create_ex(keep_spectra = 1) (tau/omega/g and [level][wavenumber] fluxes as the
+    reference's calls leave them, row-wise trapezoid) and against the oracle: same per-wavenumber arithmetic, so the
+    integrated fluxes differ only by the order of the spectral sum."""
+    lwb, swb = bands
+    V, ncol = 16, 3
+    cols = [syn.profile(20 + c, V) for c in range(ncol)]
+    go_lw, grid_lw = lwb.gas_optics(device, V)
+    go_sw, grid_sw = swb.gas_optics(device, V)
+    emis, alb = np.full(lwb.nw, 0.98), np.full(swb.nw, 0.2)
+    solar = api.create_solar_flux(grid_sw, swb.files["solar"])
+    gcols, keep = api.make_columns(cols, MOL_ORDER, cfc_order=(0, 1))
+    got = {}
+    for spectral in (True, False):
+        pipe = api.Pipeline(go_lw, go_sw, ncol, user_level, emis, alb, solar, spectral=spectral)
+        pipe.run(gcols)
+        got[spectral] = pipe.fluxes(ncol)
+        if not spectral:
+            pipe.run(gcols)
+            assert np.array_equal(pipe.fluxes(ncol), got[False])               # fixed-order reduction: the same bits every run (fast = 0)
+            with pytest.raises(api.GrtError):                       # nothing spectral is kept in this form
+                ptrs = [api.C.c_void_p() for _ in range(6)]
+                api.check(lib.grt_pipeline_views(pipe.p, 0, *[api.C.byref(p) for p in ptrs]))
+            assert pipe.views(1)["tau_gas"]                         # ... except tau_gas
+        pipe.destroy()
+    scale = np.abs(got[True]).max()
+    assert np.max(np.abs(got[True] - got[False])) < 1e-12 * scale
+    for c, col in enumerate(cols):
+        for bi, (band, lw) in enumerate(((lwb, True), (swb, False))):
+            w = oracle_column(oracle, lib, band, col, lw, emis, alb, solar, user_level)
+            assert np.max(np.abs(got[False][c, bi * 6: bi * 6 + 6] - w["integ"])) < 1e-9
+    if user_level < 0:
+        assert np.all(got[False][:, [2, 5, 8, 11]] == 0.0)
+    go_lw.destroy()
+    go_sw.destroy()
