@@ -79,7 +79,16 @@ def test_full_g1_column_against_reference(lib, device, physical):
             up = api.device_to_host(device, v["flux_up"], (V, nw))
             dn = api.device_to_host(device, v["flux_down"], (V, nw))
             fs = max(np.abs(ref[band]["up"]).max(), np.abs(ref[band]["dn"]).max())
-            m["spectral_flux_abs_w_m2_per_cm"] = float(max(np.abs(up - ref[band]["up"]).max(), np.abs(dn - ref[band]["dn"]).max()))
+            # one reference defect is not reproduced: when a range check inside sw_flux trips on a
+            # rounding-level excursion (shortwave.c:318-320) sw_fluxes_kernel stores the PREVIOUS wavenumber's fluxes
+            # (:443 ignores the code); such points -- every level equal to the left neighbour's -- are left out
+            ok = np.ones(nw, dtype=bool)
+            if band == "sw":
+                ok[1:] = ~(np.all(ref[band]["up"][:, 1:] == ref[band]["up"][:, :-1], axis=0) &
+                           np.all(ref[band]["dn"][:, 1:] == ref[band]["dn"][:, :-1], axis=0))
+                m["reference_stale_points"] = int((~ok).sum())
+                assert (~ok).mean() < 0.01
+            m["spectral_flux_abs_w_m2_per_cm"] = float(max(np.abs(up - ref[band]["up"])[:, ok].max(), np.abs(dn - ref[band]["dn"])[:, ok].max()))
             m["spectral_flux_rel"] = m["spectral_flux_abs_w_m2_per_cm"] / fs
             rep[band] = m
             for key in ("of_layer_max", "pointwise_rel", "transmission", "spectral_flux_rel"):
