@@ -119,6 +119,61 @@ def fine_grid_column(wl, dw, reps, compare_layers=0):
     return out
 
 
+def reference_abi_rate(wl, ncol=3):
+    """What an UNCHANGED caller of the reference's one-column interface gets (framework/src/driver.c:360-424): per band
+    set_*_ppmv -> calculate_optical_depth -> rayleigh_scattering -> add_optics -> calculate_{lw,sw}_fluxes with HOST flux
+    arrays (2 V n doubles over PCIe per call) -> the caller's trapezoid -> destroy_optics.  Reference-order arithmetic
+    (fast = 0, the default of a new gas-optics object) unless GRT_GAS_OPTICS_FAST is set; here both are timed."""
+    from grtcode_amd import api, synthetic as syn, workload as W
+    V = W.NUM_LEVELS
+    lw = api.LongwaveObject(V, wl.grid_lw, wl.device)
+    sw = api.ShortwaveObject(V, wl.grid_sw, wl.device)
+    objs = {}
+    for name, go, grid in (("lw", wl.go_lw, wl.grid_lw), ("sw", wl.go_sw, wl.grid_sw)):
+        objs[name] = (go, api.OpticsObject(V - 1, grid, wl.device), api.OpticsObject(V - 1, grid, wl.device), grid)
+
+    def column(c):
+        col = syn.profile(c, V)
+        total = []
+        for name in ("lw", "sw"):
+            go, gas, ray, grid = objs[name]
+            for m in W.MOL_ORDER:
+                go.set_molecule_ppmv(m, col["ppmv"][m])
+            go.set_cfc_ppmv(0, col["cfc_ppmv"][0])
+            go.set_cfc_ppmv(1, col["cfc_ppmv"][1])
+            go.set_cia_ppmv(0, col["ppmv"][syn.N2])
+            go.set_cia_ppmv(1, col["ppmv"][syn.O2])
+            go.calculate_optical_depth(col["p"], col["t"], gas)
+            ray.rayleigh(col["p"])
+            tot = api.add_optics([gas, ray])
+            if name == "lw":
+                up, dn = lw.fluxes(tot, col["t_surf"], col["t_layer"], col["t"], wl.emis)
+            else:
+                up, dn = sw.fluxes(tot, col["mu0"], 0.5, wl.albedo, wl.albedo, col["tsi"], wl.solar)
+            dw = grid.dw
+            total += [float(np.sum(0.5 * (r[:-1] + r[1:]) * dw)) for r in (up[0], up[-1], dn[0], dn[-1])]   # driver.c:302-326
+            tot.destroy()
+        return total
+    out = {}
+    for fast in (0, 3):
+        wl.go_lw.tune(fast=fast)
+        wl.go_sw.tune(fast=fast)
+        column(0)
+        t0 = time.perf_counter()
+        for c in range(ncol):
+            fl = column(c)
+        out["fast%d_columns_per_s" % fast] = ncol / (time.perf_counter() - t0)
+    out["note"] = ("one column per call, synchronous, 2*V*n doubles of spectral flux copied to the host per solver call "
+                   "(49 MB per shortwave column); fast0 = what an unchanged driver gets, fast3 = the same driver with "
+                   "GRT_GAS_OPTICS_FAST=3 in its environment")
+    for o in (lw, sw):
+        o.destroy()
+    for name in objs:
+        objs[name][1].destroy()
+        objs[name][2].destroy()
+    return out
+
+
 def parity_of_column0(wl, fluxes, bands, kind):
     """The GPU's column 0 of the last timed step against the CPU checker's column 0 (same inputs): the twelve
     integrated fluxes [W m-2] and the spectral gas optical depths of both bands."""
@@ -259,13 +314,18 @@ def main():
         fsteps = int(np.ceil(25.0 / sw_grid[2]))
         points = lambda nlines: float(L) * nlines * (2 * fsteps + 1) * cols_launch    # Voigt evaluations per launch
         valu_flop = 12.0 * points(S["sw"])                                            # ~12 flop far-wing point
-        traffic = None
+        # HBM-side bytes per launch are PMC counters (FETCH_SIZE, WRITE_SIZE: separate rocprofv3 --pmc passes of this same
+        # command, scripts/profile_round.sh) -- they cannot be read inside an ordinary run, so the figure of the last
+        # profiled run is carried here, labelled as such, and dropped when the configuration differs
+        traffic, traffic_src, solver_traffic = None, None, {}
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("cols") == args.cols and tj.get("fast") == args.fast:
+                if tj.get("cols") == args.cols and tj.get("fast") == args.fast and not strong:
                     traffic = tj["gas_optics_sw"]["hbm_bytes_per_launch"]
+                    traffic_src = f"profiles/traffic_latest.json: rocprofv3 --pmc passes of this command, round tag {tj.get('tag')} (not measured in this run)"
+                    solver_traffic = {k: v.get("hbm_bytes_per_launch") for k, v in tj.get("solvers", {}).items()}
             except Exception:
                 traffic = None
         total_cols = total_per_step * args.steps
@@ -285,7 +345,7 @@ def main():
                        "parallelism": f"columns sharded over {world} GPU(s), RCCL gather of 12 fluxes/column"},
             "roofline": {"kernel": f"{line_kernel} (line-by-line tau), SW-band launch", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "avg_launch_ms": dom_ms, "launches": ms[2][1],
+                         "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": dom_ms, "launches": ms[2][1],
                          "note": "this kernel is FP32/FP64-VALU bound by construction, see roofline_valu"},
             "roofline_valu": {"kernel": f"{line_kernel}, SW-band launch", "bound": "valu_fp32",
                               "achieved": valu_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0,
@@ -312,7 +372,8 @@ def main():
                 sol[name] = {"avg_launch_ms": t * 1e3, "columns_per_launch": cols_launch,
                              "algorithmic_bytes_survey": surv * n * cols_launch, "achieved_gb_per_s_survey": surv * n * cols_launch / t / 1e9,
                              "frac_hbm_survey": surv * n * cols_launch / t / 1e9 / HBM_PEAK_GBS,
-                             "compulsory_bytes_fused": fused_b * n * cols_launch, "achieved_gb_per_s_fused": fused_b * n * cols_launch / t / 1e9}
+                             "compulsory_bytes_fused": fused_b * n * cols_launch, "achieved_gb_per_s_fused": fused_b * n * cols_launch / t / 1e9,
+                             "traffic": solver_traffic.get(name + "_kernel")}
         line["roofline_solvers"] = dict(sol, bound="valu_fp64 (shortwave), latency (longwave: 26 000 threads)", peak=HBM_PEAK_GBS, unit="GB/s")
         if world == 1 and not args.no_extras:
             # what an unchanged caller of calculate_optical_depth gets: the reference-order form (fast = 0)
@@ -325,6 +386,7 @@ def main():
                 step()
             barrier()
             line["reference_order_columns_per_s"] = 2 * total_per_step / (time.perf_counter() - t0)
+            line["reference_abi"] = reference_abi_rate(wl)
             wl.go_lw.tune(fast=args.fast, tile=args.tile, nslice=args.lw_nslice)
             wl.go_sw.tune(fast=args.fast, tile=args.tile)
             step()                              # column 0 of the production form back in the buffers (parity below)
