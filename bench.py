@@ -130,13 +130,14 @@ def reference_abi_rate(wl, ncol=3):
     sw = api.ShortwaveObject(V, wl.grid_sw, wl.device)
     objs = {}
     for name, go, grid in (("lw", wl.go_lw, wl.grid_lw), ("sw", wl.go_sw, wl.grid_sw)):
-        objs[name] = (go, api.OpticsObject(V - 1, grid, wl.device), api.OpticsObject(V - 1, grid, wl.device), grid)
+        objs[name] = (go, api.OpticsObject(V - 1, grid, wl.device), api.OpticsObject(V - 1, grid, wl.device), grid,
+                      (np.zeros((V, grid.n)), np.zeros((V, grid.n))))       # flux arrays allocated once, as driver.c:682-688
 
     def column(c):
         col = syn.profile(c, V)
         total = []
         for name in ("lw", "sw"):
-            go, gas, ray, grid = objs[name]
+            go, gas, ray, grid, bufs = objs[name]
             for m in W.MOL_ORDER:
                 go.set_molecule_ppmv(m, col["ppmv"][m])
             go.set_cfc_ppmv(0, col["cfc_ppmv"][0])
@@ -147,9 +148,9 @@ def reference_abi_rate(wl, ncol=3):
             ray.rayleigh(col["p"])
             tot = api.add_optics([gas, ray])
             if name == "lw":
-                up, dn = lw.fluxes(tot, col["t_surf"], col["t_layer"], col["t"], wl.emis)
+                up, dn = lw.fluxes(tot, col["t_surf"], col["t_layer"], col["t"], wl.emis, bufs)
             else:
-                up, dn = sw.fluxes(tot, col["mu0"], 0.5, wl.albedo, wl.albedo, col["tsi"], wl.solar)
+                up, dn = sw.fluxes(tot, col["mu0"], 0.5, wl.albedo, wl.albedo, col["tsi"], wl.solar, bufs)
             dw = grid.dw
             total += [float(np.sum(0.5 * (r[:-1] + r[1:]) * dw)) for r in (up[0], up[-1], dn[0], dn[-1])]   # driver.c:302-326
             tot.destroy()

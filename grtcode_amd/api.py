@@ -358,10 +358,11 @@ class LongwaveObject:
         self.c = Longwave()
         check(self.lib.create_longwave(C.byref(self.c), num_levels, C.byref(grid), C.byref(C.c_int(device))))
 
-    def fluxes(self, optics, T_surf, T_layers, T_levels, emis):
+    def fluxes(self, optics, T_surf, T_layers, T_levels, emis, out=None):
+        """out: optional (flux_up, flux_down) [V][n] arrays to fill (a C driver allocates them once: driver.c:682-688)."""
         T_layers, T_levels, emis = _f64(T_layers).copy(), _f64(T_levels).copy(), _f64(emis).copy()
         V, n = self.c.num_levels, self.c.grid.n
-        up, dn = np.zeros((V, n)), np.zeros((V, n))
+        up, dn = out if out is not None else (np.zeros((V, n)), np.zeros((V, n)))
         check(self.lib.calculate_lw_fluxes(C.byref(self.c), C.byref(optics.c), T_surf, _dp(T_layers),
                                            _dp(T_levels), _dp(emis), _dp(up), _dp(dn)))
         return up, dn
@@ -376,10 +377,10 @@ class ShortwaveObject:
         self.c = Shortwave()
         check(self.lib.create_shortwave(C.byref(self.c), num_levels, C.byref(grid), C.byref(C.c_int(device))))
 
-    def fluxes(self, optics, mu_dir, mu_dif, alb_dir, alb_dif, tsi, solar):
+    def fluxes(self, optics, mu_dir, mu_dif, alb_dir, alb_dif, tsi, solar, out=None):
         alb_dir, alb_dif, solar = _f64(alb_dir).copy(), _f64(alb_dif).copy(), _f64(solar).copy()
         V, n = self.c.num_levels, self.c.grid.n
-        up, dn = np.zeros((V, n)), np.zeros((V, n))
+        up, dn = out if out is not None else (np.zeros((V, n)), np.zeros((V, n)))
         check(self.lib.calculate_sw_fluxes(C.byref(self.c), C.byref(optics.c), mu_dir, mu_dif, _dp(alb_dir),
                                            _dp(alb_dif), tsi, _dp(solar), _dp(up), _dp(dn)))
         return up, dn

@@ -32,6 +32,7 @@ def main():
         return r
     for name, go, grid in (("lw", wl.go_lw, wl.grid_lw), ("sw", wl.go_sw, wl.grid_sw)):
         go.tune(fast=args.fast)
+    bufs = {"lw": (np.zeros((V, wl.grid_lw.n)), np.zeros((V, wl.grid_lw.n))), "sw": (np.zeros((V, wl.grid_sw.n)), np.zeros((V, wl.grid_sw.n)))}
     gas = {"lw": api.OpticsObject(V - 1, wl.grid_lw, device), "sw": api.OpticsObject(V - 1, wl.grid_sw, device)}
     ray = {"lw": api.OpticsObject(V - 1, wl.grid_lw, device), "sw": api.OpticsObject(V - 1, wl.grid_sw, device)}
     for c in range(args.columns + 1):
@@ -51,9 +52,9 @@ def main():
             timed(name + " rayleigh_scattering", ray[name].rayleigh, col["p"])
             tot = timed(name + " add_optics", api.add_optics, [gas[name], ray[name]])
             if name == "lw":
-                timed("lw calculate_lw_fluxes", lw.fluxes, tot, col["t_surf"], col["t_layer"], col["t"], wl.emis)
+                timed("lw calculate_lw_fluxes", lw.fluxes, tot, col["t_surf"], col["t_layer"], col["t"], wl.emis, bufs["lw"])
             else:
-                timed("sw calculate_sw_fluxes", sw.fluxes, tot, col["mu0"], 0.5, wl.albedo, wl.albedo, col["tsi"], wl.solar)
+                timed("sw calculate_sw_fluxes", sw.fluxes, tot, col["mu0"], 0.5, wl.albedo, wl.albedo, col["tsi"], wl.solar, bufs["sw"])
             timed(name + " destroy_optics", tot.destroy)
     total = sum(t.values())
     print(json.dumps({"fast": args.fast, "ran": {"lw": wl.go_lw.last_launch(), "sw": wl.go_sw.last_launch()},
