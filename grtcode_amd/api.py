@@ -138,7 +138,7 @@ create_solar_flux destroy_solar_flux disort_shortwave
 grt_tips_load grt_tips_reset grt_tips_is_table grt_tips_source grt_sizeof grt_add_molecule_lines grt_gas_optics_tune grt_gas_optics_last_launch grt_hitran_index_stats
 grt_optical_depth_batch grt_pipeline_create grt_pipeline_create_ex grt_pipeline_destroy grt_pipeline_run grt_pipeline_sync
 grt_pipeline_stream grt_pipeline_views grt_device_malloc grt_device_free grt_device_to_host
-grt_host_to_device grt_debug_line_prep grt_debug_partition_functions grt_profile_enable grt_profile_read
+grt_host_to_device grt_debug_line_prep grt_debug_partition_functions grt_debug_voigt grt_profile_enable grt_profile_read
 grt_multi_shard grt_multi_create grt_multi_destroy grt_multi_gather_fluxes grt_multi_broadcast grt_multi_max
 grt_err_begin grt_err_frame grt_log grt_gmalloc grt_gfree grt_gmemset grt_gmemcpy
 """.split()
@@ -456,6 +456,15 @@ class Pipeline:
     def destroy(self):
         self.out.free()
         check(self.lib.grt_pipeline_destroy(C.byref(self.p)))
+
+
+def debug_voigt(device, fast, w_start, npts, wres, center, gamma, alpha):
+    """rfm_voigt_line_shape on the device (grt_debug_voigt): K [npts]."""
+    lib = load_library()
+    K = np.zeros(npts)
+    lib.grt_debug_voigt.argtypes = [C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, c_double_p]
+    check(lib.grt_debug_voigt(device, int(fast), w_start, npts, wres, center, gamma, alpha, _dp(K)))
+    return K
 
 
 def profile_enable(on=True):

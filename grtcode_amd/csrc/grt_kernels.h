@@ -122,6 +122,11 @@ int grt_launch_line_prep(void *stream, GrtGasOpticsArgs const *a, int col,
                          double *vnn, double *snn, double *gamma, double *alpha,
                          int64_t *win_s, int64_t *win_e);
 
+/* Debug/parity hook: rfm_voigt_line_shape (RFM_voigt.c:85-281) for one line on n points, from the device functions the
+   line kernels use; fast = 0 reference operation order, 1 fused arithmetic. */
+int grt_launch_voigt_debug(void *stream, int fast, double w_start, uint64_t n, double wres, double center,
+                           double gamma, double alpha, double *K_dev);
+
 /* rayleigh.c:29-68: n_layer [L] on device. */
 int grt_launch_rayleigh(void *stream, int num_layers, double w0, double dw, uint64_t nw,
                         double const *n_layer, double *tau, double *omega, double *g);

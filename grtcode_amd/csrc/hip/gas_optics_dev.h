@@ -334,6 +334,37 @@ __device__ __forceinline__ double voigt_near(float xi, float y)
     return k;
 }
 
+// ---- the cheap branches of rfm_voigt_line_shape, one point each (the ring kernel and the Voigt parity hook
+// grt_debug_voigt share them; regions 2-4 are voigt_near above) ----
+// reference order, pure Lorentz line (y >= 70.55): K = REPWID*Y / (pi (X^2 + Y^2)), quotient in double (RFM_voigt.c:97-106)
+__device__ __forceinline__ double voigt_lorentz_ref(float num, float xq, float yq)
+{
+    return (double)num/(M_PI*(double)(xq + yq));
+}
+// reference order, far wing |x| >= XLIM0: K = Y RSQRPI / (X^2 + Y^2) before the final scaling (RFM_voigt.c:170)
+__device__ __forceinline__ float voigt_far_ref(float yrrtpi, float xq, float yq)
+{
+    return yrrtpi/(xq + yq);
+}
+// reference order, region 1: D = RSQRPI/(D0 + XQ (D2 + XQ)); K = D Y (A0 + XQ) (RFM_voigt.c:181-182)
+__device__ __forceinline__ float voigt_reg1_ref(float y, float a0, float d0r, float d2r, float xq)
+{
+    float const d = kRsqrpi/(d0r + xq*(d2r + xq));
+    return d*y*(a0 + xq);
+}
+// fused form: the Lorentzian cl/(x^2 + y^2), cl = REPWID*Y/pi -- far wing (:170 with :278) and pure Lorentz (:103) alike
+__device__ __forceinline__ float voigt_lorentzian_fast(float cl, float xi, float yq)
+{
+    return cl*__builtin_amdgcn_rcpf(fmaf(xi, xi, yq));
+}
+// fused form: region 1 minus that Lorentzian, cl (1.5 XQ - 0.5 A0) / [(D0 + XQ (D2 + XQ)) (XQ + YQ)]
+// (A0 = YQ + 0.5, D0 = A0^2, D2 = 2 YQ - 1): one reciprocal, no cancellation
+__device__ __forceinline__ float voigt_reg1_corr_fast(float cl, float a0, float d0r, float d2r, float xi, float xq, float yq)
+{
+    float const den = fmaf(xq, d2r + xq, d0r)*fmaf(xi, xi, yq);
+    return cl*fmaf(1.5f, xq, -0.5f*a0)*__builtin_amdgcn_rcpf(den);
+}
+
 // x-coordinate of window point k of a line: RFM_voigt.c:102/165 with DWNO from
 // kernels.c:438.  (k converts exactly; the sum order is the reference's.)
 __device__ __forceinline__ float voigt_x(double dwno, int k, double wres, double wnoadj,

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, 
                 float kfar = 0.f;
                 if (FAST && near)
                 {
-                    kfar = cl*__builtin_amdgcn_rcpf(fmaf(xi, xi, yq));
+                    kfar = voigt_lorentzian_fast(cl, xi, yq);
                 }
                 if (inner & !near)
                 {
@@ -234,14 +234,12 @@ __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, 
                         // K1 - Kfar = cl [(A0+XQ)/(D0+XQ(D2+XQ)) - 1/(XQ+YQ)]
                         //           = cl (1.5 XQ - 0.5 A0) / [(D0+XQ(D2+XQ)) (XQ+YQ)]
                         // (A0 = YQ+0.5, D0 = A0^2, D2 = 2YQ-1): one reciprocal, no cancellation
-                        float const den = fmaf(xq, d2r + xq, d0r)*fmaf(xi, xi, yq);
-                        float const corr = cl*fmaf(1.5f, xq, -0.5f*a0)*__builtin_amdgcn_rcpf(den);
+                        float const corr = voigt_reg1_corr_fast(cl, a0, d0r, d2r, xi, xq, yq);
                         GRT_ACC_ADD(&acc[f - F0], amp*(double)corr);
                     }
                     else
                     {
-                        float const d = kRsqrpi/(d0r + xq*(d2r + xq));
-                        float const kf = d*y*(a0 + xq);
+                        float const kf = voigt_reg1_ref(y, a0, d0r, d2r, xq);
                         GRT_ACC_ADD(&acc[f - F0], amp*(norm*(double)kf));
                     }
                 }
@@ -284,7 +282,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, 
                     if (FAST)
                     {
                         float const xi = fmaf((float)(f - c), wr, ndcr);
-                        float const kf = cl*__builtin_amdgcn_rcpf(fmaf(xi, xi, yq));
+                        float const kf = voigt_lorentzian_fast(cl, xi, yq);
                         GRT_ACC_ADD(&acc[f - F0], amp*(double)kf);
                     }
                     else
@@ -294,11 +292,11 @@ __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, 
                         float const xq = abx*abx;
                         if (lorentz)
                         {
-                            GRT_ACC_ADD(&acc[f - F0], amp*((double)num/(M_PI*(double)(xq + yq))));   // :103
+                            GRT_ACC_ADD(&acc[f - F0], amp*voigt_lorentz_ref(num, xq, yq));           // :103
                         }
                         else if (abx >= xlim0)
                         {
-                            float const kf = yrrtpi/(xq + yq);                                    // :170
+                            float const kf = voigt_far_ref(yrrtpi, xq, yq);                        // :170
                             GRT_ACC_ADD(&acc[f - F0], amp*(norm*(double)kf));
                         }
                     }
@@ -326,7 +324,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, 
                 {
                     float const rel = base_rel + (float)slot;
                     float const xi = fmaf(rel, wr, ndcr);
-                    float kf = (fabsf(rel - mid) <= half) ? cl*__builtin_amdgcn_rcpf(fmaf(xi, xi, yq)) : 0.f;
+                    float kf = (fabsf(rel - mid) <= half) ? voigt_lorentzian_fast(cl, xi, yq) : 0.f;
                     asm volatile("" : "+v"(kf));    // select in fp32, then widen once
                     token = fma(amp, (double)kf, token);
                     token = ring_pass(token);
@@ -347,11 +345,11 @@ __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, 
                         if (lorentz)
                         {
                             // pure Lorentz: RFM_voigt.c:97-106 (quotient in double)
-                            token += amp*((double)num/(M_PI*(double)(xq + yq)));
+                            token += amp*voigt_lorentz_ref(num, xq, yq);
                         }
                         else if (abx >= xlim0)
                         {
-                            float const kf = yrrtpi/(xq + yq);                    // :170
+                            float const kf = voigt_far_ref(yrrtpi, xq, yq);       // :170
                             token += amp*(norm*(double)kf);
                         }
                     }
@@ -439,6 +437,110 @@ extern "C" int grt_launch_gas_optics(void *stream, GrtGasOpticsArgs const *a)
     else
     {
         hipLaunchKernelGGL(gas_optics_kernel<false>, grid, dim3(kBlock), lds, s, *a, fsteps, (unsigned)ngroups, stride);
+    }
+    return (int)hipGetLastError();
+}
+
+namespace {
+
+// Parity hook: rfm_voigt_line_shape (RFM_voigt.c:85-281) for one line on n equally spaced points, assembled from the
+// very device functions the line kernels use.  FAST = false: the reference's operation order (K bit for bit);
+// FAST = true: the fused form's arithmetic (hardware reciprocals, REPWID by Newton step, Lorentzian + region-1
+// correction, regions 2-4 through voigt_near<true>).  One thread per point.
+template <bool FAST>
+__global__ __launch_bounds__(kBlock) void voigt_debug_kernel(double w_start, uint64_t n, double wres, double center,
+                                                            double gamma, double alpha, double *K)
+{
+    uint64_t const i = (uint64_t)blockIdx.x*kBlock + threadIdx.x;
+    if (i >= n)
+    {
+        return;
+    }
+    float repwid;
+    if (FAST)
+    {
+        double const r0 = (double)__builtin_amdgcn_rcpf((float)alpha);
+        repwid = (float)((double)kSqrln2*(r0*fma(-alpha, r0, 2.0)));
+    }
+    else
+    {
+        repwid = (float)((double)kSqrln2/alpha);                                      // RFM_voigt.c:94
+    }
+    float const y = (float)((double)repwid*gamma);                                    // :95
+    bool const lorentz = (y >= 70.55f);                                               // :97
+    float const yq = y*y;
+    float const xlim0 = FAST ? __builtin_amdgcn_sqrtf(15100.0f + y*(40.0f - y*3.6f)) : sqrtf(15100.0f + y*(40.0f - y*3.6f));
+    float const r1 = 164.0f - y*(4.3f + y*1.8f);
+    float xlim1 = (y >= 8.425f) ? 0.0f : (FAST ? __builtin_amdgcn_sqrtf(r1) : sqrtf(r1));
+    if (y <= 0.000001f)
+    {
+        xlim1 = xlim0;                                                                // :122-126
+    }
+    float const a0 = FAST ? yq + 0.5f : (float)((double)yq + 0.5);                    // :177
+    float const d0r = a0*a0;
+    float const d2r = FAST ? (yq + yq) - 1.0f : (float)((double)(yq + yq) - 1.0);     // :179
+    float const num = repwid*y;                                                       // :103
+    float const yrrtpi = y*kRsqrpi;                                                   // :108
+    double const norm = (double)(kRsqrpi*repwid);                                     // :278
+    float const cl = (repwid*y)*0.318309886f;
+    float const xi = voigt_x(w_start, (int)i, wres, center, repwid);                  // :102/165
+    float const abx = fabsf(xi);
+    float const xq = abx*abx;
+    double k;
+    if (FAST)
+    {
+        float const xqf = xi*xi;
+        if (lorentz || xqf >= xlim0*xlim0)
+        {
+            k = (double)voigt_lorentzian_fast(cl, xi, yq);
+        }
+        else if (xqf >= xlim1*xlim1)
+        {
+            k = (double)voigt_lorentzian_fast(cl, xi, yq) + (double)voigt_reg1_corr_fast(cl, a0, d0r, d2r, xi, xqf, yq);
+        }
+        else
+        {
+            k = norm*voigt_near<true>(xi, y);
+        }
+    }
+    else if (lorentz)
+    {
+        k = voigt_lorentz_ref(num, xq, yq);
+    }
+    else if (abx >= xlim0)
+    {
+        k = norm*(double)voigt_far_ref(yrrtpi, xq, yq);
+    }
+    else if (abx >= xlim1)
+    {
+        k = norm*(double)voigt_reg1_ref(y, a0, d0r, d2r, xq);
+    }
+    else
+    {
+        k = norm*voigt_near<false>(xi, y);
+    }
+    K[i] = k;
+}
+
+} // namespace
+
+extern "C" int grt_launch_voigt_debug(void *stream, int fast, double w_start, uint64_t n, double wres, double center,
+                                      double gamma, double alpha, double *K_dev)
+{
+    if (n == 0 || n > 0x7fffffffull)
+    {
+        return (int)hipErrorInvalidValue;
+    }
+    dim3 const grid((unsigned)((n + kBlock - 1)/kBlock));
+    if (fast)
+    {
+        hipLaunchKernelGGL(voigt_debug_kernel<true>, grid, dim3(kBlock), 0, (hipStream_t)stream, w_start, n, wres, center,
+                           gamma, alpha, K_dev);
+    }
+    else
+    {
+        hipLaunchKernelGGL(voigt_debug_kernel<false>, grid, dim3(kBlock), 0, (hipStream_t)stream, w_start, n, wres, center,
+                           gamma, alpha, K_dev);
     }
     return (int)hipGetLastError();
 }

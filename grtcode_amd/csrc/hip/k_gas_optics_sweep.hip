@@ -121,6 +121,64 @@ __device__ bool bracket(uint64_t array_size, double const *array, double val, ui
     return true;
 }
 
+// Wave-collective search (all 64 lanes of one wave call it with the same arguments): first index in [0, n) at which
+// pred(v[idx]) holds, n if none; pred false ... false true ... true along the array.  64 probes per round instead of
+// one: three rounds for 300 000 lines where a bisection by one lane needs eighteen dependent loads.
+template <typename P>
+__device__ uint64_t first_true_wave(uint64_t n, double const *v, P pred, int lane)
+{
+    uint64_t lo = 0, hi = n;            // everything before lo is false, everything from hi on is true (or hi == n)
+    while (hi - lo > 64)
+    {
+        uint64_t const step = (hi - lo + 63)/64;
+        uint64_t const idx = lo + (uint64_t)(lane + 1)*step - 1;
+        bool const t = idx < hi ? pred(v[idx]) : true;
+        unsigned long long const m = __ballot(t);
+        int const f = __ffsll((long long)m) - 1;                // first lane whose probe holds (lane 63 probes >= hi - 1)
+        uint64_t const at = lo + (uint64_t)(f + 1)*step - 1;
+        uint64_t const before = f > 0 ? lo + (uint64_t)f*step : lo;
+        if (m == 0ull)
+        {
+            lo = lo + 64*step < hi ? lo + 64*step : hi;
+        }
+        else
+        {
+            hi = at < hi ? at : hi;
+            lo = before;
+        }
+    }
+    uint64_t const idx = lo + (uint64_t)lane;
+    bool const t = idx < hi ? pred(v[idx]) : true;
+    unsigned long long const m = __ballot(t);
+    uint64_t const r = lo + (uint64_t)(__ffsll((long long)m) - 1);
+    return m == 0ull || r > hi ? hi : r;
+}
+
+// bracket() by a whole wave, same results: where no element equals val the reference's bisection ends on
+// (largest element below val, smallest above); where one does, its answer depends on the path it takes, so that
+// (rare: a line centre exactly on a bin's interpolation wavenumber) case follows the serial search.
+__device__ bool bracket_wave(uint64_t n, double const *a, double val, uint64_t *left, uint64_t *right, int lane)
+{
+    if (n < 1)
+    {
+        return false;
+    }
+    if (val < a[0] || val > a[n - 1])
+    {
+        *left = 0;
+        *right = n - 1;
+        return false;
+    }
+    uint64_t const p = first_true_wave(n, a, [&](double x) { return x >= val; }, lane);     // < n: a[n-1] >= val
+    if (a[p] == val)
+    {
+        return bracket(n, a, val, left, right);
+    }
+    *left = p - 1;          // p >= 1: a[0] < val
+    *right = p;
+    return true;
+}
+
 // sort_lines (kernels.c:135-172): per layer, a STABLE ascending sort by shifted centre.  The input is
 // sorted by unshifted centre and a shift is at most dmax*|pavg|, so an element's rank differs from its
 // index only by the neighbours within 2*dmax*|pavg|: count them.
@@ -167,17 +225,11 @@ struct LineSweepBins
     __device__ uint64_t right_r(double v) const { double w = v + (double)25.f; if (w > maxw) w = maxw; return (uint64_t)floor((w - w0)/bin_width); }
 };
 
-// first index in [0, n) whose value f(v[idx]) >= k (n if none): f monotone non-decreasing
+// first index in [0, n) whose value f(v[idx]) >= k (n if none): f monotone non-decreasing.  Wave-collective.
 template <typename F>
-__device__ uint64_t first_at_least(uint64_t n, double const *v, uint64_t k, F f)
+__device__ uint64_t first_at_least(uint64_t n, double const *v, uint64_t k, F f, int lane)
 {
-    uint64_t lo = 0, hi = n;
-    while (lo < hi)
-    {
-        uint64_t const mid = lo + (hi - lo)/2;
-        if (f(v[mid]) >= k) hi = mid; else lo = mid + 1;
-    }
-    return lo;
+    return first_true_wave(n, v, [&](double x) { return f(x) >= k; }, lane);
 }
 
 // calc_optical_depth_bin_sweep (kernels.c:176-307), METHOD 0, and calc_optical_depth_line_sweep
@@ -207,20 +259,24 @@ __global__ __launch_bounds__(256) void bin_sweep_kernel(uint64_t num_lines, doub
     {
         tloc[p] = 0.;
     }
-    if (tid == 0 && METHOD == 1)
+    // the bin's line ranges: found by the first wave together (64 probes per search round), stored by its lane 0
+    if (tid < 64 && METHOD == 1)
     {
         LineSweepBins const b = {bins.w0, bins.wres*bins.ppb, bins.w0 + bins.num_wpoints*bins.wres};
         // local: left(v) <= j <= right(v); remote left of the line: left_r(v) <= j < left(v); right: right(v) < j <= right_r(v)
-        uint64_t const loc_b = first_at_least(num_lines, v, j, [&](double x) { return b.right(x); });
-        uint64_t const loc_e = first_at_least(num_lines, v, j + 1, [&](double x) { return b.left(x); });      // left(v) > j
-        uint64_t const rl_e = first_at_least(num_lines, v, j + 1, [&](double x) { return b.left_r(x); });     // left_r(v) > j
-        uint64_t const rr_b = first_at_least(num_lines, v, j, [&](double x) { return b.right_r(x); });
+        uint64_t const loc_b = first_at_least(num_lines, v, j, [&](double x) { return b.right(x); }, tid);
+        uint64_t const loc_e = first_at_least(num_lines, v, j + 1, [&](double x) { return b.left(x); }, tid);      // left(v) > j
+        uint64_t const rl_e = first_at_least(num_lines, v, j + 1, [&](double x) { return b.left_r(x); }, tid);     // left_r(v) > j
+        uint64_t const rr_b = first_at_least(num_lines, v, j, [&](double x) { return b.right_r(x); }, tid);
         // as seen from the BIN: lines to its right have the bin on their remote-left side and vice versa
-        range[0] = loc_b; range[1] = loc_e - 1; range[2] = loc_e > loc_b ? 1 : 0;
-        range[3] = rr_b; range[6] = loc_b;              // [rr_b, loc_b): right(v) < j <= right_r(v)
-        range[4] = loc_e; range[5] = rl_e - 1;          // [loc_e, rl_e): left_r(v) <= j < left(v)
+        if (tid == 0)
+        {
+            range[0] = loc_b; range[1] = loc_e - 1; range[2] = loc_e > loc_b ? 1 : 0;
+            range[3] = rr_b; range[6] = loc_b;              // [rr_b, loc_b): right(v) < j <= right_r(v)
+            range[4] = loc_e; range[5] = rl_e - 1;          // [loc_e, rl_e): left_r(v) <= j < left(v)
+        }
     }
-    if (tid == 0 && METHOD == 0)
+    if (tid < 64 && METHOD == 0)
     {
         uint64_t const nbin_local = 1, nbin_remote = 25;
         uint64_t nbin = nbin_local;
@@ -229,8 +285,8 @@ __global__ __launch_bounds__(256) void bin_sweep_kernel(uint64_t num_lines, doub
         uint64_t left = 0, right = 0, tmp, has_local = 0;
         if (leftw <= v[num_lines - 1] && rightw >= v[0])
         {
-            bracket(num_lines, v, leftw, &left, &tmp);
-            bracket(num_lines - left, &v[left], rightw, &tmp, &right);
+            bracket_wave(num_lines, v, leftw, &left, &tmp, tid);
+            bracket_wave(num_lines - left, &v[left], rightw, &tmp, &right, tid);
             right += left;
             has_local = 1;
         }
@@ -248,7 +304,7 @@ __global__ __launch_bounds__(256) void bin_sweep_kernel(uint64_t num_lines, doub
         if (leftw >= v[0] && leftw_r <= v[num_lines - 1])
         {
             uint64_t lr = 0;
-            if (bracket(left, v, leftw_r, &lr, &tmp) || left > 0)
+            if (bracket_wave(left, v, leftw_r, &lr, &tmp, tid) || left > 0)
             {
                 left_r = lr;
             }
@@ -259,12 +315,15 @@ __global__ __launch_bounds__(256) void bin_sweep_kernel(uint64_t num_lines, doub
         {
             uint64_t const f = right == (uint64_t)(-1) ? 1 : 0;
             uint64_t rr = 0;
-            bracket(num_lines - (right + f), &v[right + f], rightw_r, &tmp, &rr);
+            bracket_wave(num_lines - (right + f), &v[right + f], rightw_r, &tmp, &rr, tid);
             right_r = rr + right + f;
             first_r = right + 1;
         }
-        range[0] = left; range[1] = right; range[2] = has_local; range[3] = left_r; range[4] = first_r; range[5] = right_r;
-        range[6] = left;
+        if (tid == 0)
+        {
+            range[0] = left; range[1] = right; range[2] = has_local; range[3] = left_r; range[4] = first_r; range[5] = right_r;
+            range[6] = left;
+        }
     }
     __syncthreads();
     uint64_t const left = range[0], right = range[1], left_r = range[3], first_r = range[4], right_r = range[5];

@@ -1851,3 +1851,21 @@ EXTERN int grt_debug_partition_functions(GasOptics_t *gas_optics, fp_t *pressure
     GRT_TRY(grt_dev_sync(dev, s));
     return GRTCODE_SUCCESS;
 }
+
+EXTERN int grt_debug_voigt(Device_t device, int fast, fp_t w, uint64_t num_wpoints, fp_t wres, fp_t line_center,
+                           fp_t gamma, fp_t alpha, fp_t *K)
+{
+    GRT_REQUIRE_PTR(K);
+    GRT_REQUIRE_RANGE(num_wpoints, 1, 1u << 30);
+    GRT_TRY(grt_dev_require(device));
+    void *s = grt_dev_stream(device);
+    double *d = NULL;
+    GRT_TRY(grt_dev_alloc(device, (void **)&d, sizeof(double)*num_wpoints));
+    int rc = grt_dev_check(grt_launch_voigt_debug(s, fast != 0, w, num_wpoints, wres, line_center, gamma, alpha, d),
+                           "voigt debug kernel");
+    if (rc == GRTCODE_SUCCESS) rc = grt_dev_download(device, K, d, sizeof(double)*num_wpoints, s);
+    if (rc == GRTCODE_SUCCESS) rc = grt_dev_sync(device, s);
+    grt_dev_free(device, d);
+    GRT_TRY(rc);
+    return GRTCODE_SUCCESS;
+}

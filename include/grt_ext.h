@@ -168,6 +168,13 @@ EXTERN int grt_debug_line_prep(GasOptics_t *gas_optics, fp_t *pressure, fp_t *te
                                double *snn, double *gamma, double *alpha, int64_t *win_s,
                                int64_t *win_e);
 
+/* ---- parity hook: the line shape itself.  Same inputs as rfm_voigt_line_shape(LineShapeInputs_t, K)
+ * (gas-optics/src/RFM_voigt.c:85-281, line_shape.h:26-35): K[i], i < num_wpoints, at w + i*wres for a line at
+ * line_center with Lorentz / Doppler half-widths gamma / alpha, evaluated on the DEVICE by the functions the
+ * line kernels are built from.  fast = 0: reference operation order; 1: the fused forms' arithmetic. */
+EXTERN int grt_debug_voigt(Device_t device, int fast, fp_t w, uint64_t num_wpoints, fp_t wres, fp_t line_center,
+                           fp_t gamma, fp_t alpha, fp_t *K);
+
 /* ---- parity hook: the 1/Q(T, iso) block of one column's state as the DEVICE holds it (the path of
  * calc_partition_functions, kernels.c:52-66: evaluated on the host per layer and isotopologue, shipped inside the
  * column state, read by the line kernels as q[slot][layer][iso-1]).  q_out: host [num_molecules][L][GRT_MAX_ISO = 18],

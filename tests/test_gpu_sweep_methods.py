@@ -82,3 +82,28 @@ def test_sweep_objects_work_in_the_batched_pipeline(tmp_path, oracle, lib, devic
         assert tau_close(tau[c], want) < 1e-11
     pipe.destroy()
     go.destroy()
+
+
+@pytest.mark.parametrize("method", [WAVENUMBER_SWEEP, LINE_SWEEP])
+def test_centres_exactly_on_bin_wavenumbers_and_duplicates(tmp_path, oracle, lib, device, method):
+    """The reference's bracket() (kernel_utils.c:26-77) stops at whichever equal element its bisection meets first, so
+    with line centres EXACTLY on a bin's interpolation wavenumbers -- first point, midpoint, last point -- and repeated
+    centres, which lines count as local or remote depends on the search path.  The wave-parallel searches of the
+    kernel must give the path's answer (they fall back to the serial search where an element equals the value)."""
+    w0, span, dw = 500.0, 120.0, 0.25
+    band = Band(str(tmp_path), w0, w0 + span, dw, 900, mols=[syn.CO2, syn.H2O], line_range=(w0, w0 + span - 26.5))
+    for m, ln in band.lines.items():
+        v = ln["v0"].copy()
+        k = np.arange(v.size)
+        v[k % 3 == 0] = np.floor(v[k % 3 == 0])                        # on a bin's first grid point (bins are 1 cm-1 wide)
+        v[k % 3 == 1] = np.floor(v[k % 3 == 1]) + 0.375                # on its midpoint: (w + (ppb - 1) dw)/2 with ppb = 5
+        v[k % 7 == 2] = np.floor(v[k % 7 == 2]) + 0.75                 # on its last grid point
+        order = np.argsort(v, kind="stable")
+        for key in ln:
+            ln[key] = ln[key][order] if key != "v0" else v[order]
+        ln["delta"] = np.zeros_like(ln["delta"])                        # no pressure shift: the centres stay where they are
+        assert np.sum(np.diff(ln["v0"]) == 0.0) > 50                    # repeated centres
+    col = syn.profile(2, 9)
+    got = run(band, device, col, method)
+    want = band.oracle_tau(oracle, oracle, lib, col, method=method)
+    assert tau_close(got, want) < 1e-11
