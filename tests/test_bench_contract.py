@@ -1,15 +1,20 @@
-"""The bench line's contract (keys the driver and the judge read), checked on the committed round-1 line."""
+"""The bench line's contract (keys the driver and the judge read), checked on the committed round-2 line
+(profiles/r2_bench_line.json: `python bench.py` on one MI355X) and on the strong-scaling variant."""
 import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def load(name):
+    return json.load(open(os.path.join(ROOT, "profiles", name)))
+
+
 def test_committed_bench_line_has_the_contract_fields():
-    line = json.load(open(os.path.join(ROOT, "profiles", "r1_bench_line.json")))
+    line = load("r2_bench_line.json")
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity"):
         assert key in line, key
     assert line["metric"].split(" at ")[0] in base["metric"]            # BASELINE.json's metric
     assert line["unit"] == "columns/s" and line["higher_is_better"] is True and line["scaling"] == "weak"
@@ -19,8 +24,36 @@ def test_committed_bench_line_has_the_contract_fields():
     r = line["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and (r["traffic"] is None or r["traffic"] > 0)
+    assert r["traffic"] is None or "not measured in this run" in r["traffic_source"]     # carried from the profiled run, and says so
     c = line["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     # throughput is whole-job columns over the timed steps
-    cols = line["config"]["columns_per_gpu_per_step"] * line["n_gpus"]
+    cols = line["config"]["columns_per_step"]
     assert abs(line["value"] - cols / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-9
+
+
+def test_bench_line_carries_its_own_parity_against_the_reference():
+    """VERDICT r1 #1: the column the bench prints is compared, in the same run, with the reference's own C on that column."""
+    p = load("r2_bench_line.json")["parity"]
+    assert p["kind"] == "reference" and p["ok"] is True
+    assert p["max_abs_flux_diff_w_m2"] <= p["tolerance_w_m2"] == 1e-3
+    assert p["max_tau_err_of_layer_max"] <= 2e-6
+    for k in ("max_tau_err_pointwise_rel", "max_transmission_err", "flux_diff_w_m2", "tau_lw", "tau_sw"):
+        assert k in p
+
+
+def test_bench_line_reports_solvers_fine_grids_and_the_unchanged_callers_rate():
+    line = load("r2_bench_line.json")
+    s = line["roofline_solvers"]
+    assert s["lw"]["avg_launch_ms"] > 0 and s["sw"]["avg_launch_ms"] > 0 and "valu_fp64" in s["bound"]
+    assert line["reference_order_columns_per_s"] > 0
+    assert line["reference_abi"]["fast0_columns_per_s"] > 0 and line["reference_abi"]["fast3_columns_per_s"] > 0
+    g3 = line["fine_grid"]["G3_lw_0.001cm-1"]
+    assert g3["n"] == 3249001 and g3["ran"]["tree_levels"] > 0 and g3["tree_vs_ring"]["max_diff_of_layer_max"] < 2e-6
+    assert line["fine_grid"]["G2_lw_0.1cm-1"]["n"] == 32491
+
+
+def test_strong_scaling_line():
+    line = load("r2_strong_20_columns_bench_line.json")
+    assert line["scaling"] == "strong" and line["config"]["columns_per_step"] == 20
+    assert abs(line["value"] - 20 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-9
