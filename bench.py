@@ -237,13 +237,22 @@ def main():
     import torch.distributed as dist
     from grtcode_amd import api, multi, workload as W
 
+    # GRT_BENCH_REHEARSAL=1: a logic rehearsal of the N > 1 path on a box with fewer GPUs than ranks -- ranks share the
+    # devices there are and the collectives go over gloo on host copies.  Timings of such a run mean nothing (the line
+    # says so); what it exercises is the sharding, the line-list cache hand-over, the padded gather and the barriers.
+    rehearsal = os.environ.get("GRT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     # GRT_BENCH_FORCE_DIST=1 exercises the RCCL path (init, stream-ordered gather, max-reduce) at world size 1
     force_dist = os.environ.get("GRT_BENCH_FORCE_DIST") == "1"
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     device = api.create_device(local_rank)
     if world > 1:
         # the line lists are drawn once (rank 0) and shared through a cache directory instead of once per rank
@@ -276,7 +285,10 @@ def main():
     def step():
         for lo, n, gc, _ in chunks:
             wl.pipe.run(gc, out.data_ptr() + lo * row_bytes)
-        if use_dist:
+        if use_dist and rehearsal:
+            wl.pipe.sync()
+            result["all"] = multi.gather_fluxes(out[:count].cpu(), rank, world, None, num_columns=total_per_step)
+        elif use_dist:
             with torch.cuda.stream(stream):      # RCCL gather ordered after the kernels, no host sync
                 result["all"] = multi.gather_fluxes(out[:count], rank, world, gathered, num_columns=total_per_step) if world > 1 \
                     else (dist.gather(out, gathered, dst=0), gathered[0])[1]
@@ -296,11 +308,17 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = multi.max_over_ranks(elapsed, torch.device("cuda", local_rank))
+    elapsed = multi.max_over_ranks(elapsed, torch.device("cpu") if rehearsal else torch.device("cuda", local_rank))
 
     if rank == 0:
         fluxes = out.cpu().numpy()
         assert np.all(np.isfinite(fluxes)), "non-finite integrated fluxes"
+        if world > 1:
+            # what the gather delivered: every column of the step, in order, this rank's own block first
+            allf = result["all"].cpu().numpy()
+            assert allf.shape == (total_per_step, api.GRT_FLUXES_PER_COLUMN), allf.shape
+            assert np.all(np.isfinite(allf)) and np.all(allf[:, 0] > 0.), "gathered fluxes incomplete"
+            assert np.array_equal(allf[:count], fluxes[:count])
         ms = {tag: api.profile_read(tag) for tag in (1, 2, 3, 4, 5, 6, 7)}
         L, V = W.NUM_LEVELS - 1, W.NUM_LEVELS
         n_lw, n_sw = wl.grid_lw.n, wl.grid_sw.n
@@ -334,7 +352,8 @@ def main():
         line = {
             "metric": "columns/sec (60-layer, 1 cm\u207b\u00b9 LBL, LW+SW)", "value": total_cols / elapsed, "unit": "columns/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            **({"rehearsal": "ranks share devices, gloo on host copies: timings are meaningless"} if rehearsal else {}), "dtype": "f64", "data": "synthetic",
             "config": {"workload": "SURVEY §8d grid G1: LW 1-3250 + SW 1-50000 cm-1 @1 cm-1, 60 layers, 7 absorbers, "
                                    f"{S['lw']} LW + {S['sw']} SW synthetic lines, H2O/O3 continua, 2 CFC, 3 CIA, clear sky, "
                                    "integrated fluxes",

@@ -1404,8 +1404,26 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
         }
         else
         {
-            hipLaunchKernelGGL(gas_optics_far_kernel, dim3((unsigned)tiles, a->lay.num_layers, a->ncol), dim3(kBlock),
-                               far_lds_bytes(a->tile, nacc, (int)fsteps, a->lay.num_slots, shift), s, b, fsteps, shift, nacc);
+            // The gather's workgroups own wider tiles than the first pass's cell tiles (each thread takes two grid points in
+            // turn): a workgroup's fixed costs -- staging the column state and the moments of 2 fsteps extra cells, the
+            // near-field radii of the cell tiles it touches, two barriers -- are shared by twice the points.
+            static int far_want = -1;           // GRT_FAR_TILE in the environment: exploration only
+            if (far_want < 0)
+            {
+                char const *env = getenv("GRT_FAR_TILE");
+                far_want = env != NULL && atoi(env) >= 64 ? atoi(env) : 512;      // measured on G1: 256 -> 0.99 ms, 512 -> 0.90, 1 024 -> 1.42 (occupancy)
+            }
+            int far_tile = a->tile;
+            while (2*far_tile <= far_want && (uint64_t)far_tile < a->nw
+                   && far_lds_bytes(2*far_tile, 2*far_tile + 2*(int)fsteps, (int)fsteps, a->lay.num_slots, shift) <= 64*1024)
+            {
+                far_tile *= 2;
+            }
+            b.tile = far_tile;
+            unsigned const far_tiles = (unsigned)((a->nw + far_tile - 1)/far_tile);
+            int const far_ncell = far_tile + 2*(int)fsteps;
+            hipLaunchKernelGGL(gas_optics_far_kernel, dim3(far_tiles, a->lay.num_layers, a->ncol), dim3(kBlock),
+                               far_lds_bytes(far_tile, far_ncell, (int)fsteps, a->lay.num_slots, shift), s, b, fsteps, shift, far_ncell);
         }
         if (a->profile_tag) grt_profile_end(stream, slot);
         return (int)hipGetLastError();

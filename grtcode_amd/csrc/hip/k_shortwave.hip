@@ -30,9 +30,14 @@ constexpr double kMaxExpArg = 700.;   // grtcode_config.h:41
 
 struct LayerRT { double R, T, Tpure; };
 
+// exp(+-t k) of the last Eddington solution of this layer: the direct-beam and the diffuse solution share k and, unless
+// one of them had its optical depth clamped (shortwave.c:137-145), t -- then the second call takes the first call's two
+// exponentials (same arguments, same values) instead of evaluating them again
+struct ExpKt { double t, tkp, tkm; bool valid; };
+
 // shortwave.c:97-207 (+ gamma definitions :226-230).  WITH_PURE mirrors T_pure != NULL.
 template <bool WITH_PURE>
-__device__ __forceinline__ LayerRT eddington(double omega, double tau, double mu, double g)
+__device__ __forceinline__ LayerRT eddington(double omega, double tau, double mu, double g, ExpKt &shared)
 {
     LayerRT r;
     double const gamma1 = 0.25*(7. - omega*(4. + 3.*g));
@@ -70,8 +75,21 @@ __device__ __forceinline__ LayerRT eddington(double omega, double tau, double mu
         else
         {
             double const tm = exp(-t/mu);
-            double const tkm = exp(-t*k);
-            double const tkp = exp(t*k);
+            double tkm, tkp;
+            if (shared.valid && shared.t == t)
+            {
+                tkm = shared.tkm;
+                tkp = shared.tkp;
+            }
+            else
+            {
+                tkm = exp(-t*k);
+                tkp = exp(t*k);
+                shared.t = t;
+                shared.tkm = tkm;
+                shared.tkp = tkp;
+                shared.valid = true;
+            }
             r.Tpure = tm;
             if (omega >= 1.)
             {
@@ -109,8 +127,9 @@ __device__ __forceinline__ LayerProps layer_props(double omega, double g, double
     double const f = g*g;
     double const os = (1. - f)*omega/(1. - omega*f);
     double const ts = tau*(1. - omega*f);
-    LayerRT const d = eddington<true>(os, ts, mu_dir, gs);
-    LayerRT const s = eddington<false>(os, ts, mu_dif, gs);
+    ExpKt shared = {0., 0., 0., false};
+    LayerRT const d = eddington<true>(os, ts, mu_dir, gs, shared);
+    LayerRT const s = eddington<false>(os, ts, mu_dif, gs, shared);
     LayerProps p;
     p.Rdir = d.R; p.Tdir = d.T; p.Tpure = d.Tpure; p.Rdif = s.R; p.Tdif = s.T;
     return p;
