@@ -3,9 +3,10 @@
 (2) CIRC cases 1-7, clear-sky LW+SW at 1 cm-1: the reference tree holds case 1 only (circ/src/circ1.h); cases 2-7
     need circ-case{2..7}.nc + netCDF, so they are case 1 plus six deterministic perturbations (temperature offsets,
     moisture and ozone scalings, a colder/drier and a warmer/wetter column, a different sun), run as ONE batch.
-(4) 1 800 columns = 100 columns x 18 replicas, sharded: on one GPU the property is that every replica of a column
-    returns the same fluxes wherever it sits in a chunk, and that rank shards tile the set (the N-rank gather itself
-    is covered on CPU by tests/test_multi_rank_gloo.py).
+(4) 1 800 columns = 100 columns x 18 replicas, sharded over 8 ranks with one gather: as stated (61 levels, LW + SW on
+    the full 1 cm-1 grids, production form) with 8 processes taking turns on the one GPU and the gather through the C
+    entry points' file transport (test_config4_...); plus the property that a column's fluxes do not depend on its
+    shard / chunk slot / neighbours.
 (5) ERA5-like: longwave at 0.1 cm-1, shortwave at 10 cm-1 (GRTworkflow/run-era5.sh), all 21 CFC species of
     cfcs.h:32-56 active.
 
@@ -160,6 +161,120 @@ def test_era5_like_fine_longwave_coarse_shortwave_all_cfcs(tmp_path, oracle, lib
             assert tau_close(tau_dev[ci], tau_gas) < 2e-6
             mine = got[ci, bi * 6: bi * 6 + 6][[0, 1, 3, 4]]
             assert np.max(np.abs(mine - integ)) < FLUX_TOL
+    pipe.destroy()
+    go_lw.destroy()
+    go_sw.destroy()
+
+
+# ---- config 4 as BASELINE.json states it, as far as one GPU allows ------------------------------------------------- #
+RANK_SCRIPT = r"""
+import os, sys
+import numpy as np
+root, tests = sys.argv[1], sys.argv[2]
+sys.path.insert(0, root); sys.path.insert(0, tests)
+os.environ["GRT_TIPS_QUIET"] = "1"
+rank, world, total, work = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+from grtcode_amd import api, multi, synthetic as syn
+from scenario import Band, MOL_ORDER
+from test_gpu_baseline_configs import replicated_column, CONFIG4
+V, chunk = CONFIG4["levels"], CONFIG4["chunk"]
+device = api.create_device(0)
+lwb = Band(os.path.join(work, f"rank{rank}", "lw"), 1.0, 3250.0, 1.0, CONFIG4["lines"], physical=True)      # same seed -> the same spectroscopy on every rank
+swb = Band(os.path.join(work, f"rank{rank}", "sw"), 1.0, 50000.0, 1.0, CONFIG4["lines"], sw=True, physical=True)
+go_lw, grid_lw = lwb.gas_optics(device, V, from_file=False)
+go_sw, grid_sw = swb.gas_optics(device, V, from_file=False)
+go_lw.tune(fast=3); go_sw.tune(fast=3)
+emis, alb = np.full(lwb.nw, 0.98), np.full(swb.nw, 0.2)
+solar = api.create_solar_flux(grid_sw, swb.files["solar"])
+pipe = api.Pipeline(go_lw, go_sw, chunk, -1, emis, alb, solar, spectral=False)       # the production pipeline
+m = multi.Multi(multi.FILES, device, rank, world, os.path.join(work, "rdv"))
+first, count = m.shard(total)
+local = np.zeros((count, 12))
+for lo in range(0, count, chunk):
+    part = [replicated_column(first + lo + k, V) for k in range(min(chunk, count - lo))]
+    gcols, keep = api.make_columns(part, MOL_ORDER, cfc_order=(0, 1))
+    pipe.run(gcols)
+    local[lo: lo + len(part)] = pipe.fluxes(len(part))
+per = -(-total // world)
+allf = np.zeros((per * world, 12)) if rank == 0 else None
+m.gather_fluxes(local.ctypes.data if count else 0, total, allf.ctypes.data if rank == 0 else 0, False)
+if rank == 0:
+    np.save(os.path.join(work, "gathered.npy"), allf[:total])
+m.destroy(); pipe.destroy(); go_lw.destroy(); go_sw.destroy()
+print("rank", rank, "columns", first, first + count)
+"""
+CONFIG4 = dict(levels=61, chunk=45, lines=8000, base=100, replicas=18)
+
+
+def replicated_column(index, V):
+    """Column `index` of the 1 800-column set: 100 RFMIP-like base columns x 18 replicas, each replica with its own
+    temperature perturbation (SURVEY §8d "Column sets"), replica-major as run-rfmip-irf.sh walks its experiments."""
+    replica, base = divmod(index, CONFIG4["base"])
+    c = syn.profile(base, V)
+    rng = np.random.default_rng(5000 + replica)
+    dt = rng.uniform(-3.0, 3.0)
+    c["t"] = c["t"] + dt
+    c["t_layer"] = c["t_layer"] + dt
+    c["t_surf"] = c["t_surf"] + dt
+    return c
+
+
+def test_config4_1800_replicated_columns_in_8_rank_shards_with_gather(tmp_path, oracle, lib, device):
+    """BASELINE config 4 -- 1 800 synthetic-replicated columns x 61 levels, LW + SW on the full 1 cm-1 grids, production
+    form, sharded over 8 ranks (225 columns each) with ONE gather of the [225][12] blocks to rank 0 -- run as far as one
+    GPU allows: 8 processes take turns on the card (at most 4 at a time), each its own shard through its own production
+    pipeline, and the blocks meet through the library's C entry points grt_multi_* with the file transport (RCCL wants
+    a GPU per rank: the driver's 8-GPU runs).  Rank 0's gathered array must hold every column, in order, equal to what a
+    single process computes, and within 1e-3 W m-2 of the CPU checker on sampled columns."""
+    import os
+    import subprocess
+    import sys
+    from oracle import reference_column as RC
+    from scenario import full_column
+    world, total = 8, CONFIG4["base"] * CONFIG4["replicas"]
+    assert total == 1800 and [multi.shard(total, r, world)[1] for r in range(world)] == [225] * 8
+    script = tmp_path / "rank.py"
+    script.write_text(RANK_SCRIPT)
+    (tmp_path / "rdv").mkdir()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = [sys.executable, str(script), root, os.path.join(root, "tests")]
+    env = dict(os.environ, GRT_MULTI_TIMEOUT="900")
+    for wave in ([7, 6, 5, 4], [3, 2, 1, 0]):                       # rank 0 (which waits for everybody's file) in the last wave
+        procs = [subprocess.Popen(args + [str(r), str(world), str(total), str(tmp_path)], stdout=subprocess.PIPE,
+                                  stderr=subprocess.PIPE, text=True, env=env) for r in wave]
+        for r, p in zip(wave, procs):
+            out, err = p.communicate(timeout=900)
+            assert p.returncode == 0, (r, out[-500:], err[-2000:])
+    got = np.load(str(tmp_path / "gathered.npy"))
+    assert got.shape == (total, 12) and np.all(np.isfinite(got)) and np.all(got[:, 0] > 100.0) and np.all(got[:, 10] > 100.0)
+    # replicas of a base column differ (their own temperatures) ...
+    per_base = got.reshape(CONFIG4["replicas"], CONFIG4["base"], 12)
+    assert np.all(np.ptp(per_base[:, :, 0], axis=0) > 1e-3)
+    # ... and every gathered row is the column it should be: sampled rows across all eight shards against one process
+    V = CONFIG4["levels"]
+    lwb = Band(str(tmp_path / "lw"), 1.0, 3250.0, 1.0, CONFIG4["lines"], physical=True)
+    swb = Band(str(tmp_path / "sw"), 1.0, 50000.0, 1.0, CONFIG4["lines"], sw=True, physical=True)
+    go_lw, grid_lw = lwb.gas_optics(device, V, from_file=False)
+    go_sw, grid_sw = swb.gas_optics(device, V, from_file=False)
+    go_lw.tune(fast=3)
+    go_sw.tune(fast=3)
+    emis, alb = np.full(lwb.nw, 0.98), np.full(swb.nw, 0.2)
+    solar = api.create_solar_flux(grid_sw, swb.files["solar"])
+    sample = [0, 224, 225, 449, 700, 1012, 1349, 1574, 1575, 1799]
+    pipe = api.Pipeline(go_lw, go_sw, len(sample), -1, emis, alb, solar, spectral=False)
+    gcols, keep = api.make_columns([replicated_column(i, V) for i in sample], MOL_ORDER, cfc_order=(0, 1))
+    pipe.run(gcols)
+    one = pipe.fluxes(len(sample))
+    assert np.max(np.abs(one - got[sample])) < 1e-6                 # (atomics: run-to-run ~1e-9)
+    kind, chk, orc = RC.checker(omp=True)
+    worst = 0.0
+    for i in (224, 1575):
+        col = replicated_column(i, V)
+        for bi, (band, lw) in enumerate(((lwb, True), (swb, False))):
+            w = full_column(kind, chk, orc, lib, band, col, lw, emis, alb, solar)
+            worst = max(worst, np.max(np.abs(got[i, bi * 6: bi * 6 + 6] - w["integ"])))
+    print(f"config 4: 1 800 columns in 8 rank shards, gathered; worst flux difference on sampled columns {worst:.2e} W m-2 ({kind})")
+    assert worst < 1e-3
     pipe.destroy()
     go_lw.destroy()
     go_sw.destroy()
