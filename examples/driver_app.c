@@ -9,7 +9,7 @@
  *
  *   grtcode_driver HITRAN.par SOLAR.csv COLUMNS.txt [-H2O -CO2 -O3 -N2O -CO -CH4 -O2]
  *       [-h2o-ctm DIR] [-o3-ctm FILE] [-CFC-11 FILE] [-CFC-12 FILE] [-N2-N2 FILE] [-O2-N2 FILE] [-O2-O2 FILE]
- *       [-a ALBEDO] [-e EMISSIVITY] [-x FIRST] [-X LAST]
+ *       [-a ALBEDO] [-e EMISSIVITY] [-x FIRST] [-X LAST] [-aerosols]
  *       + driver.c's own options (-d, -r-lw, -r-sw, -w-lw, -W-lw, -w-sw, -W-sw, -integrated, -flux-at-level, -o, -v)
  *
  * COLUMNS.txt: one or more columns, each a block of lines "name: v0 v1 ..." opened by a line "column:" --
@@ -19,7 +19,10 @@
  * Column semantics are those of circ/src/basic-circ-test.c: level abundances pressure-interpolated from the
  * layer values (:51-66), cos(zenith) (:118-120), irradiance divided by it (:122-124), two-point constant
  * albedo / emissivity grids (:127-137, :147-153; emissivity 1 unless -e), N2 at 0.781 for the CIA pairs (:270-277).
- * Clear and clean sky only (no cloud / aerosol inputs exist in this format).
+ * Clear sky only (no cloud inputs exist in this format; a cloudy run would need the reference's clouds library).
+ * -aerosols makes the driver also run its aerosol pass (driver.c:426-472: clean = 0), whose optics the reference itself
+ * leaves at zero -- the body of calculate_aerosol_optics is commented out (driver.c:223-238) -- so the "clear-sky" fluxes
+ * it writes (rlutcs, ...) equal the "clear-clean-sky" ones (rlutcsaf, ...): the pass is plumbing, exercised as such.
  *
  * Output (-o PATH, default output.nc as driver.c names it -- but text): one line per write_output call,
  *   "<time> <column> <variable name> <count> v0 v1 ...", fluxes in W m-2 (or W m-2 cm with spectral output).
@@ -167,6 +170,7 @@ Atmosphere_t create_atmosphere(Parser_t * const parser)
     add_argument(parser, "-o3-ctm", NULL, "Ozone continuum file", &one);
     add_argument(parser, "-x", "--column-lower-bound", "Starting column index.", &one);
     add_argument(parser, "-X", "--column-upper-bound", "Ending column index.", &one);
+    add_argument(parser, "-aerosols", NULL, "Also run the driver's aerosol pass (with the reference's zero aerosol optics).", NULL);
     parse_args(*parser);
 
     char buffer[valuelen];
@@ -188,7 +192,7 @@ Atmosphere_t create_atmosphere(Parser_t * const parser)
     atm.num_times = 1;
     atm.num_levels = cols[0].num_levels;
     atm.num_layers = atm.num_levels - 1;
-    atm.clean = 1;
+    atm.clean = get_argument(*parser, "-aerosols", NULL) ? 0 : 1;
     atm.clear = 1;
     size_t const C = (size_t)atm.num_columns, V = (size_t)atm.num_levels, L = (size_t)atm.num_layers;
     atm.level_pressure = malloc(sizeof(fp_t)*C*V);
@@ -362,6 +366,17 @@ static char const *variable_name(Variables_t id)
         case RSDSCSAF: return "rsdscsaf";
         case RSUCSAF_USER_LEVEL: return "rsucsaf_user_level";
         case RSDCSAF_USER_LEVEL: return "rsdcsaf_user_level";
+        case RLUTCS: return "rlutcs";
+        case RLUSCS: return "rluscs";
+        case RLDSCS: return "rldscs";
+        case RLUCS_USER_LEVEL: return "rlucs_user_level";
+        case RLDCS_USER_LEVEL: return "rldcs_user_level";
+        case RSUTCS: return "rsutcs";
+        case RSUSCS: return "rsuscs";
+        case RSDTCS: return "rsdtcs";
+        case RSDSCS: return "rsdscs";
+        case RSUCS_USER_LEVEL: return "rsucs_user_level";
+        case RSDCS_USER_LEVEL: return "rsdcs_user_level";
         case LEVEL_PRESSURE: return "level_pressure";
         case LEVEL_TEMPERATURE: return "level_temperature";
         case LAYER_TEMPERATURE: return "layer_temperature";

@@ -135,6 +135,15 @@ def test_unchanged_reference_driver_main_matches_oracle(tmp_path, oracle, lib):
             assert np.allclose(got[(c, "h2o_vmr")], cols[c]["ppmv"][syn.H2O], rtol=1e-14)
         print(f"reference driver.c main(), {env or 'default (reference order)'}: worst integrated flux difference {worst:.2e} W m-2")
         assert worst < tol
+    # the driver's aerosol pass (driver.c:426-472, add_optics of THREE objects): the reference's own aerosol optics are
+    # zero (the body of calculate_aerosol_optics is commented out, driver.c:223-238), so its clear-sky fluxes must equal
+    # the clear-clean-sky ones of the same run
+    got = run(["-integrated", "-aerosols"], {}, "aerosols.txt")
+    for c in range(2):
+        for name, band, k in names:
+            with_aerosols = got[(c, name.replace("csaf", "cs"))]
+            assert with_aerosols.size == 1 and with_aerosols[0] == got[(c, name)][0], (c, name)
+            assert abs(got[(c, name)][0] - want[c][band]["integ"][k]) < 1e-6
     # one column only (-x/-X as run-rfmip-irf.sh shards: GRTworkflow/run-rfmip-irf.sh:121-122), spectral output
     got = run(["-x", "1", "-X", "1"], {}, "spectral.txt")
     w = want[1]
