@@ -278,3 +278,77 @@ def test_config4_1800_replicated_columns_in_8_rank_shards_with_gather(tmp_path, 
     pipe.destroy()
     go_lw.destroy()
     go_sw.destroy()
+
+
+def test_config5_era5_like_two_thousand_columns_full_grids_all_cfcs(tmp_path, oracle, lib, device):
+    """BASELINE config 5 at a size one GPU does in seconds: 2 048 columns (O(10^3) of the O(10^4)), longwave 1-3250 cm-1
+    at 0.1 cm-1 (n = 32 491: the tree form of the line kernel), shortwave 1-50 000 cm-1 at 10 cm-1 (7-point windows: the
+    direct-walk form), all 21 CFC/HCFC species of cfcs.h:32-56, 3 CIA pairs, production pipeline in chunks of 128;
+    sampled columns against the CPU checker."""
+    import os
+    from oracle import reference_column as RC
+    kind, chk, orc = RC.checker(omp=True)
+    RC.set_omp_threads(min(os.cpu_count() or 1, 16))
+    V, ncfc, ncol, chunk = 31, 21, 2048, 128
+    lwb = Band(str(tmp_path / "lw"), 1.0, 3250.0, 0.1, 6000, physical=True)
+    swb = Band(str(tmp_path / "sw"), 1.0, 50000.0, 10.0, 6000, sw=True, physical=True)
+
+    def column(c):
+        col = syn.profile(c, V)
+        col["cfc_ppmv"] = {k: np.full(V, 0.5e-4 * (1 + k) * (1.0 + 0.1 * (c % 7))) for k in range(ncfc)}
+        return col
+
+    def build(band):
+        grid = api.create_spectral_grid(band.w0, band.wn, band.dw)
+        go = api.GasOpticsObject(V, grid, device, band.par, band.h2o_dir, band.files["o3_ctm"])
+        for m in band.mols:
+            go.add_molecule_lines(m, band.lines[m])
+        for k in range(ncfc):
+            go.add_cfc(k, band.files["cfc11" if k % 2 == 0 else "cfc12"])
+        for a, b, name in ((0, 0, "cia_n2n2"), (1, 0, "cia_o2n2"), (1, 1, "cia_o2o2")):
+            go.add_cia(a, b, band.files[name])
+        go.tune(fast=3)
+        return go, grid
+
+    go_lw, grid_lw = build(lwb)
+    go_sw, grid_sw = build(swb)
+    assert grid_lw.n == 32491 and grid_sw.n == 5001
+    emis, alb = np.full(lwb.nw, 0.98), np.full(swb.nw, 0.2)
+    solar = api.create_solar_flux(grid_sw, swb.files["solar"])
+    pipe = api.Pipeline(go_lw, go_sw, chunk, -1, emis, alb, solar, spectral=False)
+    got = np.zeros((ncol, api.GRT_FLUXES_PER_COLUMN))
+    for first in range(0, ncol, chunk):
+        part = [column(c) for c in range(first, first + chunk)]
+        gcols, keep = api.make_columns(part, MOL_ORDER, cfc_order=tuple(range(ncfc)))
+        pipe.run(gcols)
+        got[first: first + chunk] = pipe.fluxes(chunk)
+    info = go_lw.last_launch()
+    assert info["fast"] == 3 and info["tree_levels"] > 0               # the cell hierarchy carried the 0.1 cm-1 longwave
+    assert np.all(np.isfinite(got)) and np.all(got[:, 0] > 100.0) and np.all(got[:, 10] > 100.0)
+    worst = 0.0
+    for c in (0, 777, 2047):
+        col = column(c)
+        for bi, (band, lw) in enumerate(((lwb, True), (swb, False))):
+            kw = band.oracle_inputs(orc, lib, col)
+            kw["cfcs"] = [(col["cfc_ppmv"][k] * 1e-6, band.table_on_grid(orc, "cfc11" if k % 2 == 0 else "cfc12")) for k in range(ncfc)]
+            tau_gas = chk.gas_optics(col["p"], col["t"], band.w0, band.dw, band.nw, **kw)
+            L = V - 1
+            z = np.zeros_like(tau_gas)
+            if kind == "reference":
+                g = chk.grid(band.w0, band.wn, band.dw)
+                tr, om_r, g_r = chk.rayleigh(g, L, col["p"])
+                tau, omega, gg = chk.add_optics(g, [tau_gas, tr], [z, om_r], [z, g_r])
+                up, dn = (chk.lw_fluxes(g, col["t_surf"], col["t_layer"], col["t"], tau, omega, emis) if lw else
+                          chk.sw_fluxes(g, omega, gg, tau, col["mu0"], 0.5, alb, alb, col["tsi"], solar))
+            else:
+                tr, om_r, g_r = chk.rayleigh(L, col["p"], band.w0, band.dw, band.nw)
+                tau, omega, gg = chk.add_optics([tau_gas, tr], [z, om_r], [z, g_r])
+                up, dn = (chk.lw_fluxes(band.w0, band.dw, col["t_surf"], col["t_layer"], col["t"], tau, omega, emis) if lw else
+                          chk.sw_fluxes(omega, gg, tau, col["mu0"], 0.5, alb, alb, col["tsi"], solar))
+            integ = np.array([orc.integrate_row(r, band.dw) for r in (up[0], up[-1], dn[0], dn[-1])])
+            worst = max(worst, np.max(np.abs(got[c, bi * 6: bi * 6 + 6][[0, 1, 3, 4]] - integ)))
+    print(f"config 5 (ERA5-like, {ncol} columns, LW @0.1 + SW @10 cm-1, 21 CFCs): worst flux difference on sampled columns {worst:.2e} W m-2 ({kind})")
+    assert worst < 1e-3
+    pipe.destroy()
+    go_lw.destroy()
+    go_sw.destroy()
