@@ -211,3 +211,35 @@ def test_full_3m_point_grid_tree_equals_ring(device):
     assert info["fast"] == 3 and info["tree_levels"] == 12 and info["moments"] == 12, info
     assert np.all(np.isfinite(tree)) and tree.min() >= 0.0
     assert tau_close(tree, ring) < BETWEEN_TOL
+
+
+def test_full_3m_point_grid_against_the_reference_c(tmp_path, lib, device):
+    """The same grid at full width (n = 3 249 001, windows of 50 001 points) against the REFERENCE'S OWN C -- not a
+    self-comparison: a line list thin enough for the CPU (16 000 lines x 4 layers x 50 001 points = 3.2e9 line-shape
+    evaluations: seconds with OpenMP) still sends the production form down its sparse-line branch -- tiles of 1 024
+    cells and more, twelve moments added straight to global memory, twelve coarse levels -- which is the branch the
+    10^6-line column takes too (0.3 lines per cell there)."""
+    import os
+    from oracle import reference_column as RC
+    from scenario import Band
+    kind, chk, orc = RC.checker(omp=True)
+    RC.set_omp_threads(min(os.cpu_count() or 1, 16))
+    V = 5
+    band = Band(str(tmp_path), 1.0, 3250.0, 0.001, 16000, physical=True)
+    assert band.nw == 3249001
+    col = syn.profile(7, V)
+    go, grid = band.gas_optics(device, V, from_file=False)
+    band.set_column(go, col)
+    go.tune(fast=3)
+    opt = api.OpticsObject(V - 1, grid, device)
+    go.calculate_optical_depth(col["p"], col["t"], opt)
+    tau = opt.read()[0]
+    info = go.last_launch()
+    assert info["fast"] == 3 and info["tree_levels"] == 12 and info["moments"] == 12 and info["tile"] >= 1024, info
+    want = band.oracle_tau(chk, orc, lib, col)
+    from oracle.reference_column import tau_metrics
+    m = tau_metrics(tau, want)
+    print(f"G3 grid, full width, 16 000 lines x 4 layers, tree form vs {kind}: {m}")
+    assert m["of_layer_max"] < 2e-6 and m["transmission"] < 4e-5
+    opt.destroy()
+    go.destroy()
