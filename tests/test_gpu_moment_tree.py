@@ -223,6 +223,8 @@ def test_full_3m_point_grid_against_the_reference_c(tmp_path, lib, device):
     from oracle import reference_column as RC
     from scenario import Band
     kind, chk, orc = RC.checker(omp=True)
+    if kind != "reference":
+        pytest.skip("needs the prebuilt reference library oracle/_ref/libgrtref_omp.so (3.2e9 evaluations: a minute for the scalar restatement)")
     RC.set_omp_threads(min(os.cpu_count() or 1, 16))
     V = 5
     band = Band(str(tmp_path), 1.0, 3250.0, 0.001, 16000, physical=True)

@@ -49,6 +49,9 @@ def record(name, payload):
 def test_full_g1_column_against_reference(lib, device, physical):
     """One column of the bench workload at FULL size, LW + SW, production form and reference-order form."""
     kind, chk, orc = RC.checker(omp=True)
+    if kind != "reference":
+        pytest.skip("needs the prebuilt reference library oracle/_ref/libgrtref_omp.so: the scalar restatement would take "
+                    "minutes for 7.7e9 line-shape evaluations (bench.py makes the same comparison for its column 0)")
     RC.set_omp_threads(min(os.cpu_count() or 1, 16))
     wl = W.G1Workload(device, 1, physical=physical, spectral=True)
     col = syn.profile(0, W.NUM_LEVELS)
