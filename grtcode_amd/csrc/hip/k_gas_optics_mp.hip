@@ -33,6 +33,9 @@
 namespace {
 
 constexpr int kMom = 8;         // moments per cell
+#ifndef GRT_FAR_GRADED_MIN
+#define GRT_FAR_GRADED_MIN 64   // single-level gather: windows wider than this many points a side take fewer terms for far cells
+#endif
 constexpr int kMomWide = 12;    // ... of the tree form on sparse lines (args.mom_terms)
 
 // The series is geometric in |z|/r: K terms leave (|z|/r)^K.  Near field out to r = sep |z|max keeps that at 7e-8.
@@ -901,7 +904,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_far_kernel(GrtGasOpticsArgs
     {
         rk[k] = fsteps + 1;
     }
-    if (fsteps > 64)
+    if (fsteps > GRT_FAR_GRADED_MIN)
     {
         bool um, cr;
         double zmax;
