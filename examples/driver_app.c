@@ -9,7 +9,7 @@
  *
  *   grtcode_driver HITRAN.par SOLAR.csv COLUMNS.txt [-H2O -CO2 -O3 -N2O -CO -CH4 -O2]
  *       [-h2o-ctm DIR] [-o3-ctm FILE] [-CFC-11 FILE] [-CFC-12 FILE] [-N2-N2 FILE] [-O2-N2 FILE] [-O2-O2 FILE]
- *       [-a ALBEDO] [-e EMISSIVITY] [-x FIRST] [-X LAST] [-aerosols]
+ *       [-a ALBEDO] [-e EMISSIVITY] [-x FIRST] [-X LAST] [-aerosols] [-clouds]
  *       + driver.c's own options (-d, -r-lw, -r-sw, -w-lw, -W-lw, -w-sw, -W-sw, -integrated, -flux-at-level, -o, -v)
  *
  * COLUMNS.txt: one or more columns, each a block of lines "name: v0 v1 ..." opened by a line "column:" --
@@ -19,7 +19,11 @@
  * Column semantics are those of circ/src/basic-circ-test.c: level abundances pressure-interpolated from the
  * layer values (:51-66), cos(zenith) (:118-120), irradiance divided by it (:122-124), two-point constant
  * albedo / emissivity grids (:127-137, :147-153; emissivity 1 unless -e), N2 at 0.781 for the CIA pairs (:270-277).
- * Clear sky only (no cloud inputs exist in this format; a cloudy run would need the reference's clouds library).
+ * -clouds makes the driver run its cloud pass too (driver.c:474-597: clear = 0) with the optional per-layer fields
+ *   cloud_fraction, liquid_water_content [g m-3], ice_water_content [g m-3] of the column file (zero when absent) and
+ *   layer thicknesses from the hydrostatic relation of basic-circ-test.c:155-166.  That pass calls a clouds library
+ *   (clouds/clouds_lib.h) -- libclouds.a of THIS repository only stops the run; link the reference's, or any object with
+ *   those four functions -- and fills Optics_t arrays in place on the host: run with GRT_OPTICS_HOST_VISIBLE=1.
  * -aerosols makes the driver also run its aerosol pass (driver.c:426-472: clean = 0), whose optics the reference itself
  * leaves at zero -- the body of calculate_aerosol_optics is commented out (driver.c:223-238) -- so the "clear-sky" fluxes
  * it writes (rlutcs, ...) equal the "clear-clean-sky" ones (rlutcsaf, ...): the pass is plumbing, exercised as such.
@@ -53,6 +57,7 @@ typedef struct Column
     fp_t level_pressure[MAXV], level_temperature[MAXV], layer_pressure[MAXV], layer_temperature[MAXV];
     fp_t surface_temperature, solar_zenith_angle, toa_solar_irradiance;
     fp_t abundance[NSPEC][MAXV];
+    fp_t cloud_fraction[MAXV], liquid_water_content[MAXV], ice_water_content[MAXV];
 } Column_t;
 
 static void die(char const *what, char const *arg)
@@ -108,6 +113,9 @@ static Column_t *read_columns(char const *path, int *count)
         else if (strcmp(line, "surface_temperature") == 0) read_values(vals, &c->surface_temperature, 1);
         else if (strcmp(line, "solar_zenith_angle") == 0) read_values(vals, &c->solar_zenith_angle, 1);
         else if (strcmp(line, "toa_solar_irradiance") == 0) read_values(vals, &c->toa_solar_irradiance, 1);
+        else if (strcmp(line, "cloud_fraction") == 0) read_values(vals, c->cloud_fraction, MAXV);
+        else if (strcmp(line, "liquid_water_content") == 0) read_values(vals, c->liquid_water_content, MAXV);
+        else if (strcmp(line, "ice_water_content") == 0) read_values(vals, c->ice_water_content, MAXV);
         else
         {
             for (int k = 0; k < NSPEC; ++k)
@@ -171,6 +179,7 @@ Atmosphere_t create_atmosphere(Parser_t * const parser)
     add_argument(parser, "-x", "--column-lower-bound", "Starting column index.", &one);
     add_argument(parser, "-X", "--column-upper-bound", "Ending column index.", &one);
     add_argument(parser, "-aerosols", NULL, "Also run the driver's aerosol pass (with the reference's zero aerosol optics).", NULL);
+    add_argument(parser, "-clouds", NULL, "Also run the driver's cloud pass (needs a clouds library and GRT_OPTICS_HOST_VISIBLE=1).", NULL);
     parse_args(*parser);
 
     char buffer[valuelen];
@@ -193,7 +202,7 @@ Atmosphere_t create_atmosphere(Parser_t * const parser)
     atm.num_levels = cols[0].num_levels;
     atm.num_layers = atm.num_levels - 1;
     atm.clean = get_argument(*parser, "-aerosols", NULL) ? 0 : 1;
-    atm.clear = 1;
+    atm.clear = get_argument(*parser, "-clouds", NULL) ? 0 : 1;
     size_t const C = (size_t)atm.num_columns, V = (size_t)atm.num_levels, L = (size_t)atm.num_layers;
     atm.level_pressure = malloc(sizeof(fp_t)*C*V);
     atm.level_temperature = malloc(sizeof(fp_t)*C*V);
@@ -214,6 +223,27 @@ Atmosphere_t create_atmosphere(Parser_t * const parser)
     atm.emissivity_grid[0] = -1.;
     atm.emissivity_grid[1] = 0.;
     atm.surface_emissivity = malloc(sizeof(fp_t)*2*C);
+    if (!atm.clear)
+    {
+        atm.cloud_fraction = malloc(sizeof(fp_t)*C*L);
+        atm.liquid_water_content = malloc(sizeof(fp_t)*C*L);
+        atm.ice_water_content = malloc(sizeof(fp_t)*C*L);
+        atm.layer_thickness = malloc(sizeof(fp_t)*C*L);
+        for (size_t c = 0; c < C; ++c)
+        {
+            Column_t const *col = &cols[x + (int)c];
+            memcpy(atm.cloud_fraction + c*L, col->cloud_fraction, sizeof(fp_t)*L);
+            memcpy(atm.liquid_water_content + c*L, col->liquid_water_content, sizeof(fp_t)*L);
+            memcpy(atm.ice_water_content + c*L, col->ice_water_content, sizeof(fp_t)*L);
+            for (size_t i = 0; i < L; ++i)
+            {
+                /* basic-circ-test.c:155-166 */
+                fp_t const gas_constant = 8.314462, gravity = 9.81, kg_per_g = .001, molar_mass = 28.9647;
+                atm.layer_thickness[c*L + i] = (fabs(log(col->level_pressure[i]) - log(col->level_pressure[i + 1]))*
+                                               col->layer_temperature[i]*gas_constant)/(molar_mass*kg_per_g*gravity);
+            }
+        }
+    }
     for (size_t c = 0; c < C; ++c)
     {
         Column_t const *col = &cols[x + (int)c];
@@ -322,6 +352,7 @@ void destroy_atmosphere(Atmosphere_t *atm)
     free(atm->layer_temperature); free(atm->surface_temperature); free(atm->solar_zenith_angle);
     free(atm->total_solar_irradiance); free(atm->albedo_grid); free(atm->surface_albedo);
     free(atm->emissivity_grid); free(atm->surface_emissivity);
+    free(atm->cloud_fraction); free(atm->liquid_water_content); free(atm->ice_water_content); free(atm->layer_thickness);
     for (int i = 0; i < atm->num_molecules; ++i) free(atm->ppmv[i]);
     for (int i = 0; i < atm->num_cfcs; ++i) free(atm->cfc_ppmv[i]);
     for (int i = 0; i < atm->num_cia_species; ++i) free(atm->cia_ppmv[i]);
@@ -366,6 +397,17 @@ static char const *variable_name(Variables_t id)
         case RSDSCSAF: return "rsdscsaf";
         case RSUCSAF_USER_LEVEL: return "rsucsaf_user_level";
         case RSDCSAF_USER_LEVEL: return "rsdcsaf_user_level";
+        case RLUTAF: return "rlutaf";
+        case RLUSAF: return "rlusaf";
+        case RLDSAF: return "rldsaf";
+        case RLUAF_USER_LEVEL: return "rluaf_user_level";
+        case RLDAF_USER_LEVEL: return "rldaf_user_level";
+        case RSUTAF: return "rsutaf";
+        case RSUSAF: return "rsusaf";
+        case RSDTAF: return "rsdtaf";
+        case RSDSAF: return "rsdsaf";
+        case RSUAF_USER_LEVEL: return "rsuaf_user_level";
+        case RSDAF_USER_LEVEL: return "rsdaf_user_level";
         case RLUTCS: return "rlutcs";
         case RLUSCS: return "rluscs";
         case RLDSCS: return "rldscs";

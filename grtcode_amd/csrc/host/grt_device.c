@@ -199,6 +199,38 @@ int grt_dev_event_destroy(Device_t device, void **ev)
     return GRTCODE_SUCCESS;
 }
 
+/* Host memory the device reads and writes through the same pointer (fine-grained, over the host link): for
+   Optics_t arrays that a caller fills IN PLACE on the host -- the cloud pass of framework/src/driver.c:474-597 does
+   (cloud_optics writes optics_liquid_cloud.tau/omega/g, :514-525 scale them by the layer thickness). */
+int grt_dev_alloc_host_visible(Device_t device, void **p, size_t bytes)
+{
+    GRT_REQUIRE_PTR(p);
+    GRT_TRY(grt_dev_require(device));
+    *p = NULL;
+    GRT_TRY(grt_dev_check((int)hipHostMalloc(p, bytes ? bytes : 8, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc"));
+    return GRTCODE_SUCCESS;
+}
+
+/* hipFree or hipHostFree, whichever the block came from */
+int grt_dev_free_any(Device_t device, void *p)
+{
+    if (p == NULL)
+    {
+        return GRTCODE_SUCCESS;
+    }
+    GRT_TRY(grt_dev_require(device));
+    hipPointerAttribute_t attr;
+    memset(&attr, 0, sizeof(attr));
+    if (hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type == hipMemoryTypeHost)
+    {
+        GRT_TRY(grt_dev_check((int)hipHostFree(p), "hipHostFree"));
+        return GRTCODE_SUCCESS;
+    }
+    (void)hipGetLastError();
+    GRT_TRY(grt_dev_check((int)hipFree(p), "hipFree"));
+    return GRTCODE_SUCCESS;
+}
+
 int grt_host_alloc_pinned(void **p, size_t bytes)
 {
     GRT_REQUIRE_PTR(p);

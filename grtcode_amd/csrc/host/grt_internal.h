@@ -45,6 +45,8 @@ void grt_log(int level, char const *file, int line, char const *fmt, ...);
 int grt_dev_require(Device_t device);                   /* GPU ordinal check; HOST_ONLY refused */
 int grt_dev_alloc(Device_t device, void **p, size_t bytes);
 int grt_dev_free(Device_t device, void *p);
+int grt_dev_alloc_host_visible(Device_t device, void **p, size_t bytes);   /* host memory the device reads/writes in place */
+int grt_dev_free_any(Device_t device, void *p);                            /* block from either allocator */
 int grt_dev_zero(Device_t device, void *p, size_t bytes, void *stream);
 int grt_dev_upload(Device_t device, void *dst, void const *src, size_t bytes, void *stream);
 int grt_dev_download(Device_t device, void *dst, void const *src, size_t bytes, void *stream);

@@ -2,11 +2,16 @@
  * Contract: utilities/src/optics.h:30-87 (optics.c:84-357).  The arrays are device
  * memory; add_optics allocates `result` (caller destroys it) but, unlike the
  * reference, stages no temporary copies: the kernel reads the K inputs in place. */
+#include <stdlib.h>
 #include <string.h>
 #include "grt_internal.h"
 
-EXTERN int create_optics(Optics_t * const optics, int const num_layers,
-                         SpectralGrid_t const * const grid, Device_t const * const device)
+/* host_visible: the arrays live in host memory that the device reads and writes through the same pointers, so a
+   caller may fill them in place -- what GRT_OPTICS_HOST_VISIBLE=1 asks of create_optics for a cloudy driver run
+   (driver.c:507-525 writes the cloud objects' tau/omega/g on the host).  Slower for the kernels (host link instead of
+   HBM); results of add_optics are always device memory. */
+static int create_optics_in(Optics_t * const optics, int const num_layers, SpectralGrid_t const * const grid,
+                            Device_t const * const device, int host_visible)
 {
     GRT_REQUIRE_PTR(optics);
     GRT_REQUIRE_PTR(grid);
@@ -21,20 +26,37 @@ EXTERN int create_optics(Optics_t * const optics, int const num_layers,
     void *s = grt_dev_stream(*device);
     /* one allocation, three rows-of-rows: keeps the triple adjacent in HBM */
     void *block = NULL;
-    GRT_TRY(grt_dev_alloc(*device, &block, 3*bytes));
+    if (host_visible)
+    {
+        GRT_TRY(grt_dev_alloc_host_visible(*device, &block, 3*bytes));
+    }
+    else
+    {
+        GRT_TRY(grt_dev_alloc(*device, &block, 3*bytes));
+    }
     GRT_TRY(grt_dev_zero(*device, block, 3*bytes, s));          /* optics.c:194-199 */
     GRT_TRY(grt_dev_sync(*device, s));
     optics->tau = (fp_t *)block;
     optics->omega = optics->tau + (size_t)num_layers*grid->n;
     optics->g = optics->omega + (size_t)num_layers*grid->n;
-    GRT_INFO("Optics object on device %d: %d layers x %zu points", *device, num_layers, (size_t)grid->n);
+    GRT_INFO("Optics object on device %d: %d layers x %zu points%s", *device, num_layers, (size_t)grid->n,
+             host_visible ? " (host-visible)" : "");
+    return GRTCODE_SUCCESS;
+}
+
+/* optics.h:43-50 (optics.c:178-200) */
+EXTERN int create_optics(Optics_t * const optics, int const num_layers,
+                         SpectralGrid_t const * const grid, Device_t const * const device)
+{
+    char const *env = getenv("GRT_OPTICS_HOST_VISIBLE");
+    GRT_TRY(create_optics_in(optics, num_layers, grid, device, env != NULL && env[0] == '1'));
     return GRTCODE_SUCCESS;
 }
 
 EXTERN int destroy_optics(Optics_t * const optics)
 {
     GRT_REQUIRE_PTR(optics);
-    GRT_TRY(grt_dev_free(optics->device, optics->tau));         /* base of the single block */
+    GRT_TRY(grt_dev_free_any(optics->device, optics->tau));     /* base of the single block */
     optics->g = optics->omega = optics->tau = NULL;
     return GRTCODE_SUCCESS;
 }
@@ -76,7 +98,7 @@ EXTERN int add_optics(Optics_t const * const * const optics, int const num_optic
         in.omega[j] = optics[j]->omega;
         in.g[j] = optics[j]->g;
     }
-    GRT_TRY(create_optics(result, first->num_layers, &first->grid, &first->device));
+    GRT_TRY(create_optics_in(result, first->num_layers, &first->grid, &first->device, 0));
     void *s = grt_dev_stream(first->device);
     uint64_t const n = (uint64_t)first->num_layers*first->grid.n;
     GRT_TRY(grt_dev_check(grt_launch_add_optics(s, n, num_optics, &in, result->tau, result->omega,

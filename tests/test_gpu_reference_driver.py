@@ -153,3 +153,87 @@ def test_unchanged_reference_driver_main_matches_oracle(tmp_path, oracle, lib):
     assert np.max(np.abs(got[(0, "rsdscsaf")] - w[1]["dn"][-1])) < 1e-10 * np.abs(w[1]["dn"]).max()
     assert np.max(np.abs(got[(0, "rsutcsaf")] - w[1]["up"][0])) < 1e-10 * np.abs(w[1]["dn"]).max()
     assert np.max(np.abs(got[(0, "rlucsaf_user_level")] - w[0]["up"][user_level])) < 1e-10 * np.abs(w[0]["up"]).max()
+
+
+CLOUDS = os.path.join(ROOT, "oracle", "_ref", "grtcode_driver_clouds_double")
+
+
+def cloud_double(band_limits, L, cf, lwc, iwc, r_liq, t_layer):
+    """tests/support/clouds_double.c in numpy: extinction [1/m], single-scattering albedo, asymmetry per (layer, band)."""
+    w = 0.5 * (band_limits[:-1] + band_limits[1:])[None, :]
+    r_ice = np.where(t_layer > 250.0, 50.0, 25.0)[:, None]
+    cf, lwc, iwc = cf[:, None], lwc[:, None], iwc[:, None]
+    liq = (cf * lwc * 1.5e-3 / r_liq * (1.0 + 0.2 * np.exp(-w / 3000.0)), 0.5 + 0.499 * (1.0 - np.exp(-w / 2500.0)) + 0 * cf,
+           0.80 + 0.07 * np.exp(-w / 8000.0) + 0 * cf)
+    ice = (cf * iwc * 1.2e-3 / r_ice * (1.0 + 0.1 * np.exp(-w / 5000.0)), 0.45 + 0.5 * (1.0 - np.exp(-w / 3500.0)) + 0 * cf,
+           0.75 + 0.1 * np.exp(-w / 10000.0) + 0 * cf)
+    return liq, ice
+
+
+@pytest.mark.skipif(not os.path.exists(CLOUDS), reason="oracle/_ref/grtcode_driver_clouds_double not built (needs /root/reference at build time)")
+@pytest.mark.gpu
+def test_reference_driver_cloud_pass_through_the_library(tmp_path, oracle, lib):
+    """SURVEY §8(f)-4, the part that can exist without the reference's netCDF cloud tables: the UNCHANGED driver's cloud
+    pass (driver.c:474-597) -- band limits, cloud_optics() filling the liquid / ice Optics_t arrays IN PLACE on the host,
+    the thickness scaling of :514-525, add_optics of FOUR objects, the all-sky flux outputs -- runs through this library
+    when create_optics hands out host-visible arrays (GRT_OPTICS_HOST_VISIBLE=1).  The clouds library itself is a test
+    double with closed-form optics (tests/support/clouds_double.c); the oracle gets the same optics from numpy."""
+    col1, v1 = circ1_column()
+    L = col1["p"].size - 1
+    cf, lwc, iwc = np.zeros(L), np.zeros(L), np.zeros(L)
+    cf[38:44], lwc[38:44] = 0.6, 0.2                 # a liquid layer low down (T > 250 K) ...
+    cf[14:19], iwc[14:19] = 0.4, 0.05                # ... and an ice layer aloft
+    swb = Band(str(tmp_path / "data"), 1.0, 8000.0, 2.0, 8000, sw=True)
+    lwb = Band(str(tmp_path / "lw_view"), 1.0, 2000.0, 1.0, 0, sw=True)
+    lwb.par, lwb.h2o_dir, lwb.files, lwb.tab = swb.par, swb.h2o_dir, swb.files, swb.tab
+    lwb.lines = {m: {k: a[(ln["v0"] >= lwb.w0) & (ln["v0"] <= lwb.wn)] for k, a in ln.items()} for m, ln in swb.lines.items()}
+    dump = str(tmp_path / "columns.txt")
+    write_column(dump, v1)
+    with open(dump, "a") as f:
+        for name, vals in (("cloud_fraction", cf), ("liquid_water_content", lwc), ("ice_water_content", iwc)):
+            f.write(name + ": " + " ".join(repr(float(x)) for x in vals) + "\n")
+    user_level, albedo, emissivity = 20, 0.196, 0.97
+    out = str(tmp_path / "cloudy.txt")
+    cmd = [CLOUDS, swb.par, swb.files["solar"], dump, *("-" + NAME[m] for m in swb.mols),
+           "-h2o-ctm", swb.h2o_dir, "-o3-ctm", swb.files["o3_ctm"], "-CFC-11", swb.files["cfc11"], "-CFC-12", swb.files["cfc12"],
+           "-N2-N2", swb.files["cia_n2n2"], "-O2-N2", swb.files["cia_o2n2"], "-O2-O2", swb.files["cia_o2o2"],
+           "-a", repr(albedo), "-e", repr(emissivity), "-flux-at-level", str(user_level + 1), "-integrated", "-clouds",
+           "-beta-path", "beta.nc", "-ice-path", "ice.nc", "-liquid-path", "liquid.nc",
+           "-w-lw", "1", "-W-lw", "2000", "-r-lw", "1", "-w-sw", "1", "-W-sw", "8000", "-r-sw", "2", "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, GRT_OPTICS_HOST_VISIBLE="1"))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert "clouds_double: initialised (beta.nc, ice.nc, liquid.nc)" in r.stderr
+    got = parse_output(out)
+    grid_sw = api.create_spectral_grid(swb.w0, swb.wn, swb.dw)
+    solar = api.create_solar_flux(grid_sw, swb.files["solar"])
+    # layer thicknesses as the application computes them (basic-circ-test.c:155-166)
+    thick = np.abs(np.log(col1["p"][:-1]) - np.log(col1["p"][1:])) * col1["t_layer"] * 8.314462 / (28.9647 * 0.001 * 9.81)
+    worst_cloudy = worst_clear = 0.0
+    for band, lw, names in ((lwb, True, ("rlut", "rlus", "rlu", None, "rlds", "rld")), (swb, False, ("rsut", "rsus", "rsu", "rsdt", "rsds", "rsd"))):
+        emis, alb = np.full(band.nw, emissivity), np.full(band.nw, albedo)
+        clear = oracle_column(oracle, lib, band, col1, lw, emis, alb, solar, user_level)
+        centres = band.w0 + np.arange(band.nw) * band.dw                      # driver.c:476-492
+        limits = np.empty(band.nw + 1)
+        limits[1:-1] = 0.5 * (centres[:-1] + centres[1:])
+        limits[0] = max(centres[0] - band.dw, 0.0)
+        limits[-1] = centres[-1] + band.dw
+        (bl, ol, gl), (bi, oi, gi) = cloud_double(limits, L, cf, lwc, iwc, 10.0, col1["t_layer"])
+        tl, ti = bl * thick[:, None], bi * thick[:, None]                      # driver.c:514-525
+        tr, om_r, g_r = oracle.rayleigh(L, col1["p"], band.w0, band.dw, band.nw)
+        z = np.zeros_like(tr)
+        tau, omega, g = oracle.add_optics([clear["tau_gas"], tr, tl, ti], [z, om_r, ol, oi], [z, g_r, gl, gi])
+        up, dn = (oracle.lw_fluxes(band.w0, band.dw, col1["t_surf"], col1["t_layer"], col1["t"], tau, omega, emis) if lw else
+                  oracle.sw_fluxes(omega, g, tau, col1["mu0"], 0.5, alb, alb, col1["tsi"], solar))
+        rows = (up[0], up[-1], up[user_level], dn[0], dn[-1], dn[user_level])
+        for k, name in enumerate(names):
+            if name is None:
+                continue
+            suffix = "_user_level" if k in (2, 5) else ""
+            want = oracle.integrate_row(rows[k], band.dw)
+            cloudy = got[(0, name + "af" + suffix)][0]
+            worst_cloudy = max(worst_cloudy, abs(cloudy - want))
+            worst_clear = max(worst_clear, abs(got[(0, name + "csaf" + suffix)][0] - clear["integ"][k]))
+            if k in (0, 3, 4) and name != "rsdt":
+                assert abs(cloudy - got[(0, name + "csaf" + suffix)][0]) > 0.5          # the clouds matter
+    print(f"reference driver.c cloud pass (clouds double): worst all-sky flux difference {worst_cloudy:.2e}, clear-sky {worst_clear:.2e} W m-2")
+    assert worst_cloudy < 1e-6 and worst_clear < 1e-6
