@@ -5,8 +5,9 @@
  * read netCDF tables this image cannot open.  The symbols exist (libclouds.a, the reference's archive name) so that the
  * unchanged driver.c links; a cloudy run fails loudly with GRTCODE_COMPILER_ERR's message instead of computing
  * anything, exactly as disort_shortwave does without --enable-disort.  Link the reference's own libclouds.a in its
- * place where netCDF exists (note: Optics_t arrays of this library are device pointers; the driver's cloud pass
- * writes them on the host, driver.c:514-525, and would need update_optics() instead).
+ * place where netCDF exists, and run with GRT_OPTICS_HOST_VISIBLE=1: the driver's cloud pass fills Optics_t arrays in
+ * place on the host (driver.c:507-525), so create_optics must hand out host-visible memory (INTEGRATION.md §2;
+ * tests/test_gpu_reference_driver.py runs that pass with a test double of this library).
  */
 #ifndef CLOUDS_LIB_H
 #define CLOUDS_LIB_H
