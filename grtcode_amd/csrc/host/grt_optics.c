@@ -4,7 +4,43 @@
  * reference, stages no temporary copies: the kernel reads the K inputs in place. */
 #include <stdlib.h>
 #include <string.h>
+#include <hip/hip_runtime_api.h>
 #include "grt_internal.h"
+
+/* A driver's column loop creates and destroys one Optics_t per band and column (add_optics allocates its result,
+   driver.c:382-383, 424): hipMalloc + hipFree of 3 x 24 MB, the latter a device-wide synchronisation -- 0.4 ms of a
+   6 ms column.  Destroyed device blocks are therefore parked (a handful, exact size match) and handed out again. */
+#define GRT_OPTICS_CACHE 6
+static struct { Device_t device; size_t bytes; void *block; } g_optics_cache[GRT_OPTICS_CACHE];
+
+static void *optics_cache_take(Device_t device, size_t bytes)
+{
+    for (int i = 0; i < GRT_OPTICS_CACHE; ++i)
+    {
+        if (g_optics_cache[i].block != NULL && g_optics_cache[i].device == device && g_optics_cache[i].bytes == bytes)
+        {
+            void *b = g_optics_cache[i].block;
+            g_optics_cache[i].block = NULL;
+            return b;
+        }
+    }
+    return NULL;
+}
+
+static int optics_cache_put(Device_t device, size_t bytes, void *block)
+{
+    for (int i = 0; i < GRT_OPTICS_CACHE; ++i)
+    {
+        if (g_optics_cache[i].block == NULL)
+        {
+            g_optics_cache[i].device = device;
+            g_optics_cache[i].bytes = bytes;
+            g_optics_cache[i].block = block;
+            return 1;
+        }
+    }
+    return 0;
+}
 
 /* host_visible: the arrays live in host memory that the device reads and writes through the same pointers, so a
    caller may fill them in place -- what GRT_OPTICS_HOST_VISIBLE=1 asks of create_optics for a cloudy driver run
@@ -30,7 +66,7 @@ static int create_optics_in(Optics_t * const optics, int const num_layers, Spect
     {
         GRT_TRY(grt_dev_alloc_host_visible(*device, &block, 3*bytes));
     }
-    else
+    else if ((block = optics_cache_take(*device, 3*bytes)) == NULL)
     {
         GRT_TRY(grt_dev_alloc(*device, &block, 3*bytes));
     }
@@ -56,7 +92,29 @@ EXTERN int create_optics(Optics_t * const optics, int const num_layers,
 EXTERN int destroy_optics(Optics_t * const optics)
 {
     GRT_REQUIRE_PTR(optics);
-    GRT_TRY(grt_dev_free_any(optics->device, optics->tau));     /* base of the single block */
+    if (optics->tau != NULL)
+    {
+        /* a device block of this object's size goes back to the cache (the stream is drained first: a kernel of this
+           object may still be reading it); host-visible blocks and what the cache has no room for are freed */
+        size_t const bytes = 3*sizeof(fp_t)*(size_t)optics->num_layers*optics->grid.n;
+        hipPointerAttribute_t attr;
+        memset(&attr, 0, sizeof(attr));
+        int const is_device = hipPointerGetAttributes(&attr, optics->tau) == hipSuccess && attr.type == hipMemoryTypeDevice;
+        if (!is_device)
+        {
+            (void)hipGetLastError();
+        }
+        int parked = 0;
+        if (is_device && optics->g == optics->tau + 2*(size_t)optics->num_layers*optics->grid.n)
+        {
+            GRT_TRY(grt_dev_sync(optics->device, grt_dev_stream(optics->device)));
+            parked = optics_cache_put(optics->device, bytes, optics->tau);
+        }
+        if (!parked)
+        {
+            GRT_TRY(grt_dev_free_any(optics->device, optics->tau));     /* base of the single block */
+        }
+    }
     optics->g = optics->omega = optics->tau = NULL;
     return GRTCODE_SUCCESS;
 }
