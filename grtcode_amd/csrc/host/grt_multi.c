@@ -236,6 +236,14 @@ EXTERN int grt_multi_destroy(GrtMulti_t **multi)
         {
             GRT_TRY(rccl_check(rccl.CommDestroy(m->comm), "ncclCommDestroy"));
         }
+        if (m->rank == 0)
+        {
+            /* every rank has joined the communicator, so nobody still needs the id: a later job that reuses
+               the directory must not pick up this one's */
+            char path[DIR_PATH_LEN + 64];
+            snprintf(path, sizeof(path), "%s/rccl_unique_id.bin", m->dir);
+            remove(path);
+        }
         GRT_TRY(grt_dev_free(m->device, m->pad_d));
     }
     free(m);

@@ -131,7 +131,10 @@ EXTERN int grt_pipeline_views(GrtPipeline_t *pipeline, int band, fp_t **tau_gas,
  * transport GRT_MULTI_RCCL: ncclGather over xGMI on the library stream (device pointers, asynchronous; the
  * communicator id travels through `rendezvous_dir`, a directory all ranks see); GRT_MULTI_FILES: per-rank files in
  * `rendezvous_dir` assembled by rank 0 (host or device pointers, synchronous) -- the reference's own scheme, and the
- * way the multi-rank path runs where there is no GPU.  GRT_MULTI_TIMEOUT [s] bounds every wait (default 600). */
+ * way the multi-rank path runs where there is no GPU.  GRT_MULTI_TIMEOUT [s] bounds every wait (default 600).
+ * `rendezvous_dir` must hold nothing from another job when the ranks start: a job's exchange files are removed as
+ * they are read and rank 0 removes the communicator id in grt_multi_destroy, so a directory is reusable after a
+ * clean run; after a crash, empty it. */
 enum grt_multi_transport { GRT_MULTI_RCCL = 0, GRT_MULTI_FILES = 1 };
 typedef struct GrtMulti GrtMulti_t;
 /* rank's block of a num_columns-column set: [first, first + count), count <= ceil(num_columns/world), 0 for ranks beyond the end */

@@ -134,5 +134,6 @@ def test_batched_c_driver_matches_oracle(tmp_path, oracle, lib):
     assert m.max(3.25) == 3.25                                       # (synchronises the stream)
     assert np.array_equal(dst.to_host((5, 12)), block)
     m.destroy()
+    assert not (rdv1 / "rccl_unique_id.bin").exists()               # rank 0 clears the id: the directory can be reused
     src.free()
     dst.free()
