@@ -230,6 +230,55 @@ __device__ int near_radius(GrtGasOpticsArgs const &a, double const *lay, double 
     return *use_moments ? R : fsteps;
 }
 
+// ---- the cell hierarchy of the tree form (described above gas_optics_tree_kernel): sizes, offsets, the shift of
+// a child's moments to its parent's centre ----
+constexpr int kMaxLevels = 20;
+constexpr int kDirectTile = 512;    // tree form, cell tiles wider than this (sparse lines): moments added straight to global memory
+
+__host__ __device__ inline uint64_t level_cells(uint64_t nw, int l)
+{
+    return (nw + ((uint64_t)1 << l) - 1) >> l;
+}
+
+// offset of level l in the (column, layer) block of gmom, floats; `terms` moments per cell.  Level i has room for
+// nw_pad >> i cells, nw_pad = nw rounded up to a whole number of top-level cells, so that the offset is a closed
+// form -- the gather's scalar walk computes it instead of looking it up (an LDS read shares its counter with the
+// scalar loads and would make every cell wait for the one before).
+__host__ __device__ inline uint64_t level_offset(uint64_t nw, int l, int terms, int levels)
+{
+    uint64_t const p2 = 2*(((nw + ((uint64_t)1 << levels) - 1) >> levels) << levels);
+    return (p2 - (p2 >> l))*terms;
+}
+
+// |C(k, j) (1/4)^(k-j) (1/2)^j|: the parent's m_k from a child's m_j (1-based, j <= k); the lower child's takes the
+// sign (-1)^(k-j), the upper child's is positive
+constexpr float shift_coef(int k, int j)
+{
+    double v = (double)binomial(k, j);
+    for (int i = 0; i < k - j; ++i) v *= 0.25;
+    for (int i = 0; i < j; ++i) v *= 0.5;
+    return (float)v;
+}
+
+// a parent's scaled moments from its two children's (the coefficients are literals in the code)
+template <int K>
+__device__ __forceinline__ void shift_pair(float const (&lo)[K], float const (&hi)[K], float (&m)[K])
+{
+#pragma unroll
+    for (int k = 1; k <= K; ++k)
+    {
+        float v = 0.f;
+#pragma unroll
+        for (int j = 1; j <= k; ++j)
+        {
+            float const cf = shift_coef(k, j);
+            v = fmaf(((k - j) & 1) ? -cf : cf, lo[j - 1], v);
+            v = fmaf(cf, hi[j - 1], v);
+        }
+        m[k - 1] = v;
+    }
+}
+
 template <int CLASS, typename Queue>
 __device__ __forceinline__ void drain_class(double *acc, Queue const *q, int wave, int first, int count, int lane)
 {
@@ -291,6 +340,17 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
     {
         mom[i] = 0.f;
     }
+    if (TREE && K == kMomWide && ncell == 0)
+    {
+        // moments straight to global memory: this workgroup is the only one that adds to its tile's level-0 cells
+        // (one slice; a line belongs to the tile of its centre index), so it clears them itself -- stores that hide
+        // behind the arithmetic instead of a 2 ms pass of their own (the barrier below orders them before the adds)
+        float4 *z = reinterpret_cast<float4 *>(a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*a.gmom_stride + (uint64_t)F0*K);
+        for (int i = tid; i < (F1 - F0)*(K/4); i += kBlock)
+        {
+            z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     for (int i = tid; i <= fsteps && !TWO_PASS; i += kBlock)
     {
         invr[i] = i > 0 ? 1.0f/(float)i : 0.f;
@@ -322,7 +382,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
 
     // moments go to the tile's LDS block, or (tree form: ncell == 0, sparse lines, wide tiles) straight to the
     // zeroed level-0 block in global memory
-    bool const direct = TREE && ncell == 0;
+    bool const direct = TREE && K == kMomWide && ncell == 0;     // (twelve moments <=> straight to global memory)
     float *gcell = TWO_PASS ? a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*a.gmom_stride : nullptr;      // [cell][8]
     auto mom_add = [&](int k, int cell, float v)
     {
@@ -794,6 +854,58 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                 unsafeAtomicAdd(&gm[i], mom[k*ncell + cidx]);
             }
         }
+        if constexpr (TREE && K == kMomWide)
+        {
+            if (direct)
+            {
+                // The tile's coarser cells, levels 1 .. log2(tile): all of them lie inside the tile (tiles are aligned
+                // powers of two), so the workgroup that made the level-0 cells makes them too -- level 1 from the lines
+                // it has just written, which are still in L2 (the adds happened there: the fence keeps L1 out of it),
+                // every further level from the one before in LDS (two buffers in the accumulator's place) -- instead of
+                // one pass over the whole hierarchy per level (7.4 ms of memory traffic at 0.001 cm-1).
+                int lt = 0;
+                while ((2 << lt) <= a.tile && lt < a.tree_levels) ++lt;
+                float *buf_odd = reinterpret_cast<float *>(smem);                   // levels 1, 3, ..: tile/2 cells
+                float *buf_even = buf_odd + (size_t)(a.tile >> 1)*K;                // levels 2, 4, ..: tile/4 cells
+                __syncthreads();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                for (int l = 1; l <= lt; ++l)
+                {
+                    float *dst = (l & 1) ? buf_odd : buf_even;
+                    float const *src = (l & 1) ? buf_even : buf_odd;
+                    float *parent = gcell + level_offset(a.nw, l, K, a.tree_levels);
+                    int const c0 = F0 >> (l - 1), c1 = (F1 + (1 << (l - 1)) - 1) >> (l - 1);    // the tile's cells one level down
+                    int const p0 = F0 >> l, p1 = (F1 + (1 << l) - 1) >> l;
+                    for (int j = p0 + tid; j < p1; j += kBlock)
+                    {
+                        float4 const *ch = l == 1 ? reinterpret_cast<float4 const *>(gcell + (size_t)(2*j)*K)
+                                                  : reinterpret_cast<float4 const *>(src + (size_t)(2*j - c0)*K);
+                        bool const two = 2*j + 1 < c1;
+                        float lo[K], hi[K];
+#pragma unroll
+                        for (int q = 0; q < K/4; ++q)
+                        {
+                            float4 const x = ch[q];
+                            float4 const y = two ? ch[K/4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+                            lo[4*q] = x.x; lo[4*q + 1] = x.y; lo[4*q + 2] = x.z; lo[4*q + 3] = x.w;
+                            hi[4*q] = y.x; hi[4*q + 1] = y.y; hi[4*q + 2] = y.z; hi[4*q + 3] = y.w;
+                        }
+                        float m[K];
+                        shift_pair<K>(lo, hi, m);
+                        float4 *out4 = reinterpret_cast<float4 *>(parent + (size_t)j*K);
+                        float4 *lds4 = reinterpret_cast<float4 *>(dst + (size_t)(j - p0)*K);
+#pragma unroll
+                        for (int q = 0; q < K/4; ++q)
+                        {
+                            float4 const v = make_float4(m[4*q], m[4*q + 1], m[4*q + 2], m[4*q + 3]);
+                            out4[q] = v;
+                            lds4[q] = v;
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+        }
         return;
     }
     // ---- far field: every grid point of the tile gathers the moment series of the cells at
@@ -978,43 +1090,9 @@ __global__ __launch_bounds__(kBlock) void gas_optics_far_kernel(GrtGasOpticsArgs
 // window: ~8 cells per level, ~100 at 0.001 cm-1 instead of 50 000 (gas_optics_tree_kernel).
 // tests/test_moment_tree.py is the same construction in numpy.
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kMaxLevels = 20;
-constexpr int kDirectTile = 512;    // tree form, cell tiles wider than this (sparse lines): moments added straight to global memory
-
-__host__ __device__ inline uint64_t level_cells(uint64_t nw, int l)
-{
-    return (nw + ((uint64_t)1 << l) - 1) >> l;
-}
-
-// offset of level l in the (column, layer) block of gmom, floats; `terms` moments per cell
-__host__ __device__ inline uint64_t level_offset(uint64_t nw, int l, int terms)
-{
-    uint64_t off = 0;
-    for (int i = 0; i < l; ++i)
-    {
-        off += level_cells(nw, i)*terms;
-    }
-    return off;
-}
-
-template <int K>
-struct ShiftTable
-{
-    float lo[K][K], hi[K][K];     // [k][j]: parent m_(k+1) from the lower / upper child's m_(j+1)
-};
-
-__global__ __launch_bounds__(kBlock) void zero_level0_kernel(float *gmom, uint64_t stride, uint64_t n4)
-{
-    uint64_t const i = (uint64_t)blockIdx.x*kBlock + threadIdx.x;
-    if (i < n4)
-    {
-        reinterpret_cast<float4 *>(gmom + ((uint64_t)blockIdx.z*gridDim.y + blockIdx.y)*stride)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-}
-
 template <int K>
 __global__ __launch_bounds__(kBlock) void moment_up_kernel(float *gmom, uint64_t stride, uint64_t off_child, uint64_t n_child,
-                                                            uint64_t off_parent, uint64_t n_parent, ShiftTable<K> t)
+                                                            uint64_t off_parent, uint64_t n_parent)
 {
     uint64_t const j = (uint64_t)blockIdx.x*kBlock + threadIdx.x;
     if (j >= n_parent)
@@ -1034,36 +1112,13 @@ __global__ __launch_bounds__(kBlock) void moment_up_kernel(float *gmom, uint64_t
         hi[4*q] = b.x; hi[4*q + 1] = b.y; hi[4*q + 2] = b.z; hi[4*q + 3] = b.w;
     }
     float m[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k)
-    {
-        float v = 0.f;
-#pragma unroll
-        for (int i = 0; i <= k; ++i)
-        {
-            v = fmaf(t.lo[k][i], lo[i], v);
-            v = fmaf(t.hi[k][i], hi[i], v);
-        }
-        m[k] = v;
-    }
+    shift_pair<K>(lo, hi, m);
     float4 *out = reinterpret_cast<float4 *>(blk + off_parent + j*K);
 #pragma unroll
     for (int q = 0; q < K/4; ++q)
     {
         out[q] = make_float4(m[4*q], m[4*q + 1], m[4*q + 2], m[4*q + 3]);
     }
-}
-
-// Largest level whose cell, with its near edge dm grid steps from the target, is admissible:
-// (dm + h/2)^2 >= sep^2 (h^2/4 + eta^2)  <=>  a h^2 - dm h - (dm^2 - sep^2 eta^2) <= 0,  a = (sep^2 - 1)/4.
-// eta2x = sep^2 eta^2, a4 = 4 a, r2a = 0.999/(2 a).
-__device__ __forceinline__ int admissible_level(float dm, float eta2x, float a4, float r2a)
-{
-    float const q = fmaf(dm, dm, -eta2x);
-    float const disc = fmaf(a4, q, dm*dm);
-    float const hmax = disc >= 0.f ? (dm + __builtin_amdgcn_sqrtf(fmaxf(disc, 0.f)))*r2a : 0.f;    // (no root: no level)
-    int const e = (__float_as_int(hmax) >> 23) - 127;           // floor(log2 hmax); below 1: level 0
-    return e > 0 ? e : 0;
 }
 
 template <int K>
@@ -1082,10 +1137,36 @@ __device__ __forceinline__ float cell_series(float const *cell, float u)
     return p*(u*u);
 }
 
-// Second pass of the tree form: workgroup = (tile of grid points, layer, column); one grid point per thread
-// and turn.  cell_shift: log2 of the first pass's cell-tile size (near-field radii are per cell tile).
 template <int K>
-__global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArgs a, long long fsteps_ll, int cell_shift, int ntab)
+__device__ __forceinline__ float cell_series_regs(float4 const (&c)[K/4], float u)
+{
+    float p = c[K/4 - 1].w;
+    p = fmaf(p, u, c[K/4 - 1].z); p = fmaf(p, u, c[K/4 - 1].y); p = fmaf(p, u, c[K/4 - 1].x);
+#pragma unroll
+    for (int q = K/4 - 2; q >= 0; --q)
+    {
+        p = fmaf(p, u, c[q].w); p = fmaf(p, u, c[q].z); p = fmaf(p, u, c[q].y); p = fmaf(p, u, c[q].x);
+    }
+    return p*(u*u);
+}
+
+// Largest level whose cell, with its near edge dm grid steps from the target, is admissible:
+// (dm + h/2)^2 >= sep^2 (h^2/4 + eta^2)  <=>  a h^2 - dm h - (dm^2 - sep^2 eta^2) <= 0,  a = (sep^2 - 1)/4.
+// eta2x = sep^2 eta^2, a4 = 4 a, r2a = 0.999/(2 a).
+__device__ __forceinline__ int admissible_level(float dm, float eta2x, float a4, float r2a)
+{
+    float const q = fmaf(dm, dm, -eta2x);
+    float const disc = fmaf(a4, q, dm*dm);
+    float const hmax = disc >= 0.f ? (dm + __builtin_amdgcn_sqrtf(fmaxf(disc, 0.f)))*r2a : 0.f;    // (no root: no level)
+    int const e = (__float_as_int(hmax) >> 23) - 127;           // floor(log2 hmax); below 1: level 0
+    return e > 0 ? e : 0;
+}
+
+// Second pass of the tree form, windows of a few hundred points (0.1 cm-1): workgroup = (tile of grid points, layer,
+// column); one grid point per thread and turn, every lane walking its own cells -- the stretches the lanes of a wave
+// could share (gas_optics_tree_kernel below) are no longer than the ones they could not.  cell_shift: log2 of the first pass's cell-tile size (near-field radii are per cell tile).
+template <int K>
+__global__ __launch_bounds__(kBlock) void gas_optics_tree_lane_kernel(GrtGasOpticsArgs a, long long fsteps_ll, int cell_shift, int ntab)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int const fsteps = (int)fsteps_ll;
@@ -1110,7 +1191,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArg
     }
     if (tid <= a.tree_levels)
     {
-        loff[tid] = (unsigned)level_offset(a.nw, tid, K);
+        loff[tid] = (unsigned)level_offset(a.nw, tid, K, a.tree_levels);
     }
     __syncthreads();
     // near-field radii of the cell tiles within `halo` of this tile (level-0 cells further away are far for sure)
@@ -1201,52 +1282,366 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArg
     write_tile(a, acc, cs, col, layer, 0, (long long)F0, (long long)F1, tid);
 }
 
+// A cell's moments through the scalar cache: issue now, wait later (scalar loads return in any order, so the only
+// wait there is is for all of them; the operands of scalar_wait tie the values to it).
+typedef float sfloat4 __attribute__((ext_vector_type(4)));
+
+template <int K>
+__device__ __forceinline__ void scalar_load_cell(float const *cell, sfloat4 (&c)[K/4])
+{
+    static_assert(K == 8 || K == 12, "two or three 16-byte pieces");
+    if constexpr (K == 12)
+    {
+        asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x10\n\ts_load_dwordx4 %2, %3, 0x20"
+                     : "=&s"(c[0]), "=&s"(c[1]), "=&s"(c[2]) : "s"(cell) : "memory");
+    }
+    else
+    {
+        asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x10"
+                     : "=&s"(c[0]), "=&s"(c[1]) : "s"(cell) : "memory");
+    }
+}
+
+template <int K>
+__device__ __forceinline__ void scalar_wait(sfloat4 (&a)[K/4], sfloat4 (&b)[K/4], sfloat4 (&c)[K/4], sfloat4 (&d)[K/4])
+{
+    if constexpr (K == 12)
+    {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a[0]), "+s"(a[1]), "+s"(a[2]), "+s"(b[0]), "+s"(b[1]), "+s"(b[2]),
+                                              "+s"(c[0]), "+s"(c[1]), "+s"(c[2]), "+s"(d[0]), "+s"(d[1]), "+s"(d[2]) :: "memory");
+    }
+    else
+    {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a[0]), "+s"(a[1]), "+s"(b[0]), "+s"(b[1]),
+                                              "+s"(c[0]), "+s"(c[1]), "+s"(d[0]), "+s"(d[1]) :: "memory");
+    }
+}
+
+template <int K>
+__device__ __forceinline__ float cell_series_s(sfloat4 const (&c)[K/4], float u)
+{
+    float p = c[K/4 - 1].w;
+    p = fmaf(p, u, c[K/4 - 1].z); p = fmaf(p, u, c[K/4 - 1].y); p = fmaf(p, u, c[K/4 - 1].x);
+#pragma unroll
+    for (int q = K/4 - 2; q >= 0; --q)
+    {
+        p = fmaf(p, u, c[q].w); p = fmaf(p, u, c[q].z); p = fmaf(p, u, c[q].y); p = fmaf(p, u, c[q].x);
+    }
+    return p*(u*u);
+}
+
+// Second pass of the tree form: workgroup = (tile of grid points, layer, column); a WAVE owns 64 consecutive grid
+// points fb .. fb + 63 (one per lane) at a time and walks the cells once for all of them.  Going up from the points:
+//   [f + 1 + rmin, XA)    per lane: the level-0 cells that may lie in some cell tile's near field (each asks its
+//                         own tile's radius, as the first pass did), then small cells up to XA = f_hi + rmax + 1
+//   [XA, E0)              shared: greedy walk, level = min(alignment, room to E0, admissible for the CLOSEST of the
+//                         64 points, top level) -- a cell admissible for the closest point is admissible for all.
+//                         Everything about the walk is wave-uniform: it runs on the scalar unit, the cell's moments
+//                         come through the scalar cache (48 bytes per wave and cell instead of 48 bytes per LANE
+//                         through the texture path), and the lanes only evaluate the series.
+//                         E0 - 1 = fb + fsteps: the last cell inside EVERY lane's window (kernels.c:435-437)
+//   [E0, f + fsteps]      per lane: the <= 63 cells that are in this lane's window only
+// and the mirror image going down.  Round 1's form walked per lane: as long on the walk (ctz, clz, the admissible
+// level: ~30 instructions per cell) and on its loads (the L1 -> register path: 3 KB per wave and cell) as on the series.
+// cell_shift: log2 of the first pass's cell-tile size (near-field radii are per cell tile); gtile: this kernel's tile.
+template <int K>
+__global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArgs a, long long fsteps_ll, int cell_shift, int ntab,
+                                                                  int gtile)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int const fsteps = (int)fsteps_ll;
+    double *acc = reinterpret_cast<double *>(smem);                               // [gtile]
+    double *ms_l = acc + gtile;                                                   // [num_slots][4]
+    double *q_l = ms_l + 4*a.lay.num_slots;                                       // [num_slots][GRT_MAX_ISO] (unused here)
+    int *rtab = reinterpret_cast<int *>(q_l + GRT_MAX_ISO*a.lay.num_slots);       // [ntab]
+    int const tid = threadIdx.x;
+    int const layer = blockIdx.y, col = blockIdx.z;
+    int const nw = (int)a.nw;
+    int const F0 = (int)blockIdx.x*gtile;
+    int const F1 = F0 + gtile < nw ? F0 + gtile : nw;
+    double const *cs = a.colstate + (uint64_t)col*a.lay.stride;
+    double const *lay = cs + a.lay.off_lay + (uint64_t)layer*4;
+    double *out = a.tau + (uint64_t)col*a.tau_col_stride + (uint64_t)layer*a.nw;
+    float const *gm = a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*a.gmom_stride;
+    stage_column_state(a, cs, layer, ms_l, q_l, tid);
+    for (int i = tid; i < F1 - F0; i += kBlock)
+    {
+        acc[i] = out[F0 + i];
+    }
+    __syncthreads();
+    // near-field radii of the cell tiles within `halo` of this tile (level-0 cells further away are far for sure)
+    int const t0 = (F0 - a.halo > 0 ? F0 - a.halo : 0) >> cell_shift;
+    int const t1 = (F1 - 1 + a.halo < nw - 1 ? F1 - 1 + a.halo : nw - 1) >> cell_shift;
+    for (int t = tid; t <= t1 - t0; t += kBlock)
+    {
+        long long const c1 = ((long long)(t0 + t + 1) << cell_shift);
+        bool um, cr;
+        rtab[t] = near_radius(a, lay, ms_l, (long long)(t0 + t) << cell_shift, c1 < nw ? c1 : nw, fsteps, &um, &cr);
+    }
+    __syncthreads();
+    int rmin_v = fsteps, rmax_v = 0;
+    for (int t = 0; t <= t1 - t0; ++t)
+    {
+        rmin_v = rtab[t] < rmin_v ? rtab[t] : rmin_v;
+        rmax_v = rtab[t] > rmax_v ? rtab[t] : rmax_v;
+    }
+    int const rmin = __builtin_amdgcn_readfirstlane(rmin_v), rmax = __builtin_amdgcn_readfirstlane(rmax_v);
+    bool um, cr;
+    double zmax;
+    near_radius(a, lay, ms_l, F0, F1, fsteps, &um, &cr, &zmax);
+    double const sep = moment_separation(K);
+    int const lmax = a.tree_levels;
+    unsigned const p2 = (unsigned)(level_offset(a.nw, 1, 1, lmax) << 1);        // 2 nw_pad: level l starts at (p2 - (p2 >> l)) K floats
+    // Admissible levels (see admissible_level): a cell of h = 2^l points whose first point is D grid steps from the
+    // target is admissible when (D - 1/2 + h/2)^2 >= sep^2 (h^2/4 + eta^2), i.e. D >= thr(l).  Lane l keeps thr(l), so
+    // "the highest admissible level at distance D" is one compare and the position of the ballot's top bit.  Level 0
+    // always passes beyond a near field (R + 1 >= sep |z|max), and the levels that pass are 0 .. the highest.
+    int thr;
+    {
+        int const l = tid & 63;
+        double const h = (double)((uint64_t)1 << (l <= lmax ? l : 0));
+        double const e2 = sep*sep*(zmax*zmax - 0.25)*1.0001;
+        double const t = (sqrt(0.25*sep*sep*h*h + e2) - 0.5*h)*1.000001 + 1.5;
+        thr = l == 0 ? (int)0x80000000 : (l <= lmax && t < 2e9) ? (int)ceil(t) : 0x7fffffff;
+    }
+    auto top_level = [&](int D) -> int      // D wave-uniform
+    {
+        return 63 - __builtin_clzll(__ballot(D >= thr));
+    };
+
+    // one lane's own cells [x, end) going up / (end, x] going down: greedy, free of branches
+    // (cap: a level admissible at the smallest distance the stretch has for any lane)
+    // (terms: K, or 4 where the stretch is so far away that four terms leave what K leave at the near field's edge)
+    auto walk_up = [&](int f, int x, int end, int cap, auto terms_tag) -> double
+    {
+        constexpr int TERMS = decltype(terms_tag)::value;
+        double sum = 0.;
+        while (x < end)
+        {
+            int const D = x - f;
+            int const la = __builtin_ctz(x), le = 31 - __builtin_clz(end - x);
+            int const l = min(min(la, le), cap);
+            float const h = __int_as_float((127 + l) << 23), rh = __int_as_float((127 - l) << 23);
+            float const d = ((float)D - 0.5f) + 0.5f*h;                     // C - f
+            float const u = -h*__builtin_amdgcn_rcpf(d);
+            sum += (double)(cell_series<TERMS>(gm + (p2 - (p2 >> l))*K + (size_t)(x >> l)*K, u)*rh);
+            x += 1 << l;
+        }
+        return sum;
+    };
+    auto walk_down = [&](int f, int x, int end, int cap, auto terms_tag) -> double
+    {
+        constexpr int TERMS = decltype(terms_tag)::value;
+        double sum = 0.;
+        while (x > end)
+        {
+            int const D = f - x;
+            int const la = __builtin_ctz(x + 1), le = 31 - __builtin_clz(x - end);
+            int const l = min(min(la, le), cap);
+            float const h = __int_as_float((127 + l) << 23), rh = __int_as_float((127 - l) << 23);
+            float const d = ((float)D - 0.5f) + 0.5f*h;                     // f - C
+            float const u = h*__builtin_amdgcn_rcpf(d);
+            sum += (double)(cell_series<TERMS>(gm + (p2 - (p2 >> l))*K + (size_t)(x >> l)*K, u)*rh);
+            x -= 1 << l;
+        }
+        return sum;
+    };
+
+    int const lane = tid & 63;
+    int const wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int cb = wave*64; cb < F1 - F0; cb += kBlock)
+    {
+        int const fb = F0 + cb;                                             // (wave-uniform from here to the lanes' f)
+        int const np = F1 - fb < 64 ? F1 - fb : 64;
+        int const fhi = fb + np - 1;
+        // shared stretches: cells [XA, E0) above, (S0, XB] below
+        int const E0 = (fb + fsteps < nw - 1 ? fb + fsteps : nw - 1) + 1;
+        int const XA = fhi + rmax + 1 < E0 ? fhi + rmax + 1 : E0;
+        int const S0 = (fhi - fsteps > 0 ? fhi - fsteps : 0) - 1;
+        int const XB = fb - rmax - 1 > S0 ? fb - rmax - 1 : S0;
+        // The shared stretches begin and end on multiples of 64 where the window has room for that: a lane's own
+        // stretches then end (going up: [.., XAs)) or begin ([E0s, ..]) on one, and an interval of n < 128 cells with
+        // one end on a multiple of 64 is popcount(n) <= 7 aligned cells; with both ends anywhere it takes up to twice that.
+        int E0s = E0, XAs = XA, S0s = S0, XBs = XB;
+        {
+            int const ea = E0 & ~63, xa = (XA + 63) & ~63;
+            if (xa <= ea) { E0s = ea; XAs = xa; }
+            int const xb = ((XB + 1) & ~63) - 1, sa = ((S0 + 64) & ~63) - 1;
+            if (xb >= sa) { XBs = xb; S0s = sa; }
+        }
+        int const f = fb + lane;
+        double sum = 0.;
+        int const cap_near = top_level(rmax + 1);                           // every own cell is at least this far from its lane's point
+        int const cap_up = max(top_level(E0s - fhi), cap_near), cap_down = max(top_level(fb - S0s), cap_near);
+        // the far stretches hold cells of at most 64 points: |z| <= sqrt(32^2 + eta^2); four terms do where (|z|/D)^4 <= 7e-8
+        float const z2far = (float)(1024. + (zmax*zmax - 0.25));
+        float const dup = (float)(E0s - fhi) - 0.5f, ddn = (float)(fb - S0s) - 0.5f;
+        bool const four_up = z2far <= 2.6e-4f*dup*dup, four_down = z2far <= 2.6e-4f*ddn*ddn;
+        std::integral_constant<int, K> const all_terms{};
+        std::integral_constant<int, 4> const four_terms{};
+        // ---- the lane's own cells ----
+        if (lane < np)
+        {
+            {
+                // (a near field nearly as wide as the window: XA = E0 cuts the shared stretch out, and the lanes whose
+                // own near field reaches beyond E0 go on cell by cell)
+                int const e = f + fsteps < nw - 1 ? f + fsteps : nw - 1;
+                int x = f + 1 + rmin;
+                int const xa = f + rmax < e ? f + rmax : e;
+                for (; x <= xa; ++x)
+                {
+                    int const D = x - f;
+                    if (D > rtab[(x >> cell_shift) - t0])
+                    {
+                        float const u = -__builtin_amdgcn_rcpf((float)D);
+                        sum += (double)cell_series<K>(gm + (size_t)x*K, u);
+                    }
+                }
+                sum += walk_up(f, x, XAs, cap_near, all_terms);
+                sum += four_up ? walk_up(f, E0s > x ? E0s : x, e + 1, cap_up, four_terms) : walk_up(f, E0s > x ? E0s : x, e + 1, cap_up, all_terms);
+            }
+            {
+                int const s = f - fsteps > 0 ? f - fsteps : 0;
+                int x = f - 1 - rmin;
+                int const xa = f - rmax > s ? f - rmax : s;
+                for (; x >= xa; --x)
+                {
+                    int const D = f - x;
+                    if (D > rtab[(x >> cell_shift) - t0])
+                    {
+                        float const u = __builtin_amdgcn_rcpf((float)D);
+                        sum += (double)cell_series<K>(gm + (size_t)x*K, u);
+                    }
+                }
+                sum += walk_down(f, x, XBs, cap_near, all_terms);
+                sum += four_down ? walk_down(f, S0s < x ? S0s : x, s - 1, cap_down, four_terms) : walk_down(f, S0s < x ? S0s : x, s - 1, cap_down, all_terms);
+            }
+        }
+        // ---- the shared stretches: one scalar walk, the lanes evaluate the series.  Cells are taken kBatch at a time:
+        // scalar loads return in any order, so a wave can only wait for ALL of its loads -- with one cell per wait the
+        // kernel ran at the scalar cache's latency (22 ms at 0.001 cm-1, no faster than round 1's form).  A batch's
+        // unused places repeat the last cell with weight zero. ----
+        constexpr int kBatch = 4;       // (scalar_wait takes four)
+        for (int x = XAs; x < E0s;)
+        {
+            sfloat4 c[kBatch][K/4];
+            float hh[kBatch], ww[kBatch];
+            int xx[kBatch];
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j)
+            {
+                bool const live = x < E0s;
+                int const xs = live ? x : E0s - 1;
+                int const D = xs - fhi;                                     // the closest point decides
+                int const la = __builtin_ctz(xs), le = 31 - __builtin_clz(E0s - xs);
+                int const l = __builtin_amdgcn_readfirstlane(min(min(la, le), top_level(D)));
+                unsigned const off = (p2 - (p2 >> l))*K;
+                scalar_load_cell<K>(gm + off + (size_t)(xs >> l)*K, c[j]);
+                hh[j] = __int_as_float((127 + l) << 23);
+                ww[j] = live ? __int_as_float((127 - l) << 23) : 0.f;
+                xx[j] = xs;
+                x = __builtin_amdgcn_readfirstlane(live ? x + (1 << l) : x);
+            }
+            scalar_wait<K>(c[0], c[1], c[2], c[3]);
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j)
+            {
+                float const d = ((float)(xx[j] - f) - 0.5f) + 0.5f*hh[j];   // C - f
+                float const u = -hh[j]*__builtin_amdgcn_rcpf(d);
+                sum += (double)(cell_series_s<K>(c[j], u)*ww[j]);
+            }
+        }
+        for (int x = XBs; x > S0s;)
+        {
+            sfloat4 c[kBatch][K/4];
+            float hh[kBatch], ww[kBatch];
+            int xx[kBatch];
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j)
+            {
+                bool const live = x > S0s;
+                int const xs = live ? x : S0s + 1;
+                int const D = fb - xs;
+                int const la = __builtin_ctz(xs + 1), le = 31 - __builtin_clz(xs - S0s);
+                int const l = __builtin_amdgcn_readfirstlane(min(min(la, le), top_level(D)));
+                unsigned const off = (p2 - (p2 >> l))*K;
+                scalar_load_cell<K>(gm + off + (size_t)(xs >> l)*K, c[j]);
+                hh[j] = __int_as_float((127 + l) << 23);
+                ww[j] = live ? __int_as_float((127 - l) << 23) : 0.f;
+                xx[j] = xs;
+                x = __builtin_amdgcn_readfirstlane(live ? x - (1 << l) : x);
+            }
+            scalar_wait<K>(c[0], c[1], c[2], c[3]);
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j)
+            {
+                float const d = ((float)(f - xx[j]) - 0.5f) + 0.5f*hh[j];   // f - C
+                float const u = hh[j]*__builtin_amdgcn_rcpf(d);
+                sum += (double)(cell_series_s<K>(c[j], u)*ww[j]);
+            }
+        }
+        if (lane < np)
+        {
+            acc[cb + lane] += sum;
+        }
+    }
+    __syncthreads();
+    write_tile(a, acc, cs, col, layer, 0, (long long)F0, (long long)F1, tid);
+}
+
 size_t tree_lds_bytes(int tile, int num_slots, int ntab)
 {
     return sizeof(double)*tile + sizeof(double)*num_slots*(4 + GRT_MAX_ISO) + sizeof(int)*((size_t)ntab + kMaxLevels + 2);
 }
 
-template <int K>
-ShiftTable<K> make_shift_table()
-{
-    ShiftTable<K> t;
-    for (int k = 1; k <= K; ++k)
-    {
-        for (int j = 1; j <= K; ++j)
-        {
-            double binom = 1.;
-            for (int i = 1; i <= j; ++i)
-            {
-                binom = binom*(double)(k - j + i)/(double)i;        // C(k, j)
-            }
-            double const mag = j <= k ? binom*pow(0.25, k - j)*pow(0.5, j) : 0.;
-            t.hi[k - 1][j - 1] = (float)mag;
-            t.lo[k - 1][j - 1] = (float)(((k - j) & 1) ? -mag : mag);
-        }
-    }
-    return t;
-}
+// windows of fewer points a side: every lane walks its own cells (gas_optics_tree_lane_kernel).  Measured, 10^6 lines,
+// lane form / wave form: 0.1 cm-1 0.22 / 0.75 ms, 0.01 cm-1 2.5 / 4.0, 0.005 cm-1 4.9 / 5.9, 0.0025 cm-1 10.1 / 9.6,
+// 0.001 cm-1 30.4 / 23.8 (coarse levels included)
+constexpr int kTreeWaveMin = 8192;
+constexpr int kTreeTile = 1024;      // the gather's tile: four stretches of 64 points per wave
+
+// the gather's tile and the number of cell tiles (first-pass tiles of `tile` cells) whose near-field radius it looks up
+inline int tree_gather_tile() { return kTreeTile; }
+inline int tree_gather_ntab(int tile, int halo) { return (tree_gather_tile() + 2*halo)/tile + 3; }
 
 // the coarse levels, one launch per level, then the gather
 template <int K>
-void launch_tree(hipStream_t s, GrtGasOpticsArgs const &b, long long fsteps, int shift, int ntab, unsigned tiles)
+void launch_tree(hipStream_t s, GrtGasOpticsArgs const &b, long long fsteps, int shift, int first_level)
 {
-    static ShiftTable<K> const table = make_shift_table<K>();
-    for (int l = 1; l <= b.tree_levels; ++l)
+    // (first_level > 1: the first pass has made the levels inside its tiles)
+    for (int l = first_level; l <= b.tree_levels; ++l)
     {
         uint64_t const n_child = level_cells(b.nw, l - 1), n_parent = level_cells(b.nw, l);
         hipLaunchKernelGGL(moment_up_kernel<K>, dim3((unsigned)((n_parent + kBlock - 1)/kBlock), b.lay.num_layers, b.ncol),
-                           dim3(kBlock), 0, s, b.gmom, b.gmom_stride, level_offset(b.nw, l - 1, K), n_child,
-                           level_offset(b.nw, l, K), n_parent, table);
+                           dim3(kBlock), 0, s, b.gmom, b.gmom_stride, level_offset(b.nw, l - 1, K, b.tree_levels), n_child,
+                           level_offset(b.nw, l, K, b.tree_levels), n_parent);
     }
-    hipLaunchKernelGGL(gas_optics_tree_kernel<K>, dim3(tiles, b.lay.num_layers, b.ncol), dim3(kBlock),
-                       tree_lds_bytes(b.tile, b.lay.num_slots, ntab), s, b, fsteps, shift, ntab);
+    static long long wave_min = -1;        // GRT_TREE_WAVE_MIN in the environment: exploration only
+    if (wave_min < 0)
+    {
+        char const *env = getenv("GRT_TREE_WAVE_MIN");
+        wave_min = env != NULL && atoll(env) > 0 ? atoll(env) : kTreeWaveMin;
+    }
+    if (fsteps < wave_min)
+    {
+        int const ntab = (b.tile + 2*b.halo)/b.tile + 2;
+        hipLaunchKernelGGL(gas_optics_tree_lane_kernel<K>, dim3((unsigned)((b.nw + b.tile - 1)/b.tile), b.lay.num_layers, b.ncol),
+                           dim3(kBlock), tree_lds_bytes(b.tile, b.lay.num_slots, ntab), s, b, fsteps, shift, ntab);
+        return;
+    }
+    int const gtile = tree_gather_tile(), ntab = tree_gather_ntab(b.tile, b.halo);
+    hipLaunchKernelGGL(gas_optics_tree_kernel<K>, dim3((unsigned)((b.nw + gtile - 1)/gtile), b.lay.num_layers, b.ncol),
+                       dim3(kBlock), tree_lds_bytes(gtile, b.lay.num_slots, ntab), s, b, fsteps, shift, ntab, gtile);
 }
 
-size_t mp_lds_bytes(int nacc, int ncell, int fsteps, int num_slots, bool tree = false)
+// subtree_tile > 0: the tree form's first pass with moments straight to global memory, which ends by building the tile's
+// coarser cells in two LDS buffers (tile/2 + tile/4 cells of twelve moments) where the accumulator was
+size_t mp_lds_bytes(int nacc, int ncell, int fsteps, int num_slots, bool tree = false, int subtree_tile = 0)
 {
-    return sizeof(double)*nacc + (tree ? sizeof(MpQueue<kMpQueueTree>) : sizeof(MpQueue<kMpQueue>)) + 2*sizeof(long long) + sizeof(double)*(num_slots*(4 + GRT_MAX_ISO) + kPowTable)
-           + sizeof(float)*((size_t)kMom*ncell + fsteps + 1);
+    size_t const main_loop = sizeof(double)*nacc + (tree ? sizeof(MpQueue<kMpQueueTree>) : sizeof(MpQueue<kMpQueue>)) + 2*sizeof(long long) + sizeof(double)*(num_slots*(4 + GRT_MAX_ISO) + kPowTable)
+                             + sizeof(float)*((size_t)kMom*ncell + fsteps + 1);
+    size_t const subtree = sizeof(float)*kMomWide*((size_t)(subtree_tile >> 1) + (size_t)(subtree_tile >> 2));
+    return main_loop > subtree ? main_loop : subtree;
 }
 
 size_t far_lds_bytes(int tile, int ncell, int fsteps, int num_slots, int cell_shift)
@@ -1280,13 +1675,14 @@ extern "C" int grt_gas_optics_mp_applicable(GrtGasOpticsArgs const *a)
         int const terms = a->mom_terms == 0 ? kMom : a->mom_terms;
         bool const direct = a->tile > kDirectTile;
         return shift >= 6 && a->gmom != NULL && a->tree_levels <= kMaxLevels && a->halo >= 3 && a->rcap <= a->halo
-               && (terms == kMom || (terms == kMomWide && direct))
+               && ((terms == kMom && !direct) || (terms == kMomWide && direct))
                && (long long)a->halo + 4 <= fsteps && fsteps < (1ll << 30) && a->nw < (1ull << 30)
                && ((long long)1 << a->tree_levels) <= fsteps
-               && a->gmom_stride >= level_offset(a->nw, a->tree_levels + 1, terms)
-               && level_offset(a->nw, a->tree_levels + 1, terms) < 0xffffffffull
+               && a->gmom_stride >= level_offset(a->nw, a->tree_levels + 1, terms, a->tree_levels)
+               && level_offset(a->nw, a->tree_levels + 1, terms, a->tree_levels) < 0xffffffffull
                && a->tile + 2*a->halo <= 65535
-               && mp_lds_bytes(a->tile + 2*a->halo, direct ? 0 : a->tile, 0, a->lay.num_slots, true) <= 64*1024
+               && mp_lds_bytes(a->tile + 2*a->halo, direct ? 0 : a->tile, 0, a->lay.num_slots, true, direct ? a->tile : 0) <= 64*1024
+               && tree_lds_bytes(tree_gather_tile(), a->lay.num_slots, tree_gather_ntab(a->tile, a->halo)) <= 64*1024
                && tree_lds_bytes(a->tile, a->lay.num_slots, (a->tile + 2*a->halo)/a->tile + 2) <= 64*1024;
     }
     if (fsteps > 4096)
@@ -1310,7 +1706,7 @@ extern "C" int grt_gas_optics_mp_applicable(GrtGasOpticsArgs const *a)
 // floats per (column, layer) block of gmom that `levels` coarse levels need (the host sizes the buffer with it)
 extern "C" uint64_t grt_gas_optics_moment_floats(uint64_t nw, int levels, int terms)
 {
-    return level_offset(nw, levels + 1, terms == 0 ? kMom : terms);
+    return level_offset(nw, levels + 1, terms == 0 ? kMom : terms, levels);
 }
 
 extern "C" double grt_gas_optics_moment_separation(int terms)
@@ -1353,14 +1749,8 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
             e = hipMemsetAsync(a->gmom, 0, sizeof(float)*a->gmom_stride*a->lay.num_layers*a->ncol, s);
         }
         bool const wide = tree && a->mom_terms == kMomWide;
-        if (e == hipSuccess && tree && a->tile > kDirectTile)
-        {
-            // the first pass adds its moments straight to the level-0 blocks (hipMemset2DAsync runs at a fraction
-            // of the memory rate: 8 ms for the 6 GB of the 0.001 cm-1 grid)
-            uint64_t const n4 = a->nw*(wide ? kMomWide : kMom)/4;
-            hipLaunchKernelGGL(zero_level0_kernel, dim3((unsigned)((n4 + kBlock - 1)/kBlock), a->lay.num_layers, a->ncol),
-                               dim3(kBlock), 0, s, a->gmom, a->gmom_stride, n4);
-        }
+        // (tree form on sparse lines, tiles wider than kDirectTile: the first pass clears and fills the level-0 cells of its
+        // tile in global memory itself, and builds the tile's coarser cells)
         if (e != hipSuccess)
         {
             return (int)e;
@@ -1374,7 +1764,7 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
         }
         int slot = a->profile_tag ? grt_profile_begin(stream, a->profile_tag) : -1;
         int const ncell = (tree && a->tile > kDirectTile) ? 0 : a->tile;
-        size_t const lds = mp_lds_bytes(nacc, ncell, 0, a->lay.num_slots, tree);
+        size_t const lds = mp_lds_bytes(nacc, ncell, 0, a->lay.num_slots, tree, tree && ncell == 0 ? a->tile : 0);
         if (wide)
         {
             hipLaunchKernelGGL((gas_optics_mp_kernel<true, true, kMomWide>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
@@ -1395,14 +1785,18 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
         slot = a->profile_tag ? grt_profile_begin(stream, a->profile_tag + 5) : -1;
         if (tree)
         {
-            int const ntab = nacc/a->tile + 2;
+            int first_level = 1;
+            if (ncell == 0)
+            {
+                while ((2 << (first_level - 1)) <= a->tile && first_level <= a->tree_levels) ++first_level;
+            }
             if (wide)
             {
-                launch_tree<kMomWide>(s, b, fsteps, shift, ntab, (unsigned)tiles);
+                launch_tree<kMomWide>(s, b, fsteps, shift, first_level);
             }
             else
             {
-                launch_tree<kMom>(s, b, fsteps, shift, ntab, (unsigned)tiles);
+                launch_tree<kMom>(s, b, fsteps, shift, first_level);
             }
         }
         else
