@@ -234,6 +234,7 @@ __device__ int near_radius(GrtGasOpticsArgs const &a, double const *lay, double 
 // a child's moments to its parent's centre ----
 constexpr int kMaxLevels = 20;
 constexpr int kDirectTile = 512;    // tree form, cell tiles wider than this (sparse lines): moments added straight to global memory
+static_assert(kDirectTile <= 2*kBlock, "the in-place coarser levels take one parent per thread");
 
 __host__ __device__ inline uint64_t level_cells(uint64_t nw, int l)
 {
@@ -852,6 +853,43 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
             else
             {
                 unsafeAtomicAdd(&gm[i], mom[k*ncell + cidx]);
+            }
+        }
+        if constexpr (TREE && K == kMom)
+        {
+            // Eight moments, kept in LDS: the tile's coarser cells (levels 1 .. log2(tile)) are made here too, in place --
+            // every parent's thread reads its two children, all wait, the parents go where the first half of the children
+            // were (and to global memory).  One parent per thread: tiles of this form are at most 2 kBlock cells.
+            int lt = 0;
+            while ((2 << lt) <= a.tile && lt < a.tree_levels) ++lt;
+            for (int l = 1; l <= lt; ++l)
+            {
+                __syncthreads();
+                int const c0 = F0 >> (l - 1), c1 = (F1 + (1 << (l - 1)) - 1) >> (l - 1);
+                int const p0 = F0 >> l, p1 = (F1 + (1 << l) - 1) >> l;
+                int const j = p0 + tid;
+                float lo[kMom], hi[kMom];
+                bool const mine = j < p1, two = mine && 2*j + 1 < c1;
+#pragma unroll
+                for (int k = 0; k < kMom; ++k)
+                {
+                    lo[k] = mine ? mom[k*ncell + (2*j - c0)] : 0.f;
+                    hi[k] = two ? mom[k*ncell + (2*j + 1 - c0)] : 0.f;
+                }
+                __syncthreads();
+                if (mine)
+                {
+                    float m[kMom];
+                    shift_pair<kMom>(lo, hi, m);
+                    float4 *out4 = reinterpret_cast<float4 *>(gcell + level_offset(a.nw, l, kMom, a.tree_levels) + (size_t)j*kMom);
+                    out4[0] = make_float4(m[0], m[1], m[2], m[3]);
+                    out4[1] = make_float4(m[4], m[5], m[6], m[7]);
+#pragma unroll
+                    for (int k = 0; k < kMom; ++k)
+                    {
+                        mom[k*ncell + (j - p0)] = m[k];
+                    }
+                }
             }
         }
         if constexpr (TREE && K == kMomWide)
@@ -1608,7 +1646,6 @@ inline int tree_gather_ntab(int tile, int halo) { return (tree_gather_tile() + 2
 template <int K>
 void launch_tree(hipStream_t s, GrtGasOpticsArgs const &b, long long fsteps, int shift, int first_level)
 {
-    // (first_level > 1: the first pass has made the levels inside its tiles)
     for (int l = first_level; l <= b.tree_levels; ++l)
     {
         uint64_t const n_child = level_cells(b.nw, l - 1), n_parent = level_cells(b.nw, l);
@@ -1785,11 +1822,9 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
         slot = a->profile_tag ? grt_profile_begin(stream, a->profile_tag + 5) : -1;
         if (tree)
         {
+            // (the first pass has made the levels inside its tiles)
             int first_level = 1;
-            if (ncell == 0)
-            {
-                while ((2 << (first_level - 1)) <= a->tile && first_level <= a->tree_levels) ++first_level;
-            }
+            while ((2 << (first_level - 1)) <= a->tile && first_level <= a->tree_levels) ++first_level;
             if (wide)
             {
                 launch_tree<kMomWide>(s, b, fsteps, shift, first_level);
