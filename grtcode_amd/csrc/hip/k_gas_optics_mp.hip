@@ -1653,12 +1653,9 @@ void launch_tree(hipStream_t s, GrtGasOpticsArgs const &b, long long fsteps, int
                            dim3(kBlock), 0, s, b.gmom, b.gmom_stride, level_offset(b.nw, l - 1, K, b.tree_levels), n_child,
                            level_offset(b.nw, l, K, b.tree_levels), n_parent);
     }
-    static long long wave_min = -1;        // GRT_TREE_WAVE_MIN in the environment: exploration only
-    if (wave_min < 0)
-    {
-        char const *env = getenv("GRT_TREE_WAVE_MIN");
-        wave_min = env != NULL && atoll(env) > 0 ? atoll(env) : kTreeWaveMin;
-    }
+    // GRT_TREE_WAVE_MIN in the environment (read at every launch): tests put both forms through the same cases
+    char const *env = getenv("GRT_TREE_WAVE_MIN");
+    long long const wave_min = env != NULL && atoll(env) > 0 ? atoll(env) : kTreeWaveMin;
     if (fsteps < wave_min)
     {
         int const ntab = (b.tile + 2*b.halo)/b.tile + 2;

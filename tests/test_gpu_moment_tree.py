@@ -19,6 +19,14 @@ FAST_TOL = 2e-6
 BETWEEN_TOL = 1.2e-6
 
 
+@pytest.fixture(params=["lane", "wave"], autouse=True)
+def gather_form(request, monkeypatch):
+    """Both forms of the tree gather on every case: each lane walking its own cells (the library's choice for windows
+    of fewer than 8 192 points a side) and the wave-shared scalar walk (its choice beyond; forced here)."""
+    monkeypatch.setenv("GRT_TREE_WAVE_MIN", "1000000000" if request.param == "lane" else "1")
+    return request.param
+
+
 def run(band, device, col, fast, tile=0):
     V = col["p"].size
     go, grid = band.gas_optics(device, V, from_file=False)
@@ -132,6 +140,8 @@ def test_randomised_fine_grids(tmp_path, oracle, lib, device, seed):
     rng = np.random.default_rng(777 + seed)
     dw = float(rng.choice([0.04, 0.02, 0.01, 0.005, 0.0025]))
     npts = int(rng.integers(1500, 9000))
+    if dw <= 0.005 and seed % 2:
+        npts *= 5           # grids several windows wide: the wave-shared gather's common stretches, aligned or not
     w0 = float(np.round(rng.choice([50.0, 700.0, 2300.0, 9000.0, 20000.0]) + rng.uniform(0, 50), 2))
     V = int(rng.integers(4, 9))
     nlines = int(rng.integers(40, 1.2e8 / ((V - 1) * 2 * 25 / dw)))      # keeps the oracle to seconds
