@@ -352,13 +352,17 @@ def main():
         total_cols = total_per_step * args.steps
         line_kernel = "gas_optics_mp_kernel" if args.fast in (1, 3) else "gas_optics_kernel"
         line = {
-            "metric": "columns/sec (60-layer, 1 cm\u207b\u00b9 LBL, LW+SW)", "value": total_cols / elapsed, "unit": "columns/s",
+            "metric": "columns/sec (60-layer, 1 cm\u207b\u00b9 LBL, LW+SW)" if (lw_grid[2], sw_grid[2]) == (1.0, 1.0) else
+                      f"columns/sec (60-layer LBL, LW @{lw_grid[2]:g} + SW @{sw_grid[2]:g} cm\u207b\u00b9)",
+            "value": total_cols / elapsed, "unit": "columns/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             **({"rehearsal": "ranks share devices, gloo on host copies: timings are meaningless"} if rehearsal else {}), "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "SURVEY §8d grid G1: LW 1-3250 + SW 1-50000 cm-1 @1 cm-1, 60 layers, 7 absorbers, "
-                                   f"{S['lw']} LW + {S['sw']} SW synthetic lines, H2O/O3 continua, 2 CFC, 3 CIA, clear sky, "
-                                   "integrated fluxes",
+            "config": {"workload": ("SURVEY §8d grid G1: LW 1-3250 + SW 1-50000 cm-1 @1 cm-1" if (lw_grid[2], sw_grid[2]) == (1.0, 1.0) else
+                                    f"LW {lw_grid[0]:g}-{lw_grid[1]:g} cm-1 @{lw_grid[2]:g} cm-1 (n = {n_lw}) + SW {sw_grid[0]:g}-{sw_grid[1]:g} cm-1 "
+                                    f"@{sw_grid[2]:g} cm-1 (n = {n_sw}) -- NOT the headline grid") +
+                                   f", 60 layers, 7 absorbers, {S['lw']} LW + {S['sw']} SW synthetic lines, H2O/O3 continua, 2 CFC, 3 CIA, "
+                                   "clear sky, integrated fluxes",
                        "columns_per_gpu_per_step": args.cols if not strong else None,
                        "columns_per_step": total_per_step, "chunk_columns": args.cols, "fast": args.fast,
                        "arithmetic": {0: "reference operation order", 1: "fused form, far wings by cell moments",
