@@ -85,6 +85,8 @@ typedef struct GrtGasOpticsArgs
     int mom_terms;            /* moments per cell: 8, or -- tree form on sparse lines -- 12 (near field 3.95 |z|max
                                  instead of 7.8 |z|max); 0 means 8 */
     int profile_tag;          /* != 0: time the line kernel under this tag (the two-pass gather under tag + 5) */
+    int near_block;           /* set by the launcher: 64 where the tree form's gather shares its walk per wave -- near
+                                 fields are then whole 64-point blocks (the halo leaves room for that); else 0 */
 } GrtGasOpticsArgs;
 
 int grt_launch_gas_optics(void *stream, GrtGasOpticsArgs const *a);

@@ -508,6 +508,11 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         // its own grid point, x_c = |delta| wr Doppler widths from the centre: the excess is at most
         // 6.5e-9 x_c^2 of it -- 1e-6 at x_c = 12.5.
         float const delta_c = dc*inv_wres_f;
+        // The near field in grid indices: |f - c| <= R -- or, where the tree form's gather shares its walk per wave
+        // (a.near_block), every 64-point block that interval touches, so that the 64 points of a wave have the same
+        // cells to gather (the moments, the queue's take-back and pre-pass 2 below all ask the same question).
+        int const near_lo = (TREE && a.near_block != 0) ? ((c - R) & ~63) : c - R;
+        int const near_hi = (TREE && a.near_block != 0) ? ((c + R) | 63) : c + R;
         bool const reg1_far = valid & voigt_reg1(y, lorentz) & (((float)(R + 1) - fabsf(delta_c))*wr < xlim0);
         bool const fold = corrected & reg1_far & (fabsf(delta_c)*wr <= 0.5f*kFoldWrMax);
         bool const direct_reg1 = valid & !lorentz & (corrected ? reg1_far & !fold : true);
@@ -670,7 +675,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                             // point on a narrow line's centre the Lorentzian is hundreds of times the true value,
                             // nothing to put through fp32 partial sums); beyond it the moments supply the
                             // Lorentzian there (to ~1e-8), to be taken back
-                            nq->far[q][wave][pos] = (r >= -R) & (r <= R) ? 0.f : cl*__builtin_amdgcn_rcpf(fmaf(xi, xi, yq));
+                            nq->far[q][wave][pos] = (f >= near_lo) & (f <= near_hi) ? 0.f : cl*__builtin_amdgcn_rcpf(fmaf(xi, xi, yq));
                             nq->idx[q][wave][pos] = (unsigned short)(f - A0);
                         }
                         qcount[q] += npush;
@@ -699,7 +704,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                     int const f = c + r;
                     float const xi = fmaf((float)r, wr, ndcr);
                     float const xq = xi*xi;
-                    if ((rr <= reach0) & (f >= lo) & (f <= hi) & (xq < x0q) & (xq >= xq_near))
+                    if ((rr <= reach0) & (f >= lo) & (f <= hi) & (xq < x0q) & (xq >= xq_near) & ((f < near_lo) | (f > near_hi)))
                     {
                         float const den = fmaf(xq, d2r + xq, d0r)*fmaf(xi, xi, yq);
                         float const corr = cl*fmaf(1.5f, xq, -0.5f*a0)*__builtin_amdgcn_rcpf(den);
@@ -710,8 +715,8 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         }
 
         // ---- near field: |f - c| <= R, clipped to the line's window and the tile ----
-        int const lo_n = valid ? (lo > c - R ? lo : c - R) : 1;
-        int const hi_n = valid ? (hi < c + R ? hi : c + R) : 0;
+        int const lo_n = valid ? (lo > near_lo ? lo : near_lo) : 1;
+        int const hi_n = valid ? (hi < near_hi ? hi : near_hi) : 0;
         // Each row of 16 lanes is a ring of its own, so each row covers the span of ITS lines (sorted lines:
         // a row's 16 centres sit in one or two cells, the wave's 64 in two to four); the wave only shares the
         // number of steps, the longest row's.
@@ -1233,8 +1238,8 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_lane_kernel(GrtGasOpti
     }
     __syncthreads();
     // near-field radii of the cell tiles within `halo` of this tile (level-0 cells further away are far for sure)
-    int const t0 = (F0 - a.halo > 0 ? F0 - a.halo : 0) >> cell_shift;
-    int const t1 = (F1 - 1 + a.halo < nw - 1 ? F1 - 1 + a.halo : nw - 1) >> cell_shift;
+    int const t0 = (F0 - a.rcap > 0 ? F0 - a.rcap : 0) >> cell_shift;                 // (rcap: no near field is wider)
+    int const t1 = (F1 - 1 + a.rcap < nw - 1 ? F1 - 1 + a.rcap : nw - 1) >> cell_shift;
     if (tid <= t1 - t0)
     {
         long long const c1 = ((long long)(t0 + tid + 1) << cell_shift);
@@ -1491,68 +1496,79 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArg
     {
         int const fb = F0 + cb;                                             // (wave-uniform from here to the lanes' f)
         int const np = F1 - fb < 64 ? F1 - fb : 64;
-        int const fhi = fb + np - 1;
-        // shared stretches: cells [XA, E0) above, (S0, XB] below
+        int const fhi = fb + np - 1;                                        // the wave's points: fb .. fhi
+        int const fhb = fb + 63;                                            // its 64-point block: fb .. fhb (fb is a multiple of 64)
+        // Near fields are whole blocks here (near_block, first pass): a cell x above the block is near when
+        // x - fhb <= R(x's cell tile), below it when fb - x <= R -- the same answer for all 64 points.
+        // shared stretches: cells [XA, E0) above, (S0, XB] below; E0 - 1 / S0 + 1: the last cell inside EVERY lane's window
         int const E0 = (fb + fsteps < nw - 1 ? fb + fsteps : nw - 1) + 1;
-        int const XA = fhi + rmax + 1 < E0 ? fhi + rmax + 1 : E0;
+        int const XA = fhb + rmax + 1 < E0 ? fhb + rmax + 1 : E0;
         int const S0 = (fhi - fsteps > 0 ? fhi - fsteps : 0) - 1;
         int const XB = fb - rmax - 1 > S0 ? fb - rmax - 1 : S0;
-        // The shared stretches begin and end on multiples of 64 where the window has room for that: a lane's own
-        // stretches then end (going up: [.., XAs)) or begin ([E0s, ..]) on one, and an interval of n < 128 cells with
-        // one end on a multiple of 64 is popcount(n) <= 7 aligned cells; with both ends anywhere it takes up to twice that.
-        int E0s = E0, XAs = XA, S0s = S0, XBs = XB;
+        // The shared stretches end on multiples of 64 where the window has room for that: a lane's own stretch then
+        // begins on one, and an interval of n < 128 cells with one end on a multiple of 64 is popcount(n) <= 7 aligned
+        // cells; with both ends anywhere it takes up to twice that.
+        int E0s = E0, S0s = S0;
         {
-            int const ea = E0 & ~63, xa = (XA + 63) & ~63;
-            if (xa <= ea) { E0s = ea; XAs = xa; }
-            int const xb = ((XB + 1) & ~63) - 1, sa = ((S0 + 64) & ~63) - 1;
-            if (xb >= sa) { XBs = xb; S0s = sa; }
+            int const ea = E0 & ~63, sa = ((S0 + 64) & ~63) - 1;
+            if (XA <= ea) { E0s = ea; }
+            if (XB >= sa) { S0s = sa; }
         }
         int const f = fb + lane;
         double sum = 0.;
-        int const cap_near = top_level(rmax + 1);                           // every own cell is at least this far from its lane's point
-        int const cap_up = max(top_level(E0s - fhi), cap_near), cap_down = max(top_level(fb - S0s), cap_near);
-        // the far stretches hold cells of at most 64 points: |z| <= sqrt(32^2 + eta^2); four terms do where (|z|/D)^4 <= 7e-8
+        int const cap_near = top_level(rmax + 1);                           // every far cell is at least this far from every point
+        int const cap_up = max(top_level(E0s - fhb), cap_near), cap_down = max(top_level(fb - S0s), cap_near);
+        // the lanes' own stretches hold cells of at most 64 points: |z| <= sqrt(32^2 + eta^2); four terms do where (|z|/D)^4 <= 7e-8
         float const z2far = (float)(1024. + (zmax*zmax - 0.25));
-        float const dup = (float)(E0s - fhi) - 0.5f, ddn = (float)(fb - S0s) - 0.5f;
+        float const dup = (float)(E0s - fhb) - 0.5f, ddn = (float)(fb - S0s) - 0.5f;
         bool const four_up = z2far <= 2.6e-4f*dup*dup, four_down = z2far <= 2.6e-4f*ddn*ddn;
         std::integral_constant<int, K> const all_terms{};
         std::integral_constant<int, 4> const four_terms{};
-        // ---- the lane's own cells ----
+        // ---- level-0 cells that may lie in some cell tile's near field: each asks its own tile's radius, as the first
+        // pass did (the radii of neighbouring tiles differ by a few cells at most: usually nothing to do here) ----
+        for (int x = fhb + 1 + rmin; x <= fhb + rmax && x < E0s; ++x)
+        {
+            if (x - fhb > __builtin_amdgcn_readfirstlane(rtab[(x >> cell_shift) - t0]))
+            {
+                sum += (double)cell_series<K>(gm + (size_t)x*K, -__builtin_amdgcn_rcpf((float)(x - f)));
+            }
+        }
+        for (int x = fb - 1 - rmin; x >= fb - rmax && x > S0s; --x)
+        {
+            if (fb - x > __builtin_amdgcn_readfirstlane(rtab[(x >> cell_shift) - t0]))
+            {
+                sum += (double)cell_series<K>(gm + (size_t)x*K, __builtin_amdgcn_rcpf((float)(f - x)));
+            }
+        }
+        // ---- the lane's own cells: the far end of its window ----
         if (lane < np)
         {
             {
-                // (a near field nearly as wide as the window: XA = E0 cuts the shared stretch out, and the lanes whose
-                // own near field reaches beyond E0 go on cell by cell)
+                // (a near field nearly as wide as the window: the first cells of the lane's stretch may be near)
                 int const e = f + fsteps < nw - 1 ? f + fsteps : nw - 1;
-                int x = f + 1 + rmin;
-                int const xa = f + rmax < e ? f + rmax : e;
-                for (; x <= xa; ++x)
+                int x = E0s;
+                int const xm = fhb + rmax < e ? fhb + rmax : e;
+                for (; x <= xm; ++x)
                 {
-                    int const D = x - f;
-                    if (D > rtab[(x >> cell_shift) - t0])
+                    if (x - fhb > rtab[(x >> cell_shift) - t0])
                     {
-                        float const u = -__builtin_amdgcn_rcpf((float)D);
-                        sum += (double)cell_series<K>(gm + (size_t)x*K, u);
+                        sum += (double)cell_series<K>(gm + (size_t)x*K, -__builtin_amdgcn_rcpf((float)(x - f)));
                     }
                 }
-                sum += walk_up(f, x, XAs, cap_near, all_terms);
-                sum += four_up ? walk_up(f, E0s > x ? E0s : x, e + 1, cap_up, four_terms) : walk_up(f, E0s > x ? E0s : x, e + 1, cap_up, all_terms);
+                sum += four_up ? walk_up(f, x, e + 1, cap_up, four_terms) : walk_up(f, x, e + 1, cap_up, all_terms);
             }
             {
                 int const s = f - fsteps > 0 ? f - fsteps : 0;
-                int x = f - 1 - rmin;
-                int const xa = f - rmax > s ? f - rmax : s;
-                for (; x >= xa; --x)
+                int x = S0s;
+                int const xm = fb - rmax > s ? fb - rmax : s;
+                for (; x >= xm; --x)
                 {
-                    int const D = f - x;
-                    if (D > rtab[(x >> cell_shift) - t0])
+                    if (fb - x > rtab[(x >> cell_shift) - t0])
                     {
-                        float const u = __builtin_amdgcn_rcpf((float)D);
-                        sum += (double)cell_series<K>(gm + (size_t)x*K, u);
+                        sum += (double)cell_series<K>(gm + (size_t)x*K, __builtin_amdgcn_rcpf((float)(f - x)));
                     }
                 }
-                sum += walk_down(f, x, XBs, cap_near, all_terms);
-                sum += four_down ? walk_down(f, S0s < x ? S0s : x, s - 1, cap_down, four_terms) : walk_down(f, S0s < x ? S0s : x, s - 1, cap_down, all_terms);
+                sum += four_down ? walk_down(f, x, s - 1, cap_down, four_terms) : walk_down(f, x, s - 1, cap_down, all_terms);
             }
         }
         // ---- the shared stretches: one scalar walk, the lanes evaluate the series.  Cells are taken kBatch at a time:
@@ -1560,7 +1576,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArg
         // kernel ran at the scalar cache's latency (22 ms at 0.001 cm-1, no faster than round 1's form).  A batch's
         // unused places repeat the last cell with weight zero. ----
         constexpr int kBatch = 4;       // (scalar_wait takes four)
-        for (int x = XAs; x < E0s;)
+        for (int x = XA; x < E0s;)
         {
             sfloat4 c[kBatch][K/4];
             float hh[kBatch], ww[kBatch];
@@ -1570,7 +1586,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArg
             {
                 bool const live = x < E0s;
                 int const xs = live ? x : E0s - 1;
-                int const D = xs - fhi;                                     // the closest point decides
+                int const D = xs - fhb;                                     // the block's end decides
                 int const la = __builtin_ctz(xs), le = 31 - __builtin_clz(E0s - xs);
                 int const l = __builtin_amdgcn_readfirstlane(min(min(la, le), top_level(D)));
                 unsigned const off = (p2 - (p2 >> l))*K;
@@ -1589,7 +1605,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArg
                 sum += (double)(cell_series_s<K>(c[j], u)*ww[j]);
             }
         }
-        for (int x = XBs; x > S0s;)
+        for (int x = XB; x > S0s;)
         {
             sfloat4 c[kBatch][K/4];
             float hh[kBatch], ww[kBatch];
@@ -1634,13 +1650,22 @@ size_t tree_lds_bytes(int tile, int num_slots, int ntab)
 
 // windows of fewer points a side: every lane walks its own cells (gas_optics_tree_lane_kernel).  Measured, 10^6 lines,
 // lane form / wave form: 0.1 cm-1 0.22 / 0.75 ms, 0.01 cm-1 2.5 / 4.0, 0.005 cm-1 4.9 / 5.9, 0.0025 cm-1 10.1 / 9.6,
-// 0.001 cm-1 30.4 / 23.8 (coarse levels included)
-constexpr int kTreeWaveMin = 8192;
+// 0.001 cm-1 30.4 / 23.8 (coarse levels included).  The wave form comes with near fields rounded out to 64-point blocks
+// (near_block): 0.0025 cm-1 first pass 21.7 -> 24.1 ms for 7.9 -> 5.9 ms of gather, 0.001 cm-1 40.5 -> 41.6 for 16.0 -> 12.9
+constexpr int kTreeWaveMin = 16384;
 constexpr int kTreeTile = 1024;      // the gather's tile: four stretches of 64 points per wave
 
 // the gather's tile and the number of cell tiles (first-pass tiles of `tile` cells) whose near-field radius it looks up
 inline int tree_gather_tile() { return kTreeTile; }
 inline int tree_gather_ntab(int tile, int halo) { return (tree_gather_tile() + 2*halo)/tile + 3; }
+
+// windows of at least kTreeWaveMin points a side: the gather shares its walk per wave, near fields are whole 64-point blocks
+bool tree_gather_by_wave(long long fsteps)
+{
+    // GRT_TREE_WAVE_MIN in the environment (read at every launch): tests put both forms through the same cases
+    char const *env = getenv("GRT_TREE_WAVE_MIN");
+    return fsteps >= (env != NULL && atoll(env) > 0 ? atoll(env) : (long long)kTreeWaveMin);
+}
 
 // the coarse levels, one launch per level, then the gather
 template <int K>
@@ -1653,10 +1678,7 @@ void launch_tree(hipStream_t s, GrtGasOpticsArgs const &b, long long fsteps, int
                            dim3(kBlock), 0, s, b.gmom, b.gmom_stride, level_offset(b.nw, l - 1, K, b.tree_levels), n_child,
                            level_offset(b.nw, l, K, b.tree_levels), n_parent);
     }
-    // GRT_TREE_WAVE_MIN in the environment (read at every launch): tests put both forms through the same cases
-    char const *env = getenv("GRT_TREE_WAVE_MIN");
-    long long const wave_min = env != NULL && atoll(env) > 0 ? atoll(env) : kTreeWaveMin;
-    if (fsteps < wave_min)
+    if (b.near_block == 0)
     {
         int const ntab = (b.tile + 2*b.halo)/b.tile + 2;
         hipLaunchKernelGGL(gas_optics_tree_lane_kernel<K>, dim3((unsigned)((b.nw + b.tile - 1)/b.tile), b.lay.num_layers, b.ncol),
@@ -1710,7 +1732,7 @@ extern "C" int grt_gas_optics_mp_applicable(GrtGasOpticsArgs const *a)
         bool const direct = a->tile > kDirectTile;
         return shift >= 6 && a->gmom != NULL && a->tree_levels <= kMaxLevels && a->halo >= 3 && a->rcap <= a->halo
                && ((terms == kMom && !direct) || (terms == kMomWide && direct))
-               && (long long)a->halo + 4 <= fsteps && fsteps < (1ll << 30) && a->nw < (1ull << 30)
+               && (long long)a->rcap + 4 <= fsteps && a->halo <= fsteps && fsteps < (1ll << 30) && a->nw < (1ull << 30)
                && ((long long)1 << a->tree_levels) <= fsteps
                && a->gmom_stride >= level_offset(a->nw, a->tree_levels + 1, terms, a->tree_levels)
                && level_offset(a->nw, a->tree_levels + 1, terms, a->tree_levels) < 0xffffffffull
@@ -1791,6 +1813,7 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
         }
         GrtGasOpticsArgs b = *a;
         b.halo = halo;
+        b.near_block = (tree && tree_gather_by_wave(fsteps)) ? 64 : 0;
         b.mom_terms = wide ? kMomWide : kMom;
         if (!tree)
         {

@@ -1536,8 +1536,9 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
                     a->tile = cand[k];
                     while ((uint64_t)a->tile > a->nw && a->tile > 64) a->tile >>= 1;
                     a->mom_terms = a->tile > 512 ? 12 : 8;
-                    a->halo = near_halo_bound(go, ncol, w_top, a->wres, grt_gas_optics_moment_separation(a->mom_terms));
-                    a->rcap = a->halo;
+                    a->rcap = near_halo_bound(go, ncol, w_top, a->wres, grt_gas_optics_moment_separation(a->mom_terms));
+                    /* (near fields may be rounded out to 64-point blocks, GrtGasOpticsArgs.near_block; never beyond the window) */
+                    a->halo = (long long)a->rcap + 64 < fsteps ? a->rcap + 64 : (int)fsteps;
                     a->gmom_stride = grt_gas_optics_moment_floats(a->nw, a->tree_levels, a->mom_terms);
                     a->gmom = (float *)8;       /* (any non-null value: the question is about sizes) */
                     if (grt_gas_optics_mp_applicable(a))
