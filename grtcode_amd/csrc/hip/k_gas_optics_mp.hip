@@ -1373,19 +1373,22 @@ __device__ __forceinline__ float cell_series_s(sfloat4 const (&c)[K/4], float u)
     return p*(u*u);
 }
 
-// Second pass of the tree form: workgroup = (tile of grid points, layer, column); a WAVE owns 64 consecutive grid
-// points fb .. fb + 63 (one per lane) at a time and walks the cells once for all of them.  Going up from the points:
-//   [f + 1 + rmin, XA)    per lane: the level-0 cells that may lie in some cell tile's near field (each asks its
-//                         own tile's radius, as the first pass did), then small cells up to XA = f_hi + rmax + 1
-//   [XA, E0)              shared: greedy walk, level = min(alignment, room to E0, admissible for the CLOSEST of the
-//                         64 points, top level) -- a cell admissible for the closest point is admissible for all.
-//                         Everything about the walk is wave-uniform: it runs on the scalar unit, the cell's moments
-//                         come through the scalar cache (48 bytes per wave and cell instead of 48 bytes per LANE
-//                         through the texture path), and the lanes only evaluate the series.
-//                         E0 - 1 = fb + fsteps: the last cell inside EVERY lane's window (kernels.c:435-437)
-//   [E0, f + fsteps]      per lane: the <= 63 cells that are in this lane's window only
-// and the mirror image going down.  Round 1's form walked per lane: as long on the walk (ctz, clz, the admissible
-// level: ~30 instructions per cell) and on its loads (the L1 -> register path: 3 KB per wave and cell) as on the series.
+// Second pass of the tree form, windows of kTreeWaveMin points a side and more: workgroup = (tile of grid points,
+// layer, column); a WAVE owns one 64-point block fb .. fb + 63 (a point per lane) at a time and walks the cells once
+// for all of them.  Near fields are whole blocks with this gather (GrtGasOpticsArgs.near_block: the first pass took
+// every block a line's c +- R touches), so a cell is near or far for the 64 points alike.  Going up from the block:
+//   fhb + 1 + rmin .. fhb + rmax   shared: the level-0 cells that may lie in some cell tile's near field (each asks its
+//                         own tile's radius, as the first pass did); fhb = fb + 63
+//   [XA, E0s)             shared, XA = fhb + rmax + 1: greedy walk, level = min(alignment, room to E0s, admissible
+//                         for the block's last point, top level) -- what is admissible for the closest point is for
+//                         all.  Everything about the walk is wave-uniform: it runs on the scalar unit, the cells'
+//                         moments come through the scalar cache (48 bytes per wave and cell instead of 48 bytes per
+//                         LANE through the L1 -> register path), and the lanes only evaluate the series.
+//                         E0 - 1 = fb + fsteps: the last cell inside EVERY lane's window (kernels.c:435-437);
+//                         E0s: E0 rounded down to a multiple of 64
+//   [E0s, f + fsteps]     per lane: the < 128 cells that are in this lane's window but not in every lane's
+// and the mirror image going down.  Round 1's form (gas_optics_tree_lane_kernel) walks per lane: as long on the walk
+// (ctz, clz, the admissible level: ~30 instructions per cell) and on its loads (3 KB per wave and cell) as on the series.
 // cell_shift: log2 of the first pass's cell-tile size (near-field radii are per cell tile); gtile: this kernel's tile.
 template <int K>
 __global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArgs a, long long fsteps_ll, int cell_shift, int ntab,
@@ -1412,7 +1415,8 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArg
         acc[i] = out[F0 + i];
     }
     __syncthreads();
-    // near-field radii of the cell tiles within `halo` of this tile (level-0 cells further away are far for sure)
+    // near-field radii of the cell tiles within `halo` (>= the widest near field + 64) of this tile: level-0 cells
+    // further away are far for sure
     int const t0 = (F0 - a.halo > 0 ? F0 - a.halo : 0) >> cell_shift;
     int const t1 = (F1 - 1 + a.halo < nw - 1 ? F1 - 1 + a.halo : nw - 1) >> cell_shift;
     for (int t = tid; t <= t1 - t0; t += kBlock)
