@@ -205,8 +205,8 @@ def parity_of_column0(wl, fluxes, bands, kind):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cols", type=int, default=int(os.environ.get("GRT_BENCH_COLS", 8)), help="columns per GPU per step")
     ap.add_argument("--fast", type=int, default=int(os.environ.get("GRT_BENCH_FAST", 3)),
                     help="3: fused form, far wings by cell moments, two passes (production); 1: the same in one pass; "
