@@ -45,8 +45,13 @@ def record(name, payload):
     json.dump(data, open(path, "w"), indent=1)
 
 
+# GRT_PARITY_PROFILES="0,3,17" in the environment: which synthetic atmospheres (synthetic.profile) -- soak runs
+PROFILES = [int(x) for x in os.environ.get("GRT_PARITY_PROFILES", "0").split(",")]
+
+
+@pytest.mark.parametrize("prof", PROFILES)
 @pytest.mark.parametrize("physical", [False, True], ids=["survey_list", "physical_list"])
-def test_full_g1_column_against_reference(lib, device, physical):
+def test_full_g1_column_against_reference(lib, device, physical, prof):
     """One column of the bench workload at FULL size, LW + SW, production form and reference-order form."""
     kind, chk, orc = RC.checker(omp=True)
     if kind != "reference":
@@ -54,7 +59,7 @@ def test_full_g1_column_against_reference(lib, device, physical):
                     "minutes for 7.7e9 line-shape evaluations (bench.py makes the same comparison for its column 0)")
     RC.set_omp_threads(min(os.cpu_count() or 1, 16))
     wl = W.G1Workload(device, 1, physical=physical, spectral=True)
-    col = syn.profile(0, W.NUM_LEVELS)
+    col = syn.profile(prof, W.NUM_LEVELS)
     ref = {}
     for band, grid, lines, sw in (("lw", W.LW_GRID, wl.lw_lines, False), ("sw", W.SW_GRID, wl.sw_lines, True)):
         ref[band] = RC.band_column(kind, chk, orc, lib.Q, col, grid, lines, syn.tables(sw=sw), W.MOL_ORDER, MOLTAB,
@@ -69,12 +74,12 @@ def test_full_g1_column_against_reference(lib, device, physical):
     stale[1:] = np.all(r["up"][:, 1:] == r["up"][:, :-1], axis=0) & np.all(r["dn"][:, 1:] == r["dn"][:, :-1], axis=0)
     assert stale.mean() < 0.01
     want = np.concatenate([ref["lw"]["integ"], ref["sw"]["integ"]])
-    if physical:
+    if physical and prof == 0:
         assert 250.0 < want[0] < 300.0                     # outgoing longwave, W m-2
         assert 0.62 < want[10] / want[9] < 0.75            # shortwave reaching the surface / incoming
-    (gcols, keep), _ = wl.columns(0, 1)
+    (gcols, keep), _ = wl.columns(prof, 1)
     L, V = W.NUM_LEVELS - 1, W.NUM_LEVELS
-    report = {"checker": kind, "reference_fluxes_w_m2": want.tolist(), "reference_stale_sw_points": int(stale.sum())}
+    report = {"checker": kind, "profile": prof, "reference_fluxes_w_m2": want.tolist(), "reference_stale_sw_points": int(stale.sum())}
     for fast in (3, 0):
         wl.go_lw.tune(fast=fast)
         wl.go_sw.tune(fast=fast)
@@ -107,7 +112,7 @@ def test_full_g1_column_against_reference(lib, device, physical):
         assert rep["max_abs_flux_diff_w_m2"] <= b["flux"], (physical, fast, rep)
         report[f"fast{fast}"] = rep
         print(f"full G1 column, {'physical' if physical else 'survey'} list, fast={fast}: {json.dumps(rep)}")
-    record("physical_list" if physical else "survey_list", report)
+    record(("physical_list" if physical else "survey_list") + ("" if prof == 0 else f"_profile{prof}"), report)
     wl.destroy()
 
 
