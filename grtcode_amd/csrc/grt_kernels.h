@@ -75,8 +75,10 @@ typedef struct GrtGasOpticsArgs
     int fast;                 /* 0: reference operation order; 1: fused form, far wings by cell moments
                                  where the window is wide enough; 2: fused form, every point in the ring;
                                  3: as 1 in two passes (cell moments through gmom) */
-    float *gmom;              /* two-pass form only: [ncol][L] blocks of gmom_stride floats; level 0 = [nw][8] cell
-                                 moments, then (tree_levels > 0) levels 1..tree_levels, level l = [ceil(nw/2^l)][8] */
+    float *gmom;              /* two-pass form only: [ncol][L] blocks of gmom_stride floats; level 0 = [nw][mom_terms] cell
+                                 moments, then (tree_levels > 0) levels 1..tree_levels: level l holds ceil(nw/2^l) cells and
+                                 starts where nw_pad*(2 - 2^(1-l)) cells end, nw_pad = nw rounded up to a multiple of
+                                 2^tree_levels (grt_gas_optics_moment_floats sizes a block) */
     uint64_t gmom_stride;
     int halo;                 /* two-pass form: grid points either side of a cell tile the first pass may add to
                                  (the window's half-width, or -- tree form -- a bound on the near-field radius) */
