@@ -206,20 +206,26 @@ __device__ __forceinline__ VoigtLimits voigt_limits(float y)
 
 // 0: regions 1-3 (one rational function of x^2), 1: region 4 inner sums (|x| <= XLIM4), 2: region 4
 // outer sums.  Same tests, same order as voigt_near below.
-template <bool FAST>
+// SPLIT: region 3 (one rational function with ten polynomials of y) is a class of its own, 3, apart from regions 1-2.
+template <bool FAST, bool SPLIT = false>
 __device__ __forceinline__ int voigt_class(float xi, float y)
 {
     VoigtLimits const l = voigt_limits<FAST>(y);
     float const abx = fabsf(xi);
-    if ((abx >= l.xlim1) | (abx >= l.xlim2) | (abx < l.xlim3))
+    if ((abx >= l.xlim1) | (abx >= l.xlim2))
     {
         return 0;
+    }
+    if (abx < l.xlim3)
+    {
+        return SPLIT ? 3 : 0;
     }
     return abx <= l.xlim4 ? 1 : 2;
 }
 
 // ONLY = -1: any region; 0 / 1 / 2: the caller has sorted its points with voigt_class and only that
-// class's code is generated (no divergence inside a batch of 64 points).
+// class's code is generated (no divergence inside a batch of 64 points); with voigt_class<., true>: 4 = class 0 without
+// region 3 (regions 1-2), 3 = region 3.
 template <bool FAST, int ONLY = -1>
 __device__ __forceinline__ double voigt_near(float xi, float y)
 {
@@ -227,7 +233,7 @@ __device__ __forceinline__ double voigt_near(float xi, float y)
     float const abx = fabsf(xi);
     float const xq = abx*abx;
     VoigtLimits lim = {0.f, 0.f, 0.f, 0.f};
-    if (ONLY <= 0)
+    if (ONLY <= 0 || ONLY == 4)
     {
         lim = voigt_limits<FAST>(y);
     }
@@ -236,7 +242,7 @@ __device__ __forceinline__ double voigt_near(float xi, float y)
         lim.xlim4 = 18.1f*y + 1.65f;
     }
     float const xlim1 = lim.xlim1, xlim2 = lim.xlim2, xlim3 = lim.xlim3, xlim4 = lim.xlim4;
-    if (ONLY <= 0 && abx >= xlim1)
+    if ((ONLY <= 0 || ONLY == 4) && abx >= xlim1)
     {
         float const a0 = (float)((double)yq + 0.5);
         float const d0 = a0*a0;
@@ -244,7 +250,7 @@ __device__ __forceinline__ double voigt_near(float xi, float y)
         float const d = quot<FAST>(kRsqrpi, d0 + xq*(d2 + xq));
         return (double)(d*y*(a0 + xq));
     }
-    if (ONLY <= 0 && abx >= xlim2)
+    if (ONLY == 4 || (ONLY <= 0 && abx >= xlim2))
     {
         float const h0 = 0.5625f + yq*(4.5f + yq*(10.5f + yq*(6.0f + yq)));
         float const h2 = -4.5f + yq*(9.0f + yq*(6.0f + yq*4.0f));
@@ -256,7 +262,7 @@ __device__ __forceinline__ double voigt_near(float xi, float y)
         float const d = quot<FAST>(kRsqrpi, h0 + xq*(h2 + xq*(h4 + xq*(h6 + xq))));
         return (double)(d*y*(e0 + xq*(e2 + xq*(e4 + xq))));
     }
-    if (ONLY == 0 || (ONLY < 0 && abx < xlim3))
+    if (ONLY == 0 || ONLY == 3 || (ONLY < 0 && abx < xlim3))
     {
         float const z0 = 272.1014f + y*(1280.829f + y*(2802.870f + y*(3764.966f
                          + y*(3447.629f + y*(2256.981f + y*(1074.409f + y*(369.1989f

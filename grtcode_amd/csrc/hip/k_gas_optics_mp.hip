@@ -114,24 +114,31 @@ __device__ __forceinline__ float row_sum_transposed(float const (&m)[8], bool b3
 // Near-centre points (Humlicek regions 1-4 inside XLIM1) wait in per-wave LDS queues, one queue per
 // class of formula (voigt_class), so that a batch of 64 points runs ONE formula with all lanes busy:
 // evaluated unsorted, a batch pays for every formula present in it (~4x the work of the usual mix).
+// Three classes (regions 1-3 | region 4 inner sums | region 4 outer sums) in the tree form, which is short of LDS; four in
+// the one-level forms, region 3 apart from regions 1-2: a batch of class 0 used to run both formulas whenever one lane
+// wanted region 3 -- ten polynomials of y for a handful of points (1 cm-1 shortwave launch 14.8 -> 14.4 ms).
 constexpr int kClasses = 3;
-// entries per (class, wave): batches of 64 leave at most 63 behind.  96 where lines are dense (1 cm-1: 64 and 128 both
-// measured slower); 64 in the tree form, whose first pass is short of LDS (0.001 cm-1: four workgroups per CU instead
-// of three, 42 -> 39 ms) and whose pushes mostly come as full batches of one class
-constexpr int kMpQueue = 96;
+constexpr int kClassesSplit = 4;
+// entries per (class, wave): batches of 64 leave at most 63 behind.  88 (80 ... 96 measured the same, 104 costs the
+// fourth workgroup of a CU: 14.4 -> 16.6 ms) where lines are dense; 64 in the tree form, whose first pass is short of
+// LDS (0.001 cm-1: four workgroups per CU instead of three, 42 -> 39 ms) and whose pushes mostly come as full batches
+constexpr int kMpQueue = 88;
 constexpr int kMpQueueTree = 64;
 
-template <int CAP>
+template <int CAP, int NCLS>
 struct MpQueue
 {
     static constexpr int capacity = CAP;
-    float amp[kClasses][kWaves][CAP];      // S(T)*N_s of the line (fp32: 6e-8 of that line's value)
-    float xi[kClasses][kWaves][CAP];
-    float y[kClasses][kWaves][CAP];
-    float repwid[kClasses][kWaves][CAP];
-    float far[kClasses][kWaves][CAP];      // the Lorentzian the moments supply at this point (beyond R), to be taken back
-    unsigned short idx[kClasses][kWaves][CAP];   // accumulator index f - F0
+    static constexpr int classes = NCLS;
+    float amp[NCLS][kWaves][CAP];      // S(T)*N_s of the line (fp32: 6e-8 of that line's value)
+    float xi[NCLS][kWaves][CAP];
+    float y[NCLS][kWaves][CAP];
+    float repwid[NCLS][kWaves][CAP];
+    unsigned short idx[NCLS][kWaves][CAP];   // accumulator index f - F0 (< 2^15); top bit: beyond the near field, where the
+                                             // moments supply the Lorentzian -- to be taken back
 };
+using MpQueueFlat = MpQueue<kMpQueue, kClassesSplit>;
+using MpQueueTree = MpQueue<kMpQueueTree, kClasses>;
 
 // (a call, not inline code: the lines that need it -- exponents that are not hundredths -- are rare, and its registers
 // would count against every wave)
@@ -280,15 +287,17 @@ __device__ __forceinline__ void shift_pair(float const (&lo)[K], float const (&h
     }
 }
 
-template <int CLASS, typename Queue>
+// CLASS: the queue; ONLY: the formula(s) voigt_near generates for it
+template <int CLASS, int ONLY, typename Queue>
 __device__ __forceinline__ void drain_class(double *acc, Queue const *q, int wave, int first, int count, int lane)
 {
     for (int i = first + lane; i < first + count; i += 64)
     {
-        float const rep = q->repwid[CLASS][wave][i];
-        double const k = (double)(kRsqrpi*rep)*voigt_near<true, CLASS>(q->xi[CLASS][wave][i], q->y[CLASS][wave][i])
-                         - (double)q->far[CLASS][wave][i];                                  // RFM_voigt.c:278
-        GRT_ACC_ADD(&acc[q->idx[CLASS][wave][i]], (double)q->amp[CLASS][wave][i]*k);        // kernels.c:459
+        float const rep = q->repwid[CLASS][wave][i], xi = q->xi[CLASS][wave][i], y = q->y[CLASS][wave][i];
+        unsigned const idx = q->idx[CLASS][wave][i];
+        float const far = (idx & 0x8000u) ? ((rep*y)*0.318309886f)*__builtin_amdgcn_rcpf(fmaf(xi, xi, y*y)) : 0.f;
+        double const k = (double)(kRsqrpi*rep)*voigt_near<true, ONLY>(xi, y) - (double)far;   // RFM_voigt.c:278
+        GRT_ACC_ADD(&acc[idx & 0x7fffu], (double)q->amp[CLASS][wave][i]*k);                   // kernels.c:459
     }
 }
 
@@ -309,7 +318,8 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int const fsteps = (int)fsteps_ll;
     double *acc = reinterpret_cast<double *>(smem);                               // [nacc]
-    using Queue = MpQueue<TREE ? kMpQueueTree : kMpQueue>;
+    using Queue = std::conditional_t<TREE, MpQueueTree, MpQueueFlat>;
+    constexpr bool kSplit = Queue::classes == kClassesSplit;
     Queue *nq = reinterpret_cast<Queue *>(smem + sizeof(double)*nacc);
     long long *range = reinterpret_cast<long long *>(nq + 1);                     // [2]
     double *ms_l = reinterpret_cast<double *>(range + 2);                         // [num_slots][4]
@@ -397,13 +407,14 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         }
     };
 
-    int qcount[kClasses] = {0, 0, 0};    // wave-uniform
+    int qcount[Queue::classes] = {};     // wave-uniform
     auto drain = [&](int cls, int first, int count)
     {
         {
-            if (cls == 0) drain_class<0>(acc, nq, wave, first, count, lane);
-            else if (cls == 1) drain_class<1>(acc, nq, wave, first, count, lane);
-            else drain_class<2>(acc, nq, wave, first, count, lane);
+            if (cls == 0) drain_class<0, kSplit ? 4 : 0>(acc, nq, wave, first, count, lane);
+            else if (cls == 1) drain_class<1, 1>(acc, nq, wave, first, count, lane);
+            else if (cls == 2) drain_class<2, 2>(acc, nq, wave, first, count, lane);
+            else if constexpr (kSplit) drain_class<3, 3>(acc, nq, wave, first, count, lane);
         }
     };
 
@@ -648,9 +659,9 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                 {
                     double const dwno = (double)s*a.wres + a.w0;                       // kernels.c:438
                     float const xr = voigt_x(dwno, f - s, a.wres, wnoadj, repwid);     // the reference's x
-                    int const cls = near ? voigt_class<true>(xr, y) : -1;
+                    int const cls = near ? voigt_class<true, kSplit>(xr, y) : -1;
 #pragma unroll
-                    for (int q = 0; q < kClasses; ++q)
+                    for (int q = 0; q < Queue::classes; ++q)
                     {
                         unsigned long long const mk = __ballot(cls == q);
                         if (mk == 0ull)
@@ -674,9 +685,8 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                             // inside the near field the point is the queue's alone (the ring skips it: at a grid
                             // point on a narrow line's centre the Lorentzian is hundreds of times the true value,
                             // nothing to put through fp32 partial sums); beyond it the moments supply the
-                            // Lorentzian there (to ~1e-8), to be taken back
-                            nq->far[q][wave][pos] = (f >= near_lo) & (f <= near_hi) ? 0.f : cl*__builtin_amdgcn_rcpf(fmaf(xi, xi, yq));
-                            nq->idx[q][wave][pos] = (unsigned short)(f - A0);
+                            // Lorentzian there (to ~1e-8), to be taken back when the entry is evaluated (top bit)
+                            nq->idx[q][wave][pos] = (unsigned short)((f - A0) | ((f >= near_lo) & (f <= near_hi) ? 0 : 0x8000));
                         }
                         qcount[q] += npush;
                         if (qcount[q] >= 64)
@@ -828,7 +838,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         }
     }
 #pragma unroll
-    for (int q = 0; q < kClasses; ++q)
+    for (int q = 0; q < Queue::classes; ++q)
     {
         drain(q, 0, qcount[q]);
     }
@@ -1698,7 +1708,7 @@ void launch_tree(hipStream_t s, GrtGasOpticsArgs const &b, long long fsteps, int
 // coarser cells in two LDS buffers (tile/2 + tile/4 cells of twelve moments) where the accumulator was
 size_t mp_lds_bytes(int nacc, int ncell, int fsteps, int num_slots, bool tree = false, int subtree_tile = 0)
 {
-    size_t const main_loop = sizeof(double)*nacc + (tree ? sizeof(MpQueue<kMpQueueTree>) : sizeof(MpQueue<kMpQueue>)) + 2*sizeof(long long) + sizeof(double)*(num_slots*(4 + GRT_MAX_ISO) + kPowTable)
+    size_t const main_loop = sizeof(double)*nacc + (tree ? sizeof(MpQueueTree) : sizeof(MpQueueFlat)) + 2*sizeof(long long) + sizeof(double)*(num_slots*(4 + GRT_MAX_ISO) + kPowTable)
                              + sizeof(float)*((size_t)kMom*ncell + fsteps + 1);
     size_t const subtree = sizeof(float)*kMomWide*((size_t)(subtree_tile >> 1) + (size_t)(subtree_tile >> 2));
     return main_loop > subtree ? main_loop : subtree;
@@ -1740,7 +1750,7 @@ extern "C" int grt_gas_optics_mp_applicable(GrtGasOpticsArgs const *a)
                && ((long long)1 << a->tree_levels) <= fsteps
                && a->gmom_stride >= level_offset(a->nw, a->tree_levels + 1, terms, a->tree_levels)
                && level_offset(a->nw, a->tree_levels + 1, terms, a->tree_levels) < 0xffffffffull
-               && a->tile + 2*a->halo <= 65535
+               && a->tile + 2*a->halo <= 32767
                && mp_lds_bytes(a->tile + 2*a->halo, direct ? 0 : a->tile, 0, a->lay.num_slots, true, direct ? a->tile : 0) <= 64*1024
                && tree_lds_bytes(tree_gather_tile(), a->lay.num_slots, tree_gather_ntab(a->tile, a->halo)) <= 64*1024
                && tree_lds_bytes(a->tile, a->lay.num_slots, (a->tile + 2*a->halo)/a->tile + 2) <= 64*1024;
