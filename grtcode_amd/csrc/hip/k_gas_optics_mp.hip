@@ -114,9 +114,9 @@ __device__ __forceinline__ float row_sum_transposed(float const (&m)[8], bool b3
 // Near-centre points (Humlicek regions 1-4 inside XLIM1) wait in per-wave LDS queues, one queue per
 // class of formula (voigt_class), so that a batch of 64 points runs ONE formula with all lanes busy:
 // evaluated unsorted, a batch pays for every formula present in it (~4x the work of the usual mix).
-// Three classes (regions 1-3 | region 4 inner sums | region 4 outer sums) in the tree form, which is short of LDS; four in
-// the one-level forms, region 3 apart from regions 1-2: a batch of class 0 used to run both formulas whenever one lane
-// wanted region 3 -- ten polynomials of y for a handful of points (1 cm-1 shortwave launch 14.8 -> 14.4 ms).
+// Four classes: regions 1-2 | region 4 inner sums | region 4 outer sums | region 3.  Region 3 used to share class 0: a
+// batch then ran both formulas whenever one lane wanted region 3 -- ten polynomials of y for a handful of points
+// (1 cm-1 shortwave launch 14.8 -> 14.4 ms).  Entries are 14 bytes so that four queues fit where three of 22 did.
 constexpr int kClasses = 3;
 constexpr int kClassesSplit = 4;
 // entries per (class, wave): batches of 64 leave at most 63 behind.  88 (80 ... 96 measured the same, 104 costs the
@@ -130,15 +130,14 @@ struct MpQueue
 {
     static constexpr int capacity = CAP;
     static constexpr int classes = NCLS;
-    float amp[NCLS][kWaves][CAP];      // S(T)*N_s of the line (fp32: 6e-8 of that line's value)
+    float amp[NCLS][kWaves][CAP];      // S(T)*N_s of the line times RSQRPI*REPWID (RFM_voigt.c:278), rounded to fp32 once
     float xi[NCLS][kWaves][CAP];
     float y[NCLS][kWaves][CAP];
-    float repwid[NCLS][kWaves][CAP];
     unsigned short idx[NCLS][kWaves][CAP];   // accumulator index f - F0 (< 2^15); top bit: beyond the near field, where the
                                              // moments supply the Lorentzian -- to be taken back
 };
 using MpQueueFlat = MpQueue<kMpQueue, kClassesSplit>;
-using MpQueueTree = MpQueue<kMpQueueTree, kClasses>;
+using MpQueueTree = MpQueue<kMpQueueTree, kClassesSplit>;
 
 // (a call, not inline code: the lines that need it -- exponents that are not hundredths -- are rare, and its registers
 // would count against every wave)
@@ -293,10 +292,11 @@ __device__ __forceinline__ void drain_class(double *acc, Queue const *q, int wav
 {
     for (int i = first + lane; i < first + count; i += 64)
     {
-        float const rep = q->repwid[CLASS][wave][i], xi = q->xi[CLASS][wave][i], y = q->y[CLASS][wave][i];
+        float const xi = q->xi[CLASS][wave][i], y = q->y[CLASS][wave][i];
         unsigned const idx = q->idx[CLASS][wave][i];
-        float const far = (idx & 0x8000u) ? ((rep*y)*0.318309886f)*__builtin_amdgcn_rcpf(fmaf(xi, xi, y*y)) : 0.f;
-        double const k = (double)(kRsqrpi*rep)*voigt_near<true, ONLY>(xi, y) - (double)far;   // RFM_voigt.c:278
+        // the Lorentzian in the same units (RFM_voigt.c:170: Y RSQRPI/(X^2 + Y^2) before the scaling of :278)
+        float const far = (idx & 0x8000u) ? (y*kRsqrpi)*__builtin_amdgcn_rcpf(fmaf(xi, xi, y*y)) : 0.f;
+        double const k = voigt_near<true, ONLY>(xi, y) - (double)far;
         GRT_ACC_ADD(&acc[idx & 0x7fffu], (double)q->amp[CLASS][wave][i]*k);                   // kernels.c:459
     }
 }
@@ -678,10 +678,9 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                         {
                             int const pos = qcount[q] + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32),
                                             __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-                            nq->amp[q][wave][pos] = (float)amp;
+                            nq->amp[q][wave][pos] = (float)(amp*(double)(kRsqrpi*repwid));
                             nq->xi[q][wave][pos] = xr;
                             nq->y[q][wave][pos] = y;
-                            nq->repwid[q][wave][pos] = repwid;
                             // inside the near field the point is the queue's alone (the ring skips it: at a grid
                             // point on a narrow line's centre the Lorentzian is hundreds of times the true value,
                             // nothing to put through fp32 partial sums); beyond it the moments supply the
