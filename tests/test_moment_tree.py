@@ -155,3 +155,102 @@ def test_window_edges_are_exact():
         want = exact_far_field(f, c, delta, eta, A, fsteps, 3)
         assert got == pytest.approx(want, rel=2e-7, abs=1e-300)
         assert (got == 0.0) == (want == 0.0)
+
+
+# ---- the wave-shared form of the gather (windows of 16 384 points and more): near fields are whole 64-point blocks ---- #
+def block_far_field(fb, levels, nw, fsteps, R, eta_max, dtype):
+    """gas_optics_tree_kernel in numpy for the block fb .. fb + 63: one walk over the cells that lie inside EVERY point's
+    window and beyond the block's near field (level chosen for the block's closest point), then every point's own cells
+    at the far end of its window.  Returns the 64 far fields (points beyond the grid: 0)."""
+    lmax, sep = len(levels) - 1, SEP[levels[0].shape[1]]
+    pts = [f for f in range(fb, fb + 64) if f < nw]
+    fhi, fhb = pts[-1], fb + 63
+    out = {f: 0.0 for f in pts}
+
+    def level(D, align, room):
+        return min(admissible_level(D - 0.5, eta_max, sep), align, room.bit_length() - 1, lmax)
+
+    # up: shared [XA, E0s), own [E0s, f + fsteps]
+    E0 = min(fb + fsteps, nw - 1) + 1
+    XA = min(fhb + R + 1, E0)
+    E0s = E0 & ~63 if XA <= (E0 & ~63) else E0
+    x = XA
+    while x < E0s:
+        l = level(x - fhb, (x & -x).bit_length() - 1, E0s - x)
+        h = 1 << l
+        for f in pts:
+            out[f] += cell_value(levels[l][x >> l], h, -((x - f) - 0.5 + h / 2), dtype)
+        x += h
+    for f in pts:
+        e, x = min(f + fsteps, nw - 1), max(E0s, XA)
+        while x <= e:
+            l = level(x - f, (x & -x).bit_length() - 1, e - x + 1)
+            h = 1 << l
+            out[f] += cell_value(levels[l][x >> l], h, -((x - f) - 0.5 + h / 2), dtype)
+            x += h
+    # down: shared (S0s, XB], own [f - fsteps, S0s]
+    S0 = max(fhi - fsteps, 0) - 1
+    XB = max(fb - R - 1, S0)
+    sa = ((S0 + 64) & ~63) - 1
+    S0s = sa if XB >= sa else S0
+    x = XB
+    while x > S0s:
+        l = level(fb - x, ((x + 1) & -(x + 1)).bit_length() - 1, x - S0s)
+        h = 1 << l
+        for f in pts:
+            out[f] += cell_value(levels[l][x >> l], h, (f - x) - 0.5 + h / 2, dtype)
+        x -= h
+    for f in pts:
+        s, x = max(f - fsteps, 0), min(S0s, XB)
+        while x >= s:
+            l = level(f - x, ((x + 1) & -(x + 1)).bit_length() - 1, x - s + 1)
+            h = 1 << l
+            out[f] += cell_value(levels[l][x >> l], h, (f - x) - 0.5 + h / 2, dtype)
+            x -= h
+    return out
+
+
+def exact_far_field_blocks(f, c, delta, eta, A, fsteps, R):
+    """The window of kernels.c:435-437 minus the block near field: every 64-point block that c +- R touches."""
+    r = f - c
+    near = (f >= ((c - R) & ~63)) & (f <= ((c + R) | 63))
+    sel = (np.abs(r) <= fsteps) & ~near
+    return float(np.sum(A[sel] / ((r[sel] - delta[sel]) ** 2 + eta[sel] ** 2)))
+
+
+@pytest.mark.parametrize("K", [8, 12])
+@pytest.mark.parametrize("eta_max,fsteps,nw", [(0.02, 1000, 5000), (40.0, 2500, 9000), (0.3, 333, 1500), (3.0, 700, 1403)])
+def test_wave_shared_walk_with_block_near_fields_equals_the_windowed_sum(eta_max, fsteps, nw, K):
+    rng = np.random.default_rng(int(eta_max * 100) + fsteps + K)
+    n = nw // 3
+    c = np.sort(rng.integers(0, nw, n))
+    delta = rng.uniform(-0.5, 0.5, n)
+    eta = eta_max * rng.uniform(0.05, 1, n)
+    A = 10.0 ** rng.uniform(-4, 0, n) * eta
+    R = radius(eta_max, K)
+    nlev = int(math.log2(fsteps)) - 1
+    blocks = sorted({0, 64, (nw // 2) & ~63, ((nw - 1) & ~63), (fsteps & ~63), ((nw - fsteps) & ~63)} |
+                    {int(b) & ~63 for b in rng.integers(0, nw, 4)})
+    scale = max(exact_far_field(int(f), c, delta, eta, A, fsteps, -1) for f in range(0, nw, 97))
+    levels = build_levels(level0_moments(nw, c, delta, eta, A, np.float64, K), nlev, np.float64)
+    worst = 0.0
+    for fb in blocks:
+        got = block_far_field(fb, levels, nw, fsteps, R, eta_max, np.float64)
+        for f, v in got.items():
+            want = exact_far_field_blocks(f, c, delta, eta, A, fsteps, R)
+            worst = max(worst, abs(v - want) / scale)
+    assert worst < 1.5e-7, worst
+
+
+def test_wave_shared_walk_keeps_the_window_edges_exact():
+    """One strong line: with block near fields and a shared walk every point still sees it exactly when it is within
+    fsteps of it (kernels.c:435-437) and outside the blocks its near field touches."""
+    nw, fsteps, cpos, R = 6000, 1000, 2771, 3
+    c, delta, eta, A = np.array([cpos]), np.array([0.37]), np.array([0.01]), np.array([1.0])
+    levels = build_levels(level0_moments(nw, c, delta, eta, A, np.float64), 8, np.float64)
+    for fb in ((cpos - fsteps - 1) & ~63, (cpos + fsteps) & ~63, cpos & ~63, (cpos & ~63) + 64, (cpos & ~63) - 64):
+        got = block_far_field(fb, levels, nw, fsteps, R, 0.01, np.float64)
+        for f, v in got.items():
+            want = exact_far_field_blocks(f, c, delta, eta, A, fsteps, R)
+            assert v == pytest.approx(want, rel=2e-7, abs=1e-300)
+            assert (v == 0.0) == (want == 0.0), (fb, f)
