@@ -187,8 +187,9 @@ typedef struct GrtSwArgs
     double const *solar;            /* [nw] */
     double *flux_up, *flux_down; uint64_t flux_stride;   /* NULL in the fused form */
     int user_level;
-    /* fused clear-sky form, as in GrtLwArgs; the downward-beam reflectances of the first sweep are parked in
-       park [ncol][2][V][nw] instead of the output rows */
+    /* fused clear-sky form, as in GrtLwArgs; the first sweep parks, per column, its downward-beam reflectances
+       (2 V rows of nw) and the five properties of every layer (5 L rows) in park [ncol][2 V + 5 L][nw]: the second
+       sweep reads the properties back instead of working them out again */
     double const *tau_gas, *n_layer;
     double w0;
     double *partials, *park;

@@ -12,9 +12,11 @@
 //   sweep 2 (TOA -> surface): layer R/T are recomputed (same inputs, same values), the
 //     upward-beam reflectance of :299-306 is carried in registers, and each parked
 //     pair is consumed and overwritten by the final fluxes of :308-329,401-405,447-451.
-// Every expression keeps the reference's evaluation order, so results are identical.  Measured: the
-// kernel is fp64-VALU-bound (two delta-Eddington solutions per layer and sweep: 70 000 instructions per wave), not
-// HBM-bound.  sw_kernel<true> is the fused form of the production pipeline.
+// Every expression keeps the reference's evaluation order, so results are identical.  Measured: in that
+// form the kernel is fp64-VALU-bound (two delta-Eddington solutions per layer and sweep: 70 000 instructions per wave),
+// not HBM-bound.  sw_kernel<true>, the fused form of the production pipeline, therefore trades bytes for flops: its first
+// sweep parks the five properties of every layer with the reflectances and its second sweep reads them back (the same
+// doubles: identical fluxes) -- 0.69 instead of 1.04 ms for 8 columns, at 4.2 TB/s.
 // The in-kernel range checks of the reference are no-ops on device builds
 // (debug.h:105-116) and are not restated.
 #include <hip/hip_runtime.h>
@@ -163,8 +165,13 @@ __global__ __launch_bounds__(kBlock) void sw_kernel(GrtSwArgs a)
     double const mu_dir = a.mu_dir[col];
     double const mu_dif = a.mu_dif;
     // where the first sweep parks R_dir_downward / R_dif_downward of every level
-    double *fu = FUSED ? a.park + ((uint64_t)col*2 + 0)*(uint64_t)V*nw + ii : a.flux_up + (uint64_t)col*a.flux_stride + ii;
-    double *fd = FUSED ? a.park + ((uint64_t)col*2 + 1)*(uint64_t)V*nw + ii : a.flux_down + (uint64_t)col*a.flux_stride + ii;
+    uint64_t const park_rows = 2*(uint64_t)V + 5*(uint64_t)L;
+    double *fu = FUSED ? a.park + ((uint64_t)col*park_rows + 0)*nw + ii : a.flux_up + (uint64_t)col*a.flux_stride + ii;
+    double *fd = FUSED ? a.park + ((uint64_t)col*park_rows + V)*nw + ii : a.flux_down + (uint64_t)col*a.flux_stride + ii;
+    // fused form: the five properties of layer j, rows 2 V + 5 j .. + 4 of the column's block -- written by the first
+    // sweep, read by the second (the same values as working them out again: two Eddington solutions, 6 exp and ~13
+    // divisions a layer, which is what this kernel's time is made of)
+    double *pp = FUSED ? a.park + ((uint64_t)col*park_rows + 2*(uint64_t)V)*nw + ii : nullptr;
     int const user = a.user_level;
     double out[6] = {0., 0., 0., 0., 0., 0.};     // up TOA, up surface, up user, down TOA, down surface, down user
 
@@ -189,6 +196,11 @@ __global__ __launch_bounds__(kBlock) void sw_kernel(GrtSwArgs a)
     {
         uint64_t const o = (uint64_t)j*nw;
         LayerProps const p = props_of(j);
+        if (FUSED)
+        {
+            double *q = pp + (uint64_t)(5*j)*nw;
+            q[0] = p.Rdir; q[nw] = p.Tdir; q[2*nw] = p.Tpure; q[3*nw] = p.Rdif; q[4*nw] = p.Tdif;
+        }
         double const A = p.Tpure;
         double const B = 1./(1. - p.Rdif*Rdif_dn);
         double const ndir = p.Rdir + (A*Rdir_dn + (p.Tdir - A)*Rdif_dn)*p.Tdif*B;
@@ -226,7 +238,16 @@ __global__ __launch_bounds__(kBlock) void sw_kernel(GrtSwArgs a)
     double Rup_prev = 0.;     // R_dif_upward[lev-1]
     for (int lev = 1; lev < V; ++lev)
     {
-        LayerProps const p = props_of(lev - 1);   // layer lev-1
+        LayerProps p;                              // layer lev-1
+        if (FUSED)
+        {
+            double const *q = pp + (uint64_t)(5*(lev - 1))*nw;
+            p.Rdir = q[0]; p.Tdir = q[nw]; p.Tpure = q[2*nw]; p.Rdif = q[3*nw]; p.Tdif = q[4*nw];
+        }
+        else
+        {
+            p = props_of(lev - 1);
+        }
         // R_dif_upward[lev-1]  (:299-306)
         Rup_prev2 = Rup_prev;
         if (lev == 1)

@@ -30,7 +30,7 @@ typedef struct GrtBand
     double **rows_d;       /* [cols][6] device row pointers for the trapezoid */
     double *zero_row;      /* [n] zeros: stands in for the user level when there is none */
     /* fused form (no spectra kept): */
-    double *park;          /* shortwave: [cols][2][V][n] first-sweep reflectances */
+    double *park;          /* shortwave: [cols][2 V + 5 L][n] first-sweep reflectances and layer properties */
     double *partials;      /* [cols][6][nblocks] trapezoid partial sums */
     unsigned nblocks;
 } GrtBand;
@@ -68,11 +68,13 @@ static int band_alloc(GrtPipeline_t *p, GrtBand *b, GasOptics_t *gas)
         /* fused form: tau_gas, (shortwave) the parked reflectances, the partial sums */
         b->nblocks = grt_solver_blocks(b->n);
         int const sw = b == &p->band[1];
-        size_t const park = sw ? 2*flx : 0, part = sizeof(double)*C*6*b->nblocks;
+        /* (shortwave: 2 V rows of reflectances and 5 L rows of layer properties per column, k_shortwave.hip) */
+        size_t const park_rows = sw ? 2*V + 5*L : 0;
+        size_t const park = sizeof(double)*C*park_rows*b->n, part = sizeof(double)*C*6*b->nblocks;
         GRT_TRY(grt_dev_alloc(p->device, &blk, opt + park + part));
         b->tau_gas = blk;
         b->park = sw ? b->tau_gas + C*L*b->n : NULL;
-        b->partials = b->tau_gas + C*L*b->n + (sw ? 2*C*V*b->n : 0);
+        b->partials = b->tau_gas + C*L*b->n + C*park_rows*b->n;
         return GRTCODE_SUCCESS;
     }
     GRT_TRY(grt_dev_alloc(p->device, &blk, 4*opt + 2*flx + sizeof(double)*b->n));
