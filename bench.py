@@ -389,8 +389,9 @@ def main():
         }
         # the solvers (fused form: Rayleigh + optics combination + solver + spectral trapezoid in one kernel).  HBM view
         # with SURVEY a19/a20's algorithmic bytes of the materialised interface (1 944 / 2 440 B per wavenumber) and with
-        # what the fused kernels must move (tau_gas once + the per-wavenumber tables); the shortwave kernel is
-        # fp64-VALU work (two delta-Eddington solutions per layer and sweep: ~27 divisions, 14 exp)
+        # what the fused kernels must move (tau_gas once + the per-wavenumber tables); the shortwave kernel's arithmetic
+        # (two delta-Eddington solutions per layer: ~13 divisions, 6 exp in fp64) is done once, in the first sweep, which
+        # parks the five properties of every layer for the second: `traffic_with_park`
         sol = {}
         for name, tag, n, surv, fused_b in (("lw", 3, n_lw, 16.0 * L + 8 + 16.0 * V, 8.0 * L + 8), ("sw", 4, n_sw, 24.0 * L + 24 + 16.0 * V, 8.0 * L + 24)):
             if ms[tag][1]:
@@ -400,7 +401,13 @@ def main():
                              "frac_hbm_survey": surv * n * cols_launch / t / 1e9 / HBM_PEAK_GBS,
                              "compulsory_bytes_fused": fused_b * n * cols_launch, "achieved_gb_per_s_fused": fused_b * n * cols_launch / t / 1e9,
                              "traffic": solver_traffic.get(name + "_kernel")}
-        line["roofline_solvers"] = dict(sol, bound="valu_fp64 (shortwave), latency (longwave: 26 000 threads)", peak=HBM_PEAK_GBS, unit="GB/s")
+                if name == "sw":
+                    # tau_gas once, albedo + solar, reflectances (2 V rows) and layer properties (5 L rows) written and read back
+                    park_b = (8.0 * L + 24 + 2 * 8.0 * (2 * V + 5 * L)) * n * cols_launch
+                    sol[name].update({"traffic_with_park": park_b, "achieved_gb_per_s_with_park": park_b / t / 1e9,
+                                      "frac_hbm_with_park": park_b / t / 1e9 / HBM_PEAK_GBS})
+        line["roofline_solvers"] = dict(sol, bound="hbm (shortwave: layer properties parked by the first sweep, read back by the second); "
+                                                   "latency (longwave: 26 000 threads)", peak=HBM_PEAK_GBS, unit="GB/s")
         if world == 1 and not args.no_extras:
             # what an unchanged caller of calculate_optical_depth gets: the reference-order form (fast = 0)
             wl.go_lw.tune(fast=0, tile=args.tile, nslice=args.lw_nslice)

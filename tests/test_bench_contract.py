@@ -45,7 +45,8 @@ def test_bench_line_carries_its_own_parity_against_the_reference():
 def test_bench_line_reports_solvers_fine_grids_and_the_unchanged_callers_rate():
     line = load("r2_bench_line.json")
     s = line["roofline_solvers"]
-    assert s["lw"]["avg_launch_ms"] > 0 and s["sw"]["avg_launch_ms"] > 0 and "valu_fp64" in s["bound"]
+    assert s["lw"]["avg_launch_ms"] > 0 and s["sw"]["avg_launch_ms"] > 0 and "hbm" in s["bound"]
+    assert 0.3 < s["sw"]["frac_hbm_with_park"] < 1.0                    # the shortwave solver streams: bandwidth-bound
     assert line["reference_order_columns_per_s"] > 0
     assert line["reference_abi"]["fast0_columns_per_s"] > 0 and line["reference_abi"]["fast3_columns_per_s"] > 0
     g3 = line["fine_grid"]["G3_lw_0.001cm-1"]
