@@ -54,8 +54,9 @@ def check(band, device, oracle, lib, col, **kw):
     assert e_two < FAST_TOL
     assert e_between < BETWEEN_TOL
     # same arithmetic, other groupings of the fp32 ring sums (where the one-pass form does not apply -- wide windows --
-    # fast=1 is the ring kernel itself and the comparison is the one above)
-    assert e_forms < (3e-7 if e_between > 1e-12 else BETWEEN_TOL)
+    # fast=1 is the ring kernel itself and the comparison is the one above): a handful of fp32 roundings of a layer's
+    # largest tau apart (a soak of 5 000 cases met 3.15e-7 once)
+    assert e_forms < (6e-7 if e_between > 1e-12 else BETWEEN_TOL)
     return mp, want
 
 
