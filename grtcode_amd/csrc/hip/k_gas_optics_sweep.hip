@@ -237,15 +237,20 @@ __device__ uint64_t first_at_least(uint64_t n, double const *v, uint64_t k, F f,
 // shifted centre per layer.  For METHOD 1 bins past the last one (the reference indexes bin `n` for lines near
 // the top of the grid: its maxw lies a grid step beyond the last point) never come up here; the reference reads
 // and writes out of bounds for them.
+// One wave per (bin, layer): the bin's line ranges are found by dependent probes of the sorted centres (a dozen loads
+// one after the other) -- in a workgroup of four waves three of them sat at the barrier meanwhile, and the launch ran at
+// that latency, not at its arithmetic.
+constexpr int kSweepBlock = 64;
+
 template <int METHOD>
-__global__ __launch_bounds__(256) void bin_sweep_kernel(uint64_t num_lines, double const *vnn, double const *snn,
+__global__ __launch_bounds__(kSweepBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void bin_sweep_kernel(uint64_t num_lines, double const *vnn, double const *snn,
                                                         double const *gamma, double const *alpha,
                                                         double const *ns /* ms[slot][.][2], stride 4 */,
                                                         SweepBins bins, double *tau)
 {
     extern __shared__ double tloc[];            // [ppb] the bin's own grid points
     __shared__ uint64_t range[7];               // local [0,1] + flag [2]; remote ranges [3,6) and [4,5]
-    __shared__ double red[3][4];
+    __shared__ double red[3][kSweepBlock/64];
     uint64_t const j = blockIdx.x;
     int const i = blockIdx.y;
     int const tid = threadIdx.x;
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(256) void bin_sweep_kernel(uint64_t num_lines, doub
     double const *a = alpha + (uint64_t)i*num_lines;
     double const n_i = ns[4*i];
     uint64_t const np = bins.r[j] - bins.l[j] + 1;
-    for (uint64_t p = tid; p < np; p += 256)
+    for (uint64_t p = tid; p < np; p += kSweepBlock)
     {
         tloc[p] = 0.;
     }
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(256) void bin_sweep_kernel(uint64_t num_lines, doub
     {
         double const w = bins.w0 + bins.l[j]*bins.wres;
         uint64_t const nloc = right - left + 1;
-        for (uint64_t q = tid; q < nloc*np; q += 256)
+        for (uint64_t q = tid; q < nloc*np; q += kSweepBlock)
         {
             uint64_t const k = left + q/np;
             int const p = (int)(q % np);
@@ -348,7 +353,7 @@ __global__ __launch_bounds__(256) void bin_sweep_kernel(uint64_t num_lines, doub
     {
         uint64_t const kb = side == 0 ? left_r : first_r;
         uint64_t const ke = side == 0 ? left_end : right_r + 1;     // [kb, ke)
-        for (uint64_t k = kb + tid; k < ke; k += 256)
+        for (uint64_t k = kb + tid; k < ke; k += kSweepBlock)
         {
             LineShape const sh = make_shape(v[k], g[k], a[k]);
 #pragma unroll
@@ -374,9 +379,14 @@ __global__ __launch_bounds__(256) void bin_sweep_kernel(uint64_t num_lines, doub
     __syncthreads();
     if (tid < kNip)
     {
-        bins.tau[((uint64_t)i*bins.n + j)*kNip + tid] += (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
+        double sum = red[tid][0];
+        for (int wv = 1; wv < kSweepBlock/64; ++wv)
+        {
+            sum += red[tid][wv];
+        }
+        bins.tau[((uint64_t)i*bins.n + j)*kNip + tid] += sum;
     }
-    for (uint64_t p = tid; p < np; p += 256)
+    for (uint64_t p = tid; p < np; p += kSweepBlock)
     {
         tau[(uint64_t)i*bins.num_wpoints + bins.l[j] + p] += tloc[p];
     }
@@ -447,7 +457,7 @@ extern "C" int grt_launch_sweep(void *stream, int method, uint64_t n, int num_la
         {
             return (int)hipErrorInvalidValue;
         }
-        hipLaunchKernelGGL(bin_sweep_kernel<0>, dim3((unsigned)b->n, num_layers), dim3(256), sizeof(double)*(size_t)b->ppb, s,
+        hipLaunchKernelGGL(bin_sweep_kernel<0>, dim3((unsigned)b->n, num_layers), dim3(kSweepBlock), sizeof(double)*(size_t)b->ppb, s,
                            n, lines, lines + ln, lines + 2*ln, lines + 3*ln, ns, bins, tau);
     }
     else if (method == 1)
@@ -456,7 +466,7 @@ extern "C" int grt_launch_sweep(void *stream, int method, uint64_t n, int num_la
         {
             return (int)hipErrorInvalidValue;
         }
-        hipLaunchKernelGGL(bin_sweep_kernel<1>, dim3((unsigned)b->n, num_layers), dim3(256), sizeof(double)*(size_t)b->ppb, s,
+        hipLaunchKernelGGL(bin_sweep_kernel<1>, dim3((unsigned)b->n, num_layers), dim3(kSweepBlock), sizeof(double)*(size_t)b->ppb, s,
                            n, lines, lines + ln, lines + 2*ln, lines + 3*ln, ns, bins, tau);
     }
     return (int)hipGetLastError();
