@@ -1401,7 +1401,13 @@ static void auto_tune(GasOptics_t const *go, int ncol, int moments, int *tile, i
         /* the one-pass moment kernel keeps tile + 2*fsteps cells of 8 moments in LDS next to the tile; the
            two-pass one only the tile's own cells, and its tiles are powers of two (256 measured best at
            1 cm-1: four workgroups per CU) */
-        int const want = moments == 2 ? 256 : (moments ? 512 : 1024);
+        int want = moments == 2 ? 256 : (moments ? 512 : 1024);
+        /* two-pass form on a short grid: narrower tiles before line slices (the G1 longwave band, 3 250 points x 60
+           layers x 8 columns: 64-cell tiles in one slice 5.75 ms, 256-cell tiles in four slices 5.92 ms) */
+        while (moments == 2 && want > 64 && ((nw + want - 1)/want)*(uint64_t)go->num_layers*(uint64_t)ncol < 16384)
+        {
+            want >>= 1;
+        }
         t = nw >= (uint64_t)want ? want : (int)(((nw + 63)/64)*64);
         if (moments == 2)
         {
