@@ -138,7 +138,8 @@ create_solar_flux destroy_solar_flux disort_shortwave
 grt_tips_load grt_tips_reset grt_tips_is_table grt_tips_source grt_sizeof grt_add_molecule_lines grt_gas_optics_tune grt_gas_optics_last_launch grt_hitran_index_stats
 grt_optical_depth_batch grt_pipeline_create grt_pipeline_create_ex grt_pipeline_destroy grt_pipeline_run grt_pipeline_sync
 grt_pipeline_stream grt_pipeline_views grt_device_malloc grt_device_free grt_device_to_host
-grt_host_to_device grt_debug_line_prep grt_debug_partition_functions grt_debug_voigt grt_profile_enable grt_profile_read
+grt_host_to_device grt_debug_line_prep grt_debug_partition_functions grt_debug_voigt grt_debug_line_strengths grt_profile_enable grt_profile_read
+grt_set_deterministic grt_deterministic
 grt_multi_shard grt_multi_create grt_multi_destroy grt_multi_gather_fluxes grt_multi_broadcast grt_multi_max
 grt_err_begin grt_err_frame grt_log grt_gmalloc grt_gfree grt_gmemset grt_gmemcpy
 """.split()
@@ -347,6 +348,15 @@ class GasOpticsObject:
         q = np.zeros((self.c.num_molecules, self.num_levels - 1, 18))
         check(self.lib.grt_debug_partition_functions(C.byref(self.c), _dp(p_mb), _dp(t), _dp(q)))
         return q
+
+    def debug_line_strengths(self):
+        """The device line store's strengths (merged store order), after the rescaling of parse_HITRAN_file.c:372-384."""
+        n = C.c_uint64(0)
+        check(self.lib.grt_debug_line_strengths(C.byref(self.c), C.byref(n), None))
+        s0 = np.zeros(n.value)
+        if n.value:
+            check(self.lib.grt_debug_line_strengths(C.byref(self.c), C.byref(n), _dp(s0)))
+        return s0
 
     def destroy(self):
         check(self.lib.destroy_gas_optics(C.byref(self.c)))

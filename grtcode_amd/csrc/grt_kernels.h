@@ -89,6 +89,12 @@ typedef struct GrtGasOpticsArgs
     int profile_tag;          /* != 0: time the line kernel under this tag (the two-pass gather under tag + 5) */
     int near_block;           /* set by the launcher: 64 where the tree form's gather shares its walk per wave -- near
                                  fields are then whole 64-point blocks (the halo leaves room for that); else 0 */
+    int deterministic;        /* != 0 (GRT_DETERMINISTIC=1 / grt_set_deterministic): every floating-point sum in one fixed
+                                 order, so that two runs agree to the last bit -- one wave of a workgroup takes all of its
+                                 lines in store order, one line slice, and the two-pass form's first pass runs in
+                                 tile_nphase launches of non-overlapping cell tiles.  A verification mode: ~4x slower. */
+    int tile_phase, tile_nphase;   /* set by the launcher: this launch takes cell tiles t with t % tile_nphase == tile_phase
+                                 (tile_nphase <= 1: all of them) */
 } GrtGasOpticsArgs;
 
 int grt_launch_gas_optics(void *stream, GrtGasOpticsArgs const *a);

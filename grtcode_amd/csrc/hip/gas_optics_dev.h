@@ -471,6 +471,19 @@ __device__ __forceinline__ WorkItem decode_work(GrtGasOpticsArgs const &a, unsig
     return w;
 }
 
+// The workgroup's walk over its candidate lines [jbeg, jend): wave w takes lines jbeg + 64 w + 256 k ...; in the
+// deterministic mode (GrtGasOpticsArgs.deterministic) wave 0 takes them all, 64 at a time in store order, and the other
+// waves none, so that every LDS accumulation of the workgroup happens in one fixed order.
+__device__ __forceinline__ uint64_t line_walk_first(GrtGasOpticsArgs const &a, uint64_t jbeg, uint64_t jend, int wave)
+{
+    return a.deterministic ? (wave == 0 ? jbeg : jend) : jbeg + (uint64_t)wave*64;
+}
+
+__device__ __forceinline__ unsigned line_walk_stride(GrtGasOpticsArgs const &a)
+{
+    return a.deterministic ? 64u : (unsigned)kBlock;
+}
+
 // This layer's slice of the column state -> LDS: [slot][4] means + [slot][GRT_MAX_ISO] 1/Q.
 __device__ __forceinline__ void stage_column_state(GrtGasOpticsArgs const &a, double const *cs, int layer,
                                                    double *ms_l, double *q_l, int tid)

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, 
     // value at that grid index and passes the token on.  After 64 steps every token has met every
     // line and sits in lane (f - span start): one conflict-free ds_add_f64 per lane flushes the
     // span into the tile.  The inner loop touches neither LDS nor atomics.
-    for (uint64_t base = jbeg + (uint64_t)wave*64; base < jend; base += kBlock)
+    for (uint64_t base = line_walk_first(a, jbeg, jend, wave); base < jend; base += line_walk_stride(a))
     {
         uint64_t const j = base + lane;
         RawLine ln = {};

@@ -335,6 +335,10 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
     int const wave = tid >> 6;
     WorkItem const wi = decode_work(a, ngroups, perm_stride);
     int const col = wi.col, layer = wi.layer, tile_idx = wi.tile_idx, slice = wi.slice;
+    if (TWO_PASS && a.tile_nphase > 1 && tile_idx % a.tile_nphase != a.tile_phase)
+    {
+        return;         // deterministic mode: this launch takes every tile_nphase-th cell tile (see the launcher)
+    }
     long long const nw = (long long)a.nw;
     long long const F0l = (long long)tile_idx*a.tile;
     long long const F1l = (F0l + a.tile < nw) ? F0l + a.tile : nw;                // [F0,F1)
@@ -420,7 +424,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         }
     };
 
-    for (uint64_t base = jbeg + (uint64_t)wave*64; base < jend; base += kBlock)
+    for (uint64_t base = line_walk_first(a, jbeg, jend, wave); base < jend; base += line_walk_stride(a))
     {
         // Lanes past the end of the range prepare the last line again and are masked at the end: straight
         // line code for the whole wave instead of nested divergent regions.
@@ -1865,29 +1869,43 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
         int slot = a->profile_tag ? grt_profile_begin(stream, a->profile_tag) : -1;
         int const ncell = (tree && a->tile > kDirectTile) ? 0 : a->tile;
         size_t const lds = mp_lds_bytes(nacc, ncell, 0, a->lay.num_slots, tree, tree && ncell == 0 ? a->tile : 0);
-        if (wide)
+        // Deterministic mode: the accumulators of cell tiles t and t' overlap when |t - t'| tile < tile + 2 halo, and the
+        // order in which their workgroups add to tau is the scheduler's.  So the first pass runs in nphase launches, launch p
+        // taking the tiles t = p (mod nphase): no two tiles of a launch touch the same point, the launches follow one
+        // another on the stream, and every point receives its contributions in tile order modulo nphase.
+        int const nphase = a->deterministic ? (2*halo)/a->tile + 2 : 1;
+        if (a->deterministic && a->nslice != 1)
         {
-            hipLaunchKernelGGL((gas_optics_mp_kernel<true, true, kMomWide>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
-                               fsteps, (unsigned)ngroups, golden_stride(ngroups), ncell, nacc, halo);
+            return (int)hipErrorInvalidValue;
         }
-        else if (tree)
+        for (int phase = 0; phase < nphase; ++phase)
         {
-            hipLaunchKernelGGL((gas_optics_mp_kernel_w4<true, true, kMom>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
-                               fsteps, (unsigned)ngroups, golden_stride(ngroups), ncell, nacc, halo);
-        }
-        else
-        {
-            // (a band that ends below 4 000 cm-1 -- the longwave -- takes the instance with the lean ring: 6.05 -> 5.9 ms at
-            // 1 cm-1; on the shortwave band the extra code cost more than the few waves it serves gained)
-            if (a->w0 + (double)a->nw*a->wres <= 4000.)
+            b.tile_phase = phase;
+            b.tile_nphase = nphase;
+            if (wide)
             {
-                hipLaunchKernelGGL((gas_optics_mp_kernel_w4<true, false, kMom, true>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
+                hipLaunchKernelGGL((gas_optics_mp_kernel<true, true, kMomWide>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
+                                   fsteps, (unsigned)ngroups, golden_stride(ngroups), ncell, nacc, halo);
+            }
+            else if (tree)
+            {
+                hipLaunchKernelGGL((gas_optics_mp_kernel_w4<true, true, kMom>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
                                    fsteps, (unsigned)ngroups, golden_stride(ngroups), ncell, nacc, halo);
             }
             else
             {
-                hipLaunchKernelGGL((gas_optics_mp_kernel_w4<true, false, kMom>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
-                                   fsteps, (unsigned)ngroups, golden_stride(ngroups), ncell, nacc, halo);
+                // (a band that ends below 4 000 cm-1 -- the longwave -- takes the instance with the lean ring: 6.05 -> 5.9 ms at
+                // 1 cm-1; on the shortwave band the extra code cost more than the few waves it serves gained)
+                if (a->w0 + (double)a->nw*a->wres <= 4000.)
+                {
+                    hipLaunchKernelGGL((gas_optics_mp_kernel_w4<true, false, kMom, true>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
+                                       fsteps, (unsigned)ngroups, golden_stride(ngroups), ncell, nacc, halo);
+                }
+                else
+                {
+                    hipLaunchKernelGGL((gas_optics_mp_kernel_w4<true, false, kMom>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
+                                       fsteps, (unsigned)ngroups, golden_stride(ngroups), ncell, nacc, halo);
+                }
             }
         }
         if (a->profile_tag) grt_profile_end(stream, slot);

@@ -1470,6 +1470,27 @@ static int near_halo_bound(GasOptics_t const *go, int ncol, double w_top, double
     return worst < 1e9 ? (int)worst : 1000000000;
 }
 
+/* Deterministic mode (grt_ext.h): -1 = follow GRT_DETERMINISTIC in the environment (read at every launch, so that a
+   test can switch it inside one process), 0 / 1 = forced off / on. */
+static int g_deterministic = -1;
+
+EXTERN int grt_set_deterministic(int on)
+{
+    GRT_REQUIRE_RANGE(on, -1, 1);
+    g_deterministic = on;
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN int grt_deterministic(void)
+{
+    if (g_deterministic >= 0)
+    {
+        return g_deterministic;
+    }
+    char const *env = getenv("GRT_DETERMINISTIC");
+    return env != NULL && env[0] != '\0' && !(env[0] == '0' && env[1] == '\0');
+}
+
 int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_stride, GrtGasOpticsArgs *a)
 {
     GrtGasOpticsImpl *im = impl_of(go);
@@ -1594,6 +1615,13 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
     if (a->fast != 1 && a->fast != 3)
     {
         auto_tune(go, ncol, 0, &a->tile, &a->nslice);
+    }
+    if (grt_deterministic())
+    {
+        /* one line slice per tile (slices add to tau in the scheduler's order), one wave per workgroup on the lines, the
+           two-pass form's first pass in launches of non-overlapping tiles: k_gas_optics_mp.hip */
+        a->deterministic = 1;
+        a->nslice = 1;
     }
     return GRTCODE_SUCCESS;
 }
@@ -1858,6 +1886,25 @@ EXTERN int grt_debug_partition_functions(GasOptics_t *gas_optics, fp_t *pressure
         GRT_TRY(grt_dev_download(dev, q_out, im->colstate_d + im->layout.off_q, sizeof(double)*count, s));
     }
     GRT_TRY(grt_dev_sync(dev, s));
+    return GRTCODE_SUCCESS;
+}
+
+/* The strengths of the device line store as the kernels read them (merged store order): what
+   parse_HITRAN_file.c:372-384 leaves in snn, with the partition sums current at the last build. */
+EXTERN int grt_debug_line_strengths(GasOptics_t *gas_optics, uint64_t *num_lines, double *s0_out)
+{
+    GRT_REQUIRE_PTR(gas_optics);
+    GRT_REQUIRE_PTR(gas_optics->impl);
+    GRT_REQUIRE_PTR(num_lines);
+    GRT_TRY(grt_gas_optics_prepare(gas_optics, 1));
+    GrtGasOpticsImpl *im = impl_of(gas_optics);
+    *num_lines = im->store.n;
+    if (s0_out != NULL && im->store.n > 0)
+    {
+        void *s = grt_dev_stream(gas_optics->device);
+        GRT_TRY(grt_dev_download(gas_optics->device, s0_out, im->store.s0, sizeof(double)*im->store.n, s));
+        GRT_TRY(grt_dev_sync(gas_optics->device, s));
+    }
     return GRTCODE_SUCCESS;
 }
 

@@ -70,6 +70,18 @@ EXTERN int grt_gas_optics_tune(GasOptics_t *gas_optics, int tile, int nslice, in
  * (grids finer than ~0.12 cm-1) make fast = 3 sum the far field through a hierarchy of cells. */
 EXTERN int grt_gas_optics_last_launch(GasOptics_t const *gas_optics, long long info[8]);
 
+/* ---- deterministic mode ------------------------------------------------------------
+ * The fused forms (fast 1-3) and line slices accumulate with floating-point atomics in LDS and in tau, in whatever
+ * order the hardware schedules waves and workgroups: two runs of the same input agree to ~1e-11 of a layer's largest
+ * tau (fp32 cell moments) / ~1e-16 (fp64 near fields), not to the last bit.  With GRT_DETERMINISTIC=1 in the
+ * environment (read at every launch), or grt_set_deterministic(1), every sum is formed in one fixed order and repeated
+ * runs are bit-identical: one wave of each workgroup takes all of its lines in store order, tiles are never cut into
+ * line slices, and the first pass of the two-pass form runs as a sequence of launches over non-overlapping cell tiles.
+ * The values are as good as the default mode's (same formulas, another order); the line kernel is ~4x slower.
+ * grt_set_deterministic(-1) returns control to the environment variable. */
+EXTERN int grt_set_deterministic(int on);
+EXTERN int grt_deterministic(void);
+
 /* ---- batched columns ------------------------------------------------------------- */
 typedef struct GrtColumns
 {
@@ -170,6 +182,11 @@ EXTERN int grt_debug_line_prep(GasOptics_t *gas_optics, fp_t *pressure, fp_t *te
                                uint64_t *num_lines, uint8_t *slot, double *v0, double *vnn,
                                double *snn, double *gamma, double *alpha, int64_t *win_s,
                                int64_t *win_e);
+
+/* ---- parity hook: the strengths of the device line store (merged store order) as the kernels read them, i.e. after
+ * the rescaling of parse_HITRAN_file.c:372-384 with the partition sums current at the last build.  Pass s0_out = NULL
+ * to query the count. */
+EXTERN int grt_debug_line_strengths(GasOptics_t *gas_optics, uint64_t *num_lines, double *s0_out);
 
 /* ---- parity hook: the line shape itself.  Same inputs as rfm_voigt_line_shape(LineShapeInputs_t, K)
  * (gas-optics/src/RFM_voigt.c:85-281, line_shape.h:26-35): K[i], i < num_wpoints, at w + i*wres for a line at

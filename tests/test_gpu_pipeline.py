@@ -155,8 +155,20 @@ def test_fused_production_pipeline_equals_materialised_pipeline(bands, oracle, l
         pipe.run(gcols)
         got[spectral] = pipe.fluxes(ncol)
         if not spectral:
-            pipe.run(gcols)                                         # (tau itself is summed with atomics across line slices:
-            assert np.max(np.abs(pipe.fluxes(ncol) - got[False])) < 1e-11       # run-to-run ~1e-13; the flux reduction adds nothing to that)
+            pipe.run(gcols)
+            # reference-order form: tau is summed in fp64, line slices add with atomics in any order (~1e-16 relative),
+            # and the flux reduction itself is ordered; bit-identical in the deterministic mode
+            again = pipe.fluxes(ncol)
+            assert np.max(np.abs(again - got[False])) < 1e-12 * np.abs(got[False]).max()
+            api.check(lib.grt_set_deterministic(1))
+            try:
+                pipe.run(gcols)
+                det = pipe.fluxes(ncol)
+                pipe.run(gcols)
+                assert np.array_equal(pipe.fluxes(ncol), det)
+                assert np.max(np.abs(det - got[False])) < 1e-12 * np.abs(got[False]).max()
+            finally:
+                api.check(lib.grt_set_deterministic(-1))
             with pytest.raises(api.GrtError):                       # nothing spectral is kept in this form
                 ptrs = [api.C.c_void_p() for _ in range(6)]
                 api.check(lib.grt_pipeline_views(pipe.p, 0, *[api.C.byref(p) for p in ptrs]))

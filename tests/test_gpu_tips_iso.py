@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from grtcode_amd import api, synthetic as syn
-from scenario import Band, MOLTAB
+from scenario import Band, MOLTAB, RUN_TO_RUN_FUSED
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -126,6 +126,7 @@ def test_table_loaded_after_add_molecule_rescales_the_store(tmp_path, clean_tips
     opt = api.OpticsObject(8, grid, device)
     go.calculate_optical_depth(col["p"], col["t"], opt)
     tau_model = opt.read()[0]
+    store_model = go.debug_line_strengths()
     tol = 1e-11 if fast == 0 else 2e-6
     assert tau_close(tau_model, band.oracle_tau(oracle, oracle, lib, col)) < tol
     qfunc = write_table(str(tmp_path / "q.csv"), mols, seed=9)
@@ -135,8 +136,15 @@ def test_table_loaded_after_add_molecule_rescales_the_store(tmp_path, clean_tips
     want = band.oracle_tau(oracle, oracle, lib, col, qfunc=qfunc)
     assert tau_close(tau_table, want) < tol
     assert tau_close(tau_table, tau_model) > 1e-2
+    store_table = go.debug_line_strengths()
+    assert store_table.size == store_model.size and np.any(store_table != store_model)
     api.check(lib.grt_tips_reset())
     go.calculate_optical_depth(col["p"], col["t"], opt)
-    assert tau_close(opt.read()[0], tau_model) < 1e-13
+    # What "restored" means exactly is the line store: the strengths are again, bit for bit, the ones the model gave.
+    assert np.array_equal(go.debug_line_strengths(), store_model)
+    # tau from the same store: the reference-order form sums in fp64 only (line slices add in any order: ~1e-15); the fused
+    # forms add fp32 cell moments and fp64 near fields with atomics in the scheduler's order, which moves tau by ~1e-11 of a
+    # layer's largest value from run to run (RUN_TO_RUN_FUSED; bit-identical under GRT_DETERMINISTIC=1, test_gpu_deterministic.py)
+    assert tau_close(opt.read()[0], tau_model) < (1e-13 if fast == 0 else RUN_TO_RUN_FUSED)
     opt.destroy()
     go.destroy()
