@@ -26,6 +26,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector
+SIMDS = 256 * 4                # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9               # MI355X_MICROARCH.md: peak engine clock
 
 
 def cpu_baseline(lw_grid, sw_grid, lw_lines, sw_lines, thin_lw=1, thin_sw=1):
@@ -55,7 +57,23 @@ def cpu_baseline(lw_grid, sw_grid, lw_lines, sw_lines, thin_lw=1, thin_sw=1):
         detail[band] = dict(gas_optics_s_sample=round(r["t_gas"], 3), rest_s=round(r["t_rest"], 3), thin=thin)
         total += r["t_gas"] * thin + r["t_rest"]
         bands[band] = r
+    # one thread, same workload (SURVEY §8d asks for 1 thread and all cores): the line lists thinned 1/8 so that the sample
+    # stays near ten seconds -- gas-optics time scaled back by the factor, every other stage at full size
+    one = None
+    if kind == "reference":
+        RC.set_omp_threads(1)
+        thin1, t1, d1 = 8, 0.0, {}
+        for band, grid, nlines, seed, sw in (("lw", lw_grid, lw_lines, 20261003, False), ("sw", sw_grid, sw_lines, 20261004, True)):
+            r = RC.band_column(kind, chk, orc, lib.Q, col, grid, W.band_lines(nlines, grid, seed), syn.tables(sw=sw),
+                               W.MOL_ORDER, MOLTAB, mol_mass, W.CIA_PAIRS, sw, thin=thin1)
+            d1[band] = dict(gas_optics_s_sample=round(r["t_gas"], 3), rest_s=round(r["t_rest"], 3), thin=thin1)
+            t1 += r["t_gas"] * thin1 + r["t_rest"]
+        RC.set_omp_threads(cores)
+        one = {"value": 1.0 / t1, "unit": "columns/s", "cores": 1, "seconds_per_column_est": round(t1, 2), "detail": d1,
+               "sample": f"1 column, line lists thinned 1/{thin1} (gas-optics time scaled back), solvers at full size"}
     base = {"value": 1.0 / total, "unit": "columns/s", "cores": cores, "kind": kind,
+            "host_cores": os.cpu_count(), "cores_note": "the GPU box's share of host cores for one GPU is 16; threads = min(host cores, 16)",
+            "one_thread": one,
             "sample": ("1 column of the bench workload at full size (LW+SW at 1 cm-1, 60 layers, all lines)"
                        if thin_lw == 1 and thin_sw == 1 else
                        f"1 column, LW+SW at 1 cm-1, 60 layers, line lists thinned 1/{thin_lw} (LW) and 1/{thin_sw} (SW); "
@@ -115,7 +133,11 @@ def fine_grid_column(wl, dw, reps, compare_layers=0):
             go.calculate_optical_depth(c["p"], c["t"], opt)
             taus[fast] = opt.read()[0]
         scale = np.abs(taus[2]).max(axis=1, keepdims=True)
-        out["tree_vs_ring"] = {"layers": compare_layers, "max_diff_of_layer_max": float(np.max(np.abs(taus[3] - taus[2]) / scale))}
+        out["tree_vs_ring"] = {"layers": compare_layers, "max_diff_of_layer_max": float(np.max(np.abs(taus[3] - taus[2]) / scale)),
+                               "what": "SELF-COMPARISON of two forms of this library (cell hierarchy vs every window point in the ring), not "
+                                       "parity: the reference's C needs ~40 CPU-minutes for this column.  Against the reference at this grid: "
+                                       "tests/test_gpu_moment_tree.py::test_full_3m_point_grid_against_the_reference_c (n = 3 249 001, "
+                                       "16 000 lines x 4 layers)"}
         opt.destroy()
         go.destroy()
     return out
@@ -202,17 +224,99 @@ def parity_of_column0(wl, fluxes, bands, kind):
     return out
 
 
+def spawn_ranks(ngpus):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks ourselves, as plain child processes --
+    the way the reference fans out its column shards (GRTworkflow/run-rfmip-irf.sh:103-132: one process per -x/-X block).
+    This parent never imports torch and never touches HIP; the children are FRESH interpreters (no fork of a GPU
+    process, no exec from one).  Rank 0's stdout (the one JSON line) is relayed; everything else goes to stderr.
+    Any rank failing, or the job outliving GRT_BENCH_TIMEOUT seconds, ends the others (by their PIDs) and the exit
+    code is non-zero."""
+    import socket
+    import subprocess
+    import threading
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs, relay = [], []
+    for r in range(ngpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(ngpus), LOCAL_WORLD_SIZE=str(ngpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GRT_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+
+    def pump():
+        for raw in procs[0].stdout:
+            relay.append(raw.decode(errors="replace"))
+    t = threading.Thread(target=pump, daemon=True)
+    t.start()
+    deadline = time.time() + float(os.environ.get("GRT_BENCH_TIMEOUT", 1500))
+    rc = 0
+    while rc == 0:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            rc = bad[0][1] if bad[0][1] > 0 else 1
+            sys.stderr.write(f"bench.py: rank {bad[0][0]} exited with code {bad[0][1]}; stopping the other ranks\n")
+        elif all(c == 0 for c in codes):
+            break
+        elif time.time() > deadline:
+            rc = 124
+            sys.stderr.write("bench.py: GRT_BENCH_TIMEOUT reached; stopping the ranks\n")
+        else:
+            time.sleep(0.05)
+    if rc != 0:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    t.join(timeout=10)
+    if rc == 0:
+        sys.stdout.write("".join(relay))
+        sys.stdout.flush()
+    return rc
+
+
+class PlaceholderEngine:
+    """GRT_BENCH_REHEARSAL=1 on a box WITHOUT a GPU: no kernel runs and nothing is measured.  A column's "fluxes" are a
+    function of its global index, so that the launcher, the sharding, the padded gather and rank 0's checks of what the
+    gather delivered can be rehearsed (tests/test_bench_launcher.py).  The product path has no CPU form; this is not one."""
+
+    def __init__(self, torch):
+        self.torch = torch
+
+    @staticmethod
+    def expected(col, k):
+        return 1000.0 * (col + 1) + k
+
+    def run(self, first, n, dst):
+        for i in range(n):
+            for k in range(dst.shape[1]):
+                dst[i, k] = self.expected(first + i, k)
+
+    def sync(self):
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--cols", type=int, default=int(os.environ.get("GRT_BENCH_COLS", 8)), help="columns per GPU per step")
+    ap.add_argument("--cols", type=int, default=int(os.environ.get("GRT_BENCH_COLS", 64)), help="columns per GPU per step (weak scaling)")
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("GRT_BENCH_CHUNK", 8)), help="columns per launch of the pipeline")
     ap.add_argument("--fast", type=int, default=int(os.environ.get("GRT_BENCH_FAST", 3)),
                     help="3: fused form, far wings by cell moments, two passes (production); 1: the same in one pass; "
                          "2: fused form, ring kernel; 0: reference operation order")
     ap.add_argument("--columns", type=int, default=0, help="strong scaling: a step is this fixed number of columns, sharded "
                     "over the ranks (0: weak scaling, --cols columns per GPU per step)")
+    ap.add_argument("--gather-every", type=int, default=0, help="steps between gathers of the output fluxes to rank 0 "
+                    "(0: ONE gather, after the last step -- the job's output, as the north star words it)")
     ap.add_argument("--tile", type=int, default=0, help="exploration only: wavenumbers (cells) per workgroup of the line kernel")
     ap.add_argument("--lw-nslice", type=int, default=0, help="exploration only: line slices per tile of the longwave launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -222,12 +326,21 @@ def main():
     ap.add_argument("--lw-dw", type=float, default=None, help="exploration only: longwave grid spacing (default 1 cm-1)")
     ap.add_argument("--sw-dw", type=float, default=None, help="exploration only: shortwave grid spacing (default 1 cm-1)")
     args = ap.parse_args()
+    if args.gpus < 1 or args.steps < 1 or args.cols < 1 or args.chunk < 1:
+        raise SystemExit("bench.py: --gpus, --steps, --cols and --chunk must be positive")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us (the driver's N > 1 runs come through torch.distributed.run, which sets WORLD_SIZE):
+        # start the ranks ourselves -- before torch or HIP exist in this process
+        raise SystemExit(spawn_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("GRT_BENCH_TEST_FAIL_RANK") == str(rank):
+        raise SystemExit(7)             # test hook (tests/test_bench_launcher.py): a rank that dies before the rendezvous
 
     # the C library reports loaded species on stdout (like the reference's log_mesg); keep stdout
     # for the single JSON line by pointing fd 1 at stderr until the result is printed
@@ -237,90 +350,155 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from grtcode_amd import api, multi, workload as W
+    from grtcode_amd import multi
 
     # GRT_BENCH_REHEARSAL=1: a logic rehearsal of the N > 1 path on a box with fewer GPUs than ranks -- ranks share the
-    # devices there are and the collectives go over gloo on host copies.  Timings of such a run mean nothing (the line
-    # says so); what it exercises is the sharding, the line-list cache hand-over, the padded gather and the barriers.
+    # devices there are (none: PlaceholderEngine) and the collectives go over gloo on host copies.  Timings of such a run
+    # mean nothing (the line says so); what it exercises is the launcher, the sharding, the line-list cache hand-over,
+    # the padded gather and the barriers.
     rehearsal = os.environ.get("GRT_BENCH_REHEARSAL") == "1"
-    if rehearsal:
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    placeholder = rehearsal and ndev == 0
+    if rehearsal and ndev > 0:
+        local_rank = local_rank % ndev
+    if not placeholder:
+        torch.cuda.set_device(local_rank)
     # GRT_BENCH_FORCE_DIST=1 exercises the RCCL path (init, stream-ordered gather, max-reduce) at world size 1
     force_dist = os.environ.get("GRT_BENCH_FORCE_DIST") == "1"
-    if world > 1 or force_dist:
+    use_dist = world > 1 or force_dist
+    backend = None
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
+        backend = "gloo" if rehearsal else "nccl"
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    device = api.create_device(local_rank)
-    if world > 1:
-        # the line lists are drawn once (rank 0) and shared through a cache directory instead of once per rank
-        os.environ.setdefault("GRT_LINES_CACHE", os.path.join(os.environ.get("TMPDIR", "/tmp"), f"grt_lines_cache_{os.getuid()}"))
-        if rank != 0:
-            dist.barrier()
-    lw_grid = (W.LW_GRID[0], W.LW_GRID[1], args.lw_dw or W.LW_GRID[2])
-    sw_grid = (W.SW_GRID[0], W.SW_GRID[1], args.sw_dw or W.SW_GRID[2])
-    wl = W.G1Workload(device, args.cols, lw_lines=args.lw_lines or W.LW_LINES,
-                      sw_lines=args.sw_lines or W.SW_LINES, fast=args.fast, lw_grid=lw_grid, sw_grid=sw_grid, tile=args.tile, lw_nslice=args.lw_nslice)
-    if world > 1 and rank == 0:
-        dist.barrier()                                              # the lists are in the cache: the other ranks may build
+        world = dist.get_world_size()
     strong = args.columns > 0
     total_per_step = args.columns if strong else world * args.cols
     first, count = multi.shard(total_per_step, rank, world)         # weak scaling: args.cols columns per rank
     per = -(-total_per_step // world)
-    # this rank's block, in chunks of at most args.cols columns (one chunk in weak mode)
-    chunks = []
-    for lo in range(0, count, args.cols):
-        n = min(args.cols, count - lo)
-        (gc, keep), _ = wl.columns(first + lo, n)
-        chunks.append((lo, n, gc, keep))
-    out = torch.zeros(max(per, 1), api.GRT_FLUXES_PER_COLUMN, dtype=torch.float64, device="cuda")
-    use_dist = world > 1 or force_dist
-    gathered = [torch.zeros_like(out) for _ in range(world)] if (use_dist and rank == 0) else None
-    stream = torch.cuda.ExternalStream(wl.pipe.stream(), device=torch.device("cuda", local_rank))
-    row_bytes = 8 * api.GRT_FLUXES_PER_COLUMN
-    result = {}
+    chunk = min(args.chunk, max(per, 1))
+    lw_grid = sw_grid = None
+    if placeholder:
+        engine = PlaceholderEngine(torch)
+        dev_t = torch.device("cpu")
+        chunks = [(lo, min(chunk, count - lo)) for lo in range(0, count, chunk)]
+    else:
+        from grtcode_amd import api, workload as W
+        device = api.create_device(local_rank)
+        dev_t = torch.device("cuda", local_rank)
+        if world > 1:
+            # the line lists are drawn once (rank 0) and shared through a cache directory instead of once per rank
+            os.environ.setdefault("GRT_LINES_CACHE", os.path.join(os.environ.get("TMPDIR", "/tmp"), f"grt_lines_cache_{os.getuid()}"))
+            if rank != 0:
+                dist.barrier()
+        lw_grid = (W.LW_GRID[0], W.LW_GRID[1], args.lw_dw or W.LW_GRID[2])
+        sw_grid = (W.SW_GRID[0], W.SW_GRID[1], args.sw_dw or W.SW_GRID[2])
+        wl = W.G1Workload(device, chunk, lw_lines=args.lw_lines or W.LW_LINES,
+                          sw_lines=args.sw_lines or W.SW_LINES, fast=args.fast, lw_grid=lw_grid, sw_grid=sw_grid, tile=args.tile, lw_nslice=args.lw_nslice)
+        if world > 1 and rank == 0:
+            dist.barrier()                                              # the lists are in the cache: the other ranks may build
+        # this rank's block, in chunks of at most `chunk` columns
+        chunks = []
+        for lo in range(0, count, chunk):
+            n = min(chunk, count - lo)
+            (gc, keep), _ = wl.columns(first + lo, n)
+            chunks.append((lo, n, gc, keep))
+    # The job's output: every step's [per][12] block of integrated fluxes stays on the device, in the step's slot of a
+    # job buffer, and the buffer is gathered to rank 0 ONCE, after the last step (--gather-every K: after every K steps).
+    nfl = 12
+    gather_every = args.gather_every if args.gather_every > 0 else args.steps
+    slots = min(gather_every, args.steps)
+    job = torch.zeros(slots, max(per, 1), nfl, dtype=torch.float64, device=dev_t)
+    gathered = [torch.zeros_like(job) for _ in range(world)] if (use_dist and rank == 0) else None
+    stream = None if placeholder else torch.cuda.ExternalStream(wl.pipe.stream(), device=dev_t)
+    row_bytes = 8 * nfl
+    gathers = {"count": 0}
+    gathered_host = [torch.zeros(slots, max(per, 1), nfl, dtype=torch.float64) for _ in range(world)] if (use_dist and rank == 0 and rehearsal) else None
 
-    def step():
-        for lo, n, gc, _ in chunks:
-            wl.pipe.run(gc, out.data_ptr() + lo * row_bytes)
-        if use_dist and rehearsal:
-            wl.pipe.sync()
-            result["all"] = multi.gather_fluxes(out[:count].cpu(), rank, world, None, num_columns=total_per_step)
-        elif use_dist:
-            with torch.cuda.stream(stream):      # RCCL gather ordered after the kernels, no host sync
-                result["all"] = multi.gather_fluxes(out[:count], rank, world, gathered, num_columns=total_per_step) if world > 1 \
-                    else (dist.gather(out, gathered, dst=0), gathered[0])[1]
+    def step(s):
+        block = job[s % slots]
+        if placeholder:
+            for lo, n in chunks:
+                engine.run(first + lo, n, block[lo: lo + n])
+        else:
+            for lo, n, gc, _ in chunks:
+                wl.pipe.run(gc, block.data_ptr() + lo * row_bytes)
+
+    def gather():
+        """the job buffer -> rank 0: one collective (blocks are padded to `per` rows, so no sizes travel)"""
+        if not use_dist:
+            return
+        gathers["count"] += 1
+        if rehearsal:
+            if not placeholder:
+                wl.pipe.sync()
+            dist.gather(job.cpu(), gathered_host if rank == 0 else None, dst=0)
+        else:
+            with torch.cuda.stream(stream):      # RCCL gather ordered after the kernels on the library stream, no host sync
+                dist.gather(job, gathered if rank == 0 else None, dst=0)
 
     def barrier():
-        wl.pipe.sync()
-        torch.cuda.synchronize()
+        if not placeholder:
+            wl.pipe.sync()
+            torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
+    for s in range(args.warmup):
+        step(s)
+    if args.warmup:
+        gather()                # (the communicator's first collective is not part of the job)
     barrier()
-    api.profile_enable(True)
+    gathers["count"] = 0
+    if not placeholder:
+        api.profile_enable(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for s in range(args.steps):
+        step(s)
+        if (s + 1) % gather_every == 0 or s + 1 == args.steps:
+            gather()
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = multi.max_over_ranks(elapsed, torch.device("cpu") if rehearsal else torch.device("cuda", local_rank))
+    elapsed = multi.max_over_ranks(elapsed, torch.device("cpu") if rehearsal else dev_t)
 
     if rank == 0:
-        fluxes = out.cpu().numpy()
+        fluxes = job[(args.steps - 1) % slots].cpu().numpy()           # this rank's block of the last step
         assert np.all(np.isfinite(fluxes)), "non-finite integrated fluxes"
-        if world > 1:
-            # what the gather delivered: every column of the step, in order, this rank's own block first
-            allf = result["all"].cpu().numpy()
-            assert allf.shape == (total_per_step, api.GRT_FLUXES_PER_COLUMN), allf.shape
-            assert np.all(np.isfinite(allf)) and np.all(allf[:, 0] > 0.), "gathered fluxes incomplete"
-            assert np.array_equal(allf[:count], fluxes[:count])
+        if use_dist:
+            # what the gathers delivered: [rank][slot][per][12]; a slot's blocks laid end to end are that step's columns in order
+            got = torch.stack([g.cpu() for g in (gathered_host if rehearsal else gathered)]).numpy()
+            allf = got.transpose(1, 0, 2, 3).reshape(slots, world * max(per, 1), nfl)[:, :total_per_step]
+            assert np.all(np.isfinite(allf)) and np.all(allf[:, :, 0] > 0.), "gathered fluxes incomplete"
+            assert np.array_equal(allf[:, :count], job.cpu().numpy()[:, :count]), "rank 0's own block changed in the gather"
+            if placeholder:
+                want = np.array([[PlaceholderEngine.expected(c, k) for k in range(nfl)] for c in range(total_per_step)])
+                assert all(np.array_equal(allf[sl], want) for sl in range(slots)), "gathered blocks are not the columns in order"
+        total_cols = total_per_step * args.steps
+        dist_info = {"n_gpus": world, "rccl_ranks": world if backend == "nccl" else 0,
+                     "collective": {"backend": backend, "gathers_in_timed_region": gathers["count"],
+                                    "bytes_per_rank_per_gather": int(job.numel()) * 8 if use_dist else 0,
+                                    "what": "one gather of the job's [steps][columns][12] integrated fluxes to rank 0" if use_dist else None}}
+        if placeholder:
+            line = {"metric": "columns/sec (60-layer, 1 cm\u207b\u00b9 LBL, LW+SW)", "value": total_cols / elapsed, "unit": "columns/s",
+                    **dist_info, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+                    "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64",
+                    "data": "synthetic",
+                    "rehearsal": "NO DEVICE: placeholder flux blocks, no kernel ran, nothing was measured -- launcher, sharding and gather only",
+                    "config": {"workload": "none (rehearsal)", "columns_per_step": total_per_step, "chunk_columns": chunk,
+                               "shards": [list(multi.shard(total_per_step, r, world)) for r in range(world)]}}
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            print(json.dumps(line), flush=True)
+            os.dup2(2, 1)
+    if placeholder:
+        if use_dist:
+            dist.destroy_process_group()
+        return
+    if rank == 0:
         ms = {tag: api.profile_read(tag) for tag in (1, 2, 3, 4, 5, 6, 7)}
         L, V = W.NUM_LEVELS - 1, W.NUM_LEVELS
         n_lw, n_sw = wl.grid_lw.n, wl.grid_sw.n
@@ -328,7 +506,7 @@ def main():
         # algorithmic bytes of the dominant kernel (line-by-line tau, SW-band launch), per launch:
         # SURVEY.md §8(d) terms it owns: 60 B/line once per column + per wavenumber 8*C_tab table
         # reads + 8*L tau written once (C_tab = 4 H2O + 1 O3 + 2 CFC + 3 CIA = 10 tables)
-        cols_launch = count / max(len(chunks), 1)          # columns per line-kernel launch on this rank (= --cols in weak mode)
+        cols_launch = count / max(len(chunks), 1)          # columns per line-kernel launch on this rank (= --chunk)
         bytes_gas = lambda nlines, n: cols_launch * (60.0 * nlines + n * (8.0 * 10 + 8.0 * L))
         dom_ms = ms[2][0] / max(ms[2][1], 1)
         achieved = bytes_gas(S["sw"], n_sw) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -338,24 +516,25 @@ def main():
         # HBM-side bytes per launch are PMC counters (FETCH_SIZE, WRITE_SIZE: separate rocprofv3 --pmc passes of this same
         # command, scripts/profile_round.sh) -- they cannot be read inside an ordinary run, so the figure of the last
         # profiled run is carried here, labelled as such, and dropped when the configuration differs
-        traffic, traffic_src, solver_traffic = None, None, {}
+        traffic, traffic_src, solver_traffic, sq = None, None, {}, {}
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("cols") == args.cols and tj.get("fast") == args.fast and not strong:
+                if tj.get("cols") == round(cols_launch) and tj.get("fast") == args.fast and (lw_grid[2], sw_grid[2]) == (1.0, 1.0) \
+                        and args.lw_lines is None and args.sw_lines is None:
                     traffic = tj["gas_optics_sw"]["hbm_bytes_per_launch"]
                     traffic_src = f"profiles/traffic_latest.json: rocprofv3 --pmc passes of this command, round tag {tj.get('tag')} (not measured in this run)"
                     solver_traffic = {k: v.get("hbm_bytes_per_launch") for k, v in tj.get("solvers", {}).items()}
+                    sq = tj["gas_optics_sw"].get("sq", {})
             except Exception:
                 traffic = None
-        total_cols = total_per_step * args.steps
         line_kernel = "gas_optics_mp_kernel" if args.fast in (1, 3) else "gas_optics_kernel"
         line = {
             "metric": "columns/sec (60-layer, 1 cm\u207b\u00b9 LBL, LW+SW)" if (lw_grid[2], sw_grid[2]) == (1.0, 1.0) else
                       f"columns/sec (60-layer LBL, LW @{lw_grid[2]:g} + SW @{sw_grid[2]:g} cm\u207b\u00b9)",
             "value": total_cols / elapsed, "unit": "columns/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            **dist_info, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             **({"rehearsal": "ranks share devices, gloo on host copies: timings are meaningless"} if rehearsal else {}), "dtype": "f64", "data": "synthetic",
             "config": {"workload": ("SURVEY §8d grid G1: LW 1-3250 + SW 1-50000 cm-1 @1 cm-1" if (lw_grid[2], sw_grid[2]) == (1.0, 1.0) else
@@ -364,11 +543,11 @@ def main():
                                    f", 60 layers, 7 absorbers, {S['lw']} LW + {S['sw']} SW synthetic lines, H2O/O3 continua, 2 CFC, 3 CIA, "
                                    "clear sky, integrated fluxes",
                        "columns_per_gpu_per_step": args.cols if not strong else None,
-                       "columns_per_step": total_per_step, "chunk_columns": args.cols, "fast": args.fast,
+                       "columns_per_step": total_per_step, "chunk_columns": chunk, "fast": args.fast,
                        "arithmetic": {0: "reference operation order", 1: "fused form, far wings by cell moments",
                                       2: "fused form, every window point in the ring",
                                       3: "fused form, far wings by cell moments, two passes"}.get(args.fast, str(args.fast)),
-                       "parallelism": f"columns sharded over {world} GPU(s), RCCL gather of 12 fluxes/column"},
+                       "parallelism": f"columns sharded over {world} GPU(s), one process per GPU; one RCCL gather of the job's 12 fluxes/column to rank 0"},
             "roofline": {"kernel": f"{line_kernel} (line-by-line tau), SW-band launch", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": dom_ms, "launches": ms[2][1],
@@ -379,7 +558,15 @@ def main():
                                       "delivers the far-wing points without evaluating them one by one)",
                               "frac": (valu_flop / (dom_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS) if dom_ms > 0 else 0.0,
                               "voigt_points_per_launch": points(S["sw"]),
-                              "gpoints_per_s": points(S["sw"]) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0},
+                              "gpoints_per_s": points(S["sw"]) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0,
+                              # What the vector pipe actually does (the algorithmic rate above is speed-up-shaped: far-wing
+                              # points are delivered by the moment series, not evaluated): SQ_INSTS_VALU of the profiled run
+                              # of this command over the issue slots of this run's launch -- 1 024 SIMDs, one wave64
+                              # instruction per two cycles at best
+                              "issue_utilisation": (sq["SQ_INSTS_VALU"] / (SIMDS * dom_ms * 1e-3 * CLOCK_HZ * 0.5)) if sq.get("SQ_INSTS_VALU") and dom_ms > 0 else None,
+                              "valu_wave_instructions_per_launch": sq.get("SQ_INSTS_VALU"),
+                              "instructions_per_64_lines": (sq["SQ_INSTS_VALU"] / (cols_launch * L * S["sw"] / 64.0)) if sq.get("SQ_INSTS_VALU") else None,
+                              "utilisation_source": traffic_src},
             "kernel_ms_per_step": {"gas_optics_lw": ms[1][0] / args.steps, "gas_optics_sw": ms[2][0] / args.steps,
                                    "far_field_lw": ms[6][0] / args.steps, "far_field_sw": ms[7][0] / args.steps,
                                    "lw_solver": ms[3][0] / args.steps, "sw_solver": ms[4][0] / args.steps,
@@ -412,23 +599,25 @@ def main():
             # what an unchanged caller of calculate_optical_depth gets: the reference-order form (fast = 0)
             wl.go_lw.tune(fast=0, tile=args.tile, nslice=args.lw_nslice)
             wl.go_sw.tune(fast=0, tile=args.tile)
-            step()
+            lo, n, gc, _ = chunks[0]
+            wl.pipe.run(gc, job[0].data_ptr())
             barrier()
             t0 = time.perf_counter()
             for _ in range(2):
-                step()
+                wl.pipe.run(gc, job[0].data_ptr())
             barrier()
-            line["reference_order_columns_per_s"] = 2 * total_per_step / (time.perf_counter() - t0)
+            line["reference_order_columns_per_s"] = 2 * n / (time.perf_counter() - t0)
             line["reference_abi"] = reference_abi_rate(wl)
             wl.go_lw.tune(fast=args.fast, tile=args.tile, nslice=args.lw_nslice)
             wl.go_sw.tune(fast=args.fast, tile=args.tile)
-            step()                              # column 0 of the production form back in the buffers (parity below)
-            barrier()
-            fluxes = out.cpu().numpy()
             if args.lw_dw is None and args.lw_lines is None:
                 line["fine_grid"] = {"G2_lw_0.1cm-1": fine_grid_column(wl, 0.1, 4),
                                      "G3_lw_0.001cm-1": fine_grid_column(wl, 0.001, 2, compare_layers=12)}
         if world == 1 and not args.no_cpu_baseline:
+            # the production form's column 0 back in the pipeline's buffers and in job[0] (parity below)
+            wl.pipe.run(chunks[0][2], job[0].data_ptr())
+            barrier()
+            fluxes = job[0].cpu().numpy()
             line["cpu_baseline"], ref_bands = cpu_baseline(lw_grid, sw_grid, args.lw_lines or W.LW_LINES,
                                                            args.sw_lines or W.SW_LINES)
             full = all(v["thin"] == 1 for v in line["cpu_baseline"]["detail"].values())

@@ -37,6 +37,21 @@
 #include <stdlib.h>
 #include <string.h>
 #include "grt_ext.h"
+#ifdef GRT_BACKTRACE    /* -DGRT_BACKTRACE -rdynamic: a fatal signal prints where it happened (tests build it that way) */
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+static void fatal_signal(int sig)
+{
+    void *frames[64];
+    int const n = backtrace(frames, 64);
+    char const msg[] = "rfmip_batch_driver: fatal signal, backtrace:\n";
+    if (write(2, msg, sizeof(msg) - 1) < 0) _exit(128 + sig);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+#endif
 
 #define check(call) { int rc_ = (call); if (rc_ != GRTCODE_SUCCESS) { char b_[4096]; \
     grtcode_errstr(rc_, b_, 4096); fprintf(stderr, "[%s:%d] %s\n", __FILE__, __LINE__, b_); return EXIT_FAILURE; } }
@@ -75,6 +90,12 @@ static void layers_to_levels(double *ppmv, double const *abundance, int num_laye
 
 int main(int argc, char **argv)
 {
+#ifdef GRT_BACKTRACE
+    signal(SIGSEGV, fatal_signal);
+    signal(SIGBUS, fatal_signal);
+    signal(SIGFPE, fatal_signal);
+    signal(SIGABRT, fatal_signal);
+#endif
     if (argc < 4)
     {
         fprintf(stderr, "usage: %s HITRAN.par SOLAR.csv COLUMNS.bin [options]\n", argv[0]);

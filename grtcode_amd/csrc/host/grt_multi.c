@@ -20,8 +20,11 @@
  * [world*per][12] IS the global array -- row r*per + i is column r*per + i -- and 100 columns over 8 ranks
  * (13,13,...,9) need no size exchange.
  */
+#define _GNU_SOURCE     /* dladdr */
+#include <dirent.h>
 #include <dlfcn.h>
 #include <errno.h>
+#include <fcntl.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -37,6 +40,7 @@ struct GrtMulti
     int transport, rank, world;
     Device_t device;
     char dir[DIR_PATH_LEN];
+    unsigned long long nonce;       /* file transport: this job's number, in every exchange file's name (see grt_multi_create) */
     unsigned long epoch;            /* one per collective call: names the files of that call */
     unsigned long seen_epoch;       /* file transport: the last grt_multi_max call whose marker file is still there */
     int have_seen;
@@ -64,8 +68,28 @@ static int rccl_open(void)
     {
         return GRTCODE_SUCCESS;
     }
-    char const *names[3] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+    /* RCCL must sit on the SAME HIP/HSA runtime instance as this library (a process can hold two copies of libamdhip64
+       -- PyTorch's wheel bundles its own next to its own librccl -- and only one of them gets the device: a communicator
+       made through the other fails with "no ROCm-capable device").  So: first the librccl that lies beside the
+       libamdhip64 this process resolves hipGetDeviceCount to, then the usual names. */
     void *h = NULL;
+    {
+        Dl_info info;
+        void *sym = dlsym(RTLD_DEFAULT, "hipGetDeviceCount");
+        if (sym != NULL && dladdr(sym, &info) != 0 && info.dli_fname != NULL)
+        {
+            char const *slash = strrchr(info.dli_fname, '/');
+            size_t const dirlen = slash != NULL ? (size_t)(slash - info.dli_fname) : 0;
+            char const *beside[2] = {"librccl.so.1", "librccl.so"};
+            for (int i = 0; i < 2 && h == NULL && dirlen > 0 && dirlen < DIR_PATH_LEN; ++i)
+            {
+                char path[DIR_PATH_LEN + 32];
+                snprintf(path, sizeof(path), "%.*s/%s", (int)dirlen, info.dli_fname, beside[i]);
+                h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+            }
+        }
+    }
+    char const *names[3] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
     for (int i = 0; i < 3 && h == NULL; ++i)
     {
         h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
@@ -151,6 +175,48 @@ static int read_file_wait(char const *path, void *data, size_t bytes, double tim
     }
 }
 
+/* Exchange files of the file transport: <kind>_<job nonce>_<epoch>_rank<r>.bin.  The nonce is drawn by rank 0 in
+   grt_multi_create and published as job.bin, so that no file of an earlier job in the same directory -- a marker left
+   behind, a block written before a crash -- can ever be taken for one of this job's. */
+static void exchange_name(GrtMulti_t const *m, char *path, size_t len, char const *kind, unsigned long epoch, int rank)
+{
+    snprintf(path, len, "%s/%s_%016llx_%lu_rank%d.bin", m->dir, kind, m->nonce, epoch, rank);
+}
+
+static unsigned long long draw_nonce(void)
+{
+    unsigned long long v = 0;
+    int const fd = open("/dev/urandom", O_RDONLY);
+    if (fd >= 0)
+    {
+        if (read(fd, &v, sizeof(v)) != (ssize_t)sizeof(v)) v = 0;
+        close(fd);
+    }
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    v ^= ((unsigned long long)ts.tv_sec << 32) ^ (unsigned long long)ts.tv_nsec ^ ((unsigned long long)getpid() << 48);
+    return v != 0 ? v : 1;
+}
+
+/* (quietly) wait for a file of `bytes` bytes: 1 when it is there, 0 after `timeout_s` */
+static int file_appears(char const *path, size_t bytes, double timeout_s)
+{
+    struct timespec const nap = {0, 2000000};
+    for (double waited = 0.; ; waited += 0.002)
+    {
+        struct stat st;
+        if (stat(path, &st) == 0 && (size_t)st.st_size == bytes)
+        {
+            return 1;
+        }
+        if (waited > timeout_s)
+        {
+            return 0;
+        }
+        nanosleep(&nap, NULL);
+    }
+}
+
 static double multi_timeout(void)
 {
     char const *env = getenv("GRT_MULTI_TIMEOUT");
@@ -211,6 +277,20 @@ EXTERN int grt_multi_create(GrtMulti_t **multi, int transport, Device_t device, 
         }
         if (rc == GRTCODE_SUCCESS) rc = rccl_check(rccl.CommInitRank(&m->comm, world, id, rank), "ncclCommInitRank");
     }
+    if (rc == GRTCODE_SUCCESS && transport == GRT_MULTI_FILES)
+    {
+        char path[DIR_PATH_LEN + 64];
+        snprintf(path, sizeof(path), "%s/job.bin", m->dir);
+        if (rank == 0)
+        {
+            m->nonce = draw_nonce();
+            rc = write_file_atomic(path, &m->nonce, sizeof(m->nonce));
+        }
+        else
+        {
+            rc = read_file_wait(path, &m->nonce, sizeof(m->nonce), multi_timeout());
+        }
+    }
     if (rc != GRTCODE_SUCCESS)
     {
         grt_err_frame(__FILE__, __LINE__);
@@ -229,25 +309,70 @@ EXTERN int grt_multi_destroy(GrtMulti_t **multi)
     {
         return GRTCODE_SUCCESS;
     }
+    /* everything is released whatever fails on the way; the first failure is what the caller hears of */
+    int rc = GRTCODE_SUCCESS;
+    char path[DIR_PATH_LEN + 96];
     if (m->transport == GRT_MULTI_RCCL)
     {
-        GRT_TRY(grt_dev_sync(m->device, grt_dev_stream(m->device)));
+        rc = grt_dev_sync(m->device, grt_dev_stream(m->device));
         if (m->comm != NULL)
         {
-            GRT_TRY(rccl_check(rccl.CommDestroy(m->comm), "ncclCommDestroy"));
+            int const r2 = rccl_check(rccl.CommDestroy(m->comm), "ncclCommDestroy");
+            rc = rc != GRTCODE_SUCCESS ? rc : r2;
         }
         if (m->rank == 0)
         {
             /* every rank has joined the communicator, so nobody still needs the id: a later job that reuses
                the directory must not pick up this one's */
-            char path[DIR_PATH_LEN + 64];
             snprintf(path, sizeof(path), "%s/rccl_unique_id.bin", m->dir);
             remove(path);
         }
-        GRT_TRY(grt_dev_free(m->device, m->pad_d));
+        int const r3 = grt_dev_free(m->device, m->pad_d);
+        rc = rc != GRTCODE_SUCCESS ? rc : r3;
+    }
+    else
+    {
+        /* File transport: a rank's last seen_ marker (grt_multi_max) has to outlive the call -- a slower peer may still be
+           waiting for it -- so it is still there now.  Every rank says it is done; rank 0 waits for all of them (briefly:
+           a rank that died says nothing) and then removes what this job left in the directory, its nonce first, so that
+           the directory is reusable after a clean run.  Files of other jobs carry other nonces and are not touched. */
+        double const one = 1.;
+        exchange_name(m, path, sizeof(path), "done", 0, m->rank);
+        int const r1 = write_file_atomic(path, &one, sizeof(one));
+        rc = rc != GRTCODE_SUCCESS ? rc : r1;
+        if (m->rank == 0)
+        {
+            double const patience = multi_timeout() < 10. ? multi_timeout() : 10.;
+            int all_done = 1;
+            for (int r = 1; r < m->world && all_done; ++r)
+            {
+                exchange_name(m, path, sizeof(path), "done", 0, r);
+                all_done = file_appears(path, sizeof(double), patience);    /* (a peer that never got here is not this call's failure) */
+            }
+            snprintf(path, sizeof(path), "%s/job.bin", m->dir);
+            remove(path);
+            char tag[32];
+            snprintf(tag, sizeof(tag), "_%016llx_", m->nonce);
+            DIR *d = opendir(m->dir);
+            if (d != NULL)
+            {
+                struct dirent *e;
+                while ((e = readdir(d)) != NULL)
+                {
+                    if (strstr(e->d_name, tag) != NULL)
+                    {
+                        char victim[DIR_PATH_LEN + 272];
+                        snprintf(victim, sizeof(victim), "%s/%s", m->dir, e->d_name);
+                        remove(victim);
+                    }
+                }
+                closedir(d);
+            }
+        }
     }
     free(m);
     *multi = NULL;
+    GRT_TRY(rc);
     return GRTCODE_SUCCESS;
 }
 
@@ -315,7 +440,7 @@ EXTERN int grt_multi_gather_fluxes(GrtMulti_t *m, fp_t const *local, int num_col
     int rc = GRTCODE_SUCCESS;
     if (m->rank != 0)
     {
-        snprintf(path, sizeof(path), "%s/fluxes_%lu_rank%d.bin", m->dir, epoch, m->rank);
+        exchange_name(m, path, sizeof(path), "fluxes", epoch, m->rank);
         rc = write_file_atomic(path, src, bytes);
     }
     else
@@ -337,7 +462,7 @@ EXTERN int grt_multi_gather_fluxes(GrtMulti_t *m, fp_t const *local, int num_col
         {
             int f = 0, c = 0;
             rc = grt_multi_shard(num_columns, r, m->world, &f, &c);
-            snprintf(path, sizeof(path), "%s/fluxes_%lu_rank%d.bin", m->dir, epoch, r);
+            exchange_name(m, path, sizeof(path), "fluxes", epoch, r);
             if (rc == GRTCODE_SUCCESS)
             {
                 rc = read_file_wait(path, stage + (size_t)r*per*row, sizeof(fp_t)*(size_t)c*row, multi_timeout());
@@ -395,34 +520,34 @@ EXTERN int grt_multi_max(GrtMulti_t *m, double *value)
     }
     unsigned long const epoch = m->epoch++;
     char path[DIR_PATH_LEN + 96];
-    snprintf(path, sizeof(path), "%s/max_%lu_rank%d.bin", m->dir, epoch, m->rank);
+    exchange_name(m, path, sizeof(path), "max", epoch, m->rank);
     GRT_TRY(write_file_atomic(path, value, sizeof(double)));
     double best = *value;
     for (int r = 0; r < m->world; ++r)
     {
         double v = 0.;
-        snprintf(path, sizeof(path), "%s/max_%lu_rank%d.bin", m->dir, epoch, r);
+        exchange_name(m, path, sizeof(path), "max", epoch, r);
         GRT_TRY(read_file_wait(path, &v, sizeof(double), multi_timeout()));
         best = v > best ? v : best;
     }
     if (m->have_seen)
     {
         /* every rank has entered this call, so every rank has left the previous one: its marker can go */
-        snprintf(path, sizeof(path), "%s/seen_%lu_rank%d.bin", m->dir, m->seen_epoch, m->rank);
+        exchange_name(m, path, sizeof(path), "seen", m->seen_epoch, m->rank);
         remove(path);
     }
     m->have_seen = 1;
     m->seen_epoch = epoch;
     /* everyone has read everyone's value once all ranks have passed a second round */
-    snprintf(path, sizeof(path), "%s/seen_%lu_rank%d.bin", m->dir, epoch, m->rank);
+    exchange_name(m, path, sizeof(path), "seen", epoch, m->rank);
     GRT_TRY(write_file_atomic(path, &best, sizeof(double)));
     for (int r = 0; r < m->world; ++r)
     {
         double v = 0.;
-        snprintf(path, sizeof(path), "%s/seen_%lu_rank%d.bin", m->dir, epoch, r);
+        exchange_name(m, path, sizeof(path), "seen", epoch, r);
         GRT_TRY(read_file_wait(path, &v, sizeof(double), multi_timeout()));
     }
-    snprintf(path, sizeof(path), "%s/max_%lu_rank%d.bin", m->dir, epoch, m->rank);
+    exchange_name(m, path, sizeof(path), "max", epoch, m->rank);
     remove(path);
     *value = best;
     return GRTCODE_SUCCESS;

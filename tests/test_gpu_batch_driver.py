@@ -50,6 +50,22 @@ def rfmip_like_columns(n, V):
     return cols, np.concatenate(raw)
 
 
+def run_driver(args, env=None, timeout=600):
+    """Run the C driver; if it dies on a signal, run it once more under rocgdb (where there is one) so that the failure
+    report carries the backtrace."""
+    r = subprocess.run(args, capture_output=True, text=True, timeout=timeout, env=env)
+    if r.returncode < 0:
+        import shutil
+        gdb = shutil.which("rocgdb") or shutil.which("gdb")
+        bt = ""
+        if gdb:
+            g = subprocess.run([gdb, "-batch", "-ex", "run", "-ex", "bt", "-ex", "info registers rip", "--args", *args],
+                               capture_output=True, text=True, timeout=timeout, env=env)
+            bt = "\n--- under " + gdb + " ---\n" + g.stdout[-6000:] + g.stderr[-2000:]
+        raise AssertionError(f"driver died on signal {-r.returncode}\n{r.stderr[-1500:]}{bt}")
+    return r
+
+
 def test_batched_c_driver_matches_oracle(tmp_path, oracle, lib):
     V, ncol = 13, 7
     cols, raw = rfmip_like_columns(ncol, V)
@@ -64,7 +80,7 @@ def test_batched_c_driver_matches_oracle(tmp_path, oracle, lib):
         f.write(np.array([GM[syn.CO2], GM[syn.CH4], GM[syn.N2O], GM[syn.CO], GM[syn.O2]]).tobytes())
         f.write(raw.astype("<f8").tobytes())
     exe = str(tmp_path / "rfmip_batch_driver")
-    r = subprocess.run(["gcc", "-std=gnu99", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
+    r = subprocess.run(["gcc", "-std=gnu99", "-O2", "-g", "-Wall", "-DGRT_BACKTRACE", "-rdynamic", "-I" + os.path.join(ROOT, "include"),
                         os.path.join(ROOT, "examples", "rfmip_batch_driver.c"), "-L" + LIBDIR, *ARCHIVES,
                         "-L/opt/rocm/lib", "-lamdhip64", "-lstdc++", "-lm", "-Wl,-rpath,/opt/rocm/lib", "-o", exe],
                        capture_output=True, text=True)
@@ -74,7 +90,7 @@ def test_batched_c_driver_matches_oracle(tmp_path, oracle, lib):
             "-N2-N2", swb.files["cia_n2n2"], "-O2-N2", swb.files["cia_o2n2"], "-O2-O2", swb.files["cia_o2o2"],
             "-w-lw", "1", "-W-lw", "2000", "-r-lw", "1", "-w-sw", "1", "-W-sw", "6000", "-r-sw", "2",
             "-chunk", "3", "-fast", "3"]
-    r = subprocess.run(args, capture_output=True, text=True, timeout=600)
+    r = run_driver(args)
     assert r.returncode == 0, r.stderr[-3000:]
     got = {}
     for line in r.stdout.splitlines():

@@ -134,8 +134,32 @@ def test_c_entry_points_gather_through_files(tmp_path, world, ncol):
         out, err = p.communicate(timeout=300)
         assert p.returncode == 0, (r, out, err[-2000:])
         assert f"rank {r} ok" in out
-    left = [f for f in os.listdir(rdv) if f.startswith("fluxes_") or f.startswith("max_")]
-    assert left == []                                      # every exchange file was consumed
+    assert os.listdir(rdv) == []                           # every exchange file, marker and the job's nonce are gone
+
+
+def test_rendezvous_directory_is_reusable_and_stale_files_are_ignored(tmp_path):
+    """a job used to leave its last seen_<epoch>_rank*.bin markers behind; the next job in the same directory
+    restarted its epochs at 0, met them, passed a barrier early and hung its peer.  File names now carry a per-job nonce
+    (rank 0 draws it, job.bin publishes it) and grt_multi_destroy clears what the job wrote.  Here: the same directory
+    three times in a row, with leftovers of a job that crashed -- old-style names and names under a foreign nonce --
+    lying in it throughout."""
+    script = tmp_path / "rank.py"
+    script.write_text(C_RANK % {"root": ROOT})
+    rdv = tmp_path / "rdv"
+    rdv.mkdir()
+    stale = ["seen_0_rank0.bin", "seen_0_rank1.bin", "max_1_rank1.bin", "fluxes_0_rank1.bin",
+             "seen_00000000deadbeef_1_rank1.bin", "max_00000000deadbeef_1_rank1.bin", "fluxes_00000000deadbeef_0_rank1.bin"]
+    for name in stale:
+        (rdv / name).write_bytes(np.full(60, -7.0).tobytes()[: 8 if not name.startswith("fluxes") else 480])
+    world, ncol = 2, 9
+    env = dict(os.environ, GRT_MULTI_TIMEOUT="60")
+    for job in range(3):
+        procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(ncol), str(rdv)], stdout=subprocess.PIPE,
+                                  stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
+        for r, p in enumerate(procs):
+            out, err = p.communicate(timeout=200)
+            assert p.returncode == 0, (job, r, out, err[-2000:])
+        assert sorted(os.listdir(rdv)) == sorted(stale), (job, os.listdir(rdv))
 
 
 def test_c_gather_reports_a_missing_rank(tmp_path):
