@@ -139,7 +139,7 @@ grt_tips_load grt_tips_reset grt_tips_is_table grt_tips_source grt_sizeof grt_ad
 grt_optical_depth_batch grt_pipeline_create grt_pipeline_create_ex grt_pipeline_destroy grt_pipeline_run grt_pipeline_sync
 grt_pipeline_stream grt_pipeline_views grt_device_malloc grt_device_free grt_device_to_host
 grt_host_to_device grt_debug_line_prep grt_debug_partition_functions grt_debug_voigt grt_debug_line_strengths grt_profile_enable grt_profile_read
-grt_set_deterministic grt_deterministic
+grt_set_deterministic grt_deterministic grt_gas_optics_probe grt_optics_cache_flush
 grt_multi_shard grt_multi_create grt_multi_destroy grt_multi_gather_fluxes grt_multi_broadcast grt_multi_max
 grt_err_begin grt_err_frame grt_log grt_gmalloc grt_gfree grt_gmemset grt_gmemcpy
 """.split()

@@ -93,6 +93,12 @@ typedef struct GrtGasOpticsArgs
                                  order, so that two runs agree to the last bit -- one wave of a workgroup takes all of its
                                  lines in store order, one line slice, and the two-pass form's first pass runs in
                                  tile_nphase launches of non-overlapping cell tiles.  A verification mode: ~4x slower. */
+    unsigned long long *probe;     /* != NULL (grt_gas_optics_probe; cell-moment kernels only): an instrumented instance of the
+                                 kernel runs and leaves 16 words per workgroup at record ((col L + layer) tiles + tile) nslice +
+                                 slice: clock at entry, clock at exit, candidate lines, R | corrected << 16 | moments << 17,
+                                 then sums over its waves of: 64-line blocks worked on, ring steps, near-centre points queued,
+                                 moment reductions, lane-by-lane moment adds, region-1 correction steps, near-centre walk steps.
+                                 Zeroed by the caller. */
     int tile_phase, tile_nphase;   /* set by the launcher: this launch takes cell tiles t with t % tile_nphase == tile_phase
                                  (tile_nphase <= 1: all of them) */
 } GrtGasOpticsArgs;
@@ -145,6 +151,10 @@ int grt_launch_rayleigh(void *stream, int num_layers, double w0, double dw, uint
 typedef struct GrtOpticsPtrs { double const *tau[8]; double const *omega[8]; double const *g[8]; } GrtOpticsPtrs;
 int grt_launch_add_optics(void *stream, uint64_t n, int num_optics, GrtOpticsPtrs const *in,
                           double *tau, double *omega, double *g);
+
+/* ... any K: table_dev is a DEVICE array [3][K] of array pointers (tau, omega, g of each object) */
+int grt_launch_add_optics_table(void *stream, uint64_t n, int num_optics, double const *const *table_dev,
+                                double *tau, double *omega, double *g);
 
 /* optics.c:306-321 */
 int grt_launch_sample_optics(void *stream, uint64_t n, uint64_t factor, double *tau,

@@ -313,7 +313,10 @@ __device__ __forceinline__ void drain_class(double *acc, Queue const *q, int wav
 // that a near field can reach -- and the far field is left to the cell hierarchy (gas_optics_tree_kernel).
 // LEAN: the launch covers wavenumbers whose Doppler widths lie far below the grid step (the longwave band at 1 cm-1):
 // the ring has a lean form for waves in which only a line's OWN grid point can be anything but Lorentzian.
-template <bool TWO_PASS, bool TREE, int K, bool LEAN = false>
+// PROBE: the instrumented instance (GrtGasOpticsArgs.probe): per-workgroup clocks and event counts, for the cost
+// analysis of scripts/line_cost_by_wavenumber.py; the production instances carry none of it.
+constexpr int kProbeWords = 16;
+template <bool TWO_PASS, bool TREE, int K, bool LEAN = false, bool PROBE = false>
 __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long long fsteps_ll, unsigned ngroups,
                                                unsigned perm_stride, int ncell, int nacc, int halo)
 {
@@ -343,6 +346,39 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
     long long const F0l = (long long)tile_idx*a.tile;
     long long const F1l = (F0l + a.tile < nw) ? F0l + a.tile : nw;                // [F0,F1)
     int const F0 = (int)F0l, F1 = (int)F1l;
+    unsigned long long *probe_rec = nullptr;
+    unsigned pc_blocks = 0, pc_ring = 0, pc_near = 0, pc_momred = 0, pc_momlane = 0, pc_pre2 = 0, pc_walk = 0;    // wave-uniform
+    if constexpr (PROBE)
+    {
+        unsigned long long const ntiles = ((unsigned long long)a.nw + a.tile - 1)/a.tile;
+        probe_rec = a.probe + ((((unsigned long long)col*a.lay.num_layers + layer)*ntiles + tile_idx)*a.nslice + slice)*kProbeWords;
+        if (tid == 0)
+        {
+            probe_rec[0] = __builtin_readcyclecounter();
+        }
+    }
+    auto probe_finish = [&](unsigned long long nlines, int R, bool corrected, bool use_moments)
+    {
+        if constexpr (PROBE)
+        {
+            if (lane == 0)
+            {
+                atomicAdd(&probe_rec[4], (unsigned long long)pc_blocks);
+                atomicAdd(&probe_rec[5], (unsigned long long)pc_ring);
+                atomicAdd(&probe_rec[6], (unsigned long long)pc_near);
+                atomicAdd(&probe_rec[7], (unsigned long long)pc_momred);
+                atomicAdd(&probe_rec[8], (unsigned long long)pc_momlane);
+                atomicAdd(&probe_rec[9], (unsigned long long)pc_pre2);
+                atomicAdd(&probe_rec[10], (unsigned long long)pc_walk);
+            }
+            if (tid == 0)
+            {
+                probe_rec[2] = nlines;
+                probe_rec[3] = (unsigned long long)R | ((unsigned long long)corrected << 16) | ((unsigned long long)use_moments << 17);
+                probe_rec[1] = __builtin_readcyclecounter();
+            }
+        }
+    };
     int const cell0 = TWO_PASS ? F0 : F0 - fsteps;                                // cell of mom[.][0]
     int const A0 = TWO_PASS ? F0 - halo : F0;                                     // grid index of acc[0]
 
@@ -453,6 +489,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         {
             continue;
         }
+        if constexpr (PROBE) ++pc_blocks;
         // the line's window, clipped to what the accumulator spans (two-pass form: the tile and `halo` points
         // either side -- the whole window, or, in the tree form, all that a near field can reach)
         int const lo = valid ? (TREE ? (s > A0 ? s : A0) : (TWO_PASS || s > F0 ? s : F0)) : 1;
@@ -587,6 +624,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                 int const c_ref = __builtin_amdgcn_readlane(c, __builtin_ctzll(vmask));
                 if (__ballot(valid & (c != c_ref)) == 0ull)
                 {
+                    if constexpr (PROBE) ++pc_momred;
                     float const t = row_sum_transposed(m, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0);
                     if ((lane & 1) == 0)
                     {
@@ -608,6 +646,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                     cr = min(cr, dpp_i<0x124>(cr));
                     cr = min(cr, dpp_i<0x128>(cr));                      // the row's lowest pending cell, in every lane
                     bool const mine = pending & (c == cr);
+                    if constexpr (PROBE) ++pc_momred;
                     float mm[kMom];
     #pragma unroll
                     for (int k = 0; k < kMom; ++k)
@@ -621,6 +660,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                     }
                     pending = pending & !mine;
                 }
+                if constexpr (PROBE) pc_momlane += (unsigned)__popcll(__ballot(pending));
                 if (pending)
                 {
 #pragma unroll
@@ -655,6 +695,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
             int const r_last = (int)ceilf(delta + span) - 1;        // largest integer < delta + span
             int const count = voigt_line ? r_last - r_first + 1 : 0;
             int const nmax = wave_max_s(count);
+            if constexpr (PROBE) pc_walk += (unsigned)nmax;
             for (int t = 0; t < nmax; ++t)
             {
                 int const r = r_first + t;
@@ -675,6 +716,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                             continue;
                         }
                         int const npush = __popcll(mk);
+                        if constexpr (PROBE) pc_near += (unsigned)npush;
                         if (qcount[q] + npush > Queue::capacity)
                         {
                             drain(q, 0, qcount[q]);
@@ -710,6 +752,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         {
             int const reach0 = direct_reg1 ? (int)(xlim0*rwr) + 1 : -1;       // (folded lines: the moments carry region 1)
             int const rmax = __ballot(reach0 > R) != 0ull ? wave_max_s(reach0) : -1;
+            if constexpr (PROBE) pc_pre2 += rmax > R ? (unsigned)(rmax - R) : 0u;
             for (int rr = R + 1; rr <= rmax; ++rr)
             {
 #pragma unroll
@@ -779,6 +822,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         {
             constexpr int PERIOD = decltype(period_tag)::value;
             constexpr int MODE = decltype(mode_tag)::value;
+            if constexpr (PROBE) pc_ring += PERIOD;
             float token = 0.f;
             float slotf = (float)(lane & (PERIOD - 1));
             float const base_rel = (float)(fbp - c);
@@ -992,6 +1036,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                 }
             }
         }
+        probe_finish(jend - jbeg, R, corrected, use_moments);
         return;
     }
     // ---- far field: every grid point of the tile gathers the moment series of the cells at
@@ -1020,6 +1065,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         __syncthreads();
     }
     write_tile(a, acc, cs, col, layer, slice, F0l, F1l, tid);
+    probe_finish(jend - jbeg, R, corrected, use_moments);
 }
 
 template <bool TWO_PASS, bool TREE = false, int K = kMom>
@@ -1037,6 +1083,15 @@ void gas_optics_mp_kernel_w4(GrtGasOpticsArgs a, long long fsteps_ll, unsigned n
                              int nacc, int halo)
 {
     mp_kernel_body<TWO_PASS, TREE, K, LEAN>(a, fsteps_ll, ngroups, perm_stride, ncell, nacc, halo);
+}
+
+// The instrumented instance of the two-pass first pass (single-level form), see mp_kernel_body<..., PROBE>.
+template <bool LEAN>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void gas_optics_mp_probe_kernel(GrtGasOpticsArgs a, long long fsteps_ll, unsigned ngroups, unsigned perm_stride, int ncell,
+                                int nacc, int halo)
+{
+    mp_kernel_body<true, false, kMom, LEAN, true>(a, fsteps_ll, ngroups, perm_stride, ncell, nacc, halo);
 }
 
 // Second pass of the two-pass form: workgroup = (tile of grid points, layer, column).  Stages the moments
@@ -1896,7 +1951,20 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
             {
                 // (a band that ends below 4 000 cm-1 -- the longwave -- takes the instance with the lean ring: 6.05 -> 5.9 ms at
                 // 1 cm-1; on the shortwave band the extra code cost more than the few waves it serves gained)
-                if (a->w0 + (double)a->nw*a->wres <= 4000.)
+                if (a->probe != NULL)
+                {
+                    if (a->w0 + (double)a->nw*a->wres <= 4000.)
+                    {
+                        hipLaunchKernelGGL((gas_optics_mp_probe_kernel<true>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
+                                           fsteps, (unsigned)ngroups, golden_stride(ngroups), ncell, nacc, halo);
+                    }
+                    else
+                    {
+                        hipLaunchKernelGGL((gas_optics_mp_probe_kernel<false>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
+                                           fsteps, (unsigned)ngroups, golden_stride(ngroups), ncell, nacc, halo);
+                    }
+                }
+                else if (a->w0 + (double)a->nw*a->wres <= 4000.)
                 {
                     hipLaunchKernelGGL((gas_optics_mp_kernel_w4<true, false, kMom, true>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
                                        fsteps, (unsigned)ngroups, golden_stride(ngroups), ncell, nacc, halo);

@@ -57,6 +57,29 @@ __global__ __launch_bounds__(kBlock) void add_optics_kernel(uint64_t n, int K, G
     }
 }
 
+// The same for any number of objects (the reference has no limit, optics.c:84-124): the K x 3 array pointers come from a
+// device table [3][K] (tau rows, omega rows, g rows) instead of the kernel arguments; same sums in the same order.
+__global__ __launch_bounds__(kBlock) void add_optics_table_kernel(uint64_t n, int K, double const *const *tab,
+                                                                  double *tau, double *omega, double *g)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x*kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x*kBlock)
+    {
+        double gs = 0., os = 0., ts = 0.;
+        for (int j = 0; j < K; ++j)
+        {
+            double const t = tab[j][i], o = tab[K + j][i], gg = tab[2*K + j][i];
+            gs += gg*o*t;
+            os += o*t;
+            ts += t;
+        }
+        gs /= os;
+        os /= ts;
+        g[i] = gs;
+        omega[i] = os;
+        tau[i] = ts;
+    }
+}
+
 // utilities/src/optics.c:306-321
 __global__ __launch_bounds__(kBlock) void sample_optics_kernel(uint64_t n, uint64_t factor, double *tau,
                                                                double *omega, double *g,
@@ -180,6 +203,18 @@ extern "C" int grt_launch_add_optics(void *stream, uint64_t n, int num_optics, G
     }
     hipLaunchKernelGGL(add_optics_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream,
                        n, num_optics, *in, tau, omega, g);
+    return (int)hipGetLastError();
+}
+
+extern "C" int grt_launch_add_optics_table(void *stream, uint64_t n, int num_optics, double const *const *table_dev,
+                                           double *tau, double *omega, double *g)
+{
+    if (num_optics < 1 || table_dev == NULL)
+    {
+        return (int)hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(add_optics_table_kernel, dim3(grid_for(n)), dim3(kBlock), 0, (hipStream_t)stream,
+                       n, num_optics, table_dev, tau, omega, g);
     return (int)hipGetLastError();
 }
 

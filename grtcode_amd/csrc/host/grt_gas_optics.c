@@ -70,25 +70,30 @@ static int host_lines_reserve(GrtHostLines *l, uint64_t cap)
    tabulated 296 K strengths; this factor is applied when the device store is built (upload_lines), with
    the partition sums of the provider current at that moment (grt_tips.c), so that a table loaded after
    add_molecule() is never mixed with strengths scaled by another provider. */
-void grt_rescale_strengths(int mol_id, uint64_t n, uint8_t const *iso, double const *v0, float const *en,
-                           double *s0)
+/* one line; q296 [GRT_MAX_ISO + 1]: this molecule's Q(296 K, iso), filled on first use (negative = not yet) */
+static inline void rescale_one(int mol_id, fp_t *q296, int iso, double v0, float en, double *s0)
 {
     fp_t const tref = 296.f;
     fp_t const c2 = -1.4387686f;
+    if (q296[iso] < 0.)
+    {
+        q296[iso] = Q(mol_id, tref, iso);
+    }
+    fp_t const e = en;
+    *s0 *= q296[iso]/(exp(c2*e/tref)*(1.f - exp(c2*v0/tref)));
+}
+
+void grt_rescale_strengths(int mol_id, uint64_t n, uint8_t const *iso, double const *v0, float const *en,
+                           double *s0)
+{
     fp_t q296[GRT_MAX_ISO + 1];
-    for (int k = 1; k <= GRT_MAX_ISO; ++k)
+    for (int k = 0; k <= GRT_MAX_ISO; ++k)
     {
         q296[k] = -1.;
     }
     for (uint64_t i = 0; i < n; ++i)
     {
-        int const k = iso[i];
-        if (q296[k] < 0.)
-        {
-            q296[k] = Q(mol_id, tref, k);
-        }
-        fp_t const e = en[i];
-        s0[i] *= q296[k]/(exp(c2*e/tref)*(1.f - exp(c2*v0[i]/tref)));
+        rescale_one(mol_id, q296, iso[i], v0[i], en[i], &s0[i]);
     }
 }
 
@@ -1100,6 +1105,10 @@ static int upload_lines(GasOptics_t *go, SortKey const *keys, uint64_t total, Gr
     }
     off[9] = bytes;
     unsigned char *host = malloc(bytes);
+    if (host == NULL)
+    {
+        GRT_FAIL(GRTCODE_NULL_ERR, "out of host memory staging %zu lines for the device.", (size_t)total);
+    }
     double *v0 = (double *)(host + off[0]), *s0 = (double *)(host + off[1]);
     float *yair = (float *)(host + off[2]), *yself = (float *)(host + off[3]);
     float *en = (float *)(host + off[4]), *nexp = (float *)(host + off[5]), *delta = (float *)(host + off[6]);
@@ -1123,16 +1132,21 @@ static int upload_lines(GasOptics_t *go, SortKey const *keys, uint64_t total, Gr
         if (h->yself[j] > st->yself_max[keys[k].slot]) st->yself_max[keys[k].slot] = h->yself[j];
         if (fabs((double)h->nexp[j]) > st->nmax) st->nmax = fabs((double)h->nexp[j]);
     }
-    /* strengths: tabulated -> the reference's pre-scaled form, molecule by molecule (runs of equal slot
-       are not contiguous in a merged store, so go line by line through a one-element view) */
+    /* strengths: tabulated -> the reference's pre-scaled form.  In a store merged by centre the molecules interleave
+       line by line, so Q(296 K) is kept per (slot, isotopologue) for the whole build -- a few dozen evaluations of the
+       provider instead of one per line */
     {
-        uint64_t k = 0;
-        while (k < total)
+        static fp_t q296[GRT_MAX_SLOTS][GRT_MAX_ISO + 1];
+        for (int sl = 0; sl < GRT_MAX_SLOTS; ++sl)
         {
-            uint64_t e = k + 1;
-            while (e < total && slot[e] == slot[k]) ++e;
-            grt_rescale_strengths(go->mols[slot[k]].id, e - k, iso + k, v0 + k, en + k, s0 + k);
-            k = e;
+            for (int k = 0; k <= GRT_MAX_ISO; ++k)
+            {
+                q296[sl][k] = -1.;
+            }
+        }
+        for (uint64_t k = 0; k < total; ++k)
+        {
+            rescale_one(go->mols[slot[k]].id, q296[slot[k]], iso[k], v0[k], en[k], &s0[k]);
         }
     }
     int rc = grt_dev_alloc(go->device, block, bytes);
@@ -1172,6 +1186,10 @@ static int build_store(GasOptics_t *go)
         return GRTCODE_SUCCESS;
     }
     SortKey *keys = malloc(sizeof(SortKey)*total);
+    if (keys == NULL)
+    {
+        GRT_FAIL(GRTCODE_NULL_ERR, "out of host memory sorting %zu lines.", (size_t)total);
+    }
     uint64_t k = 0;
     for (int s = 0; s < go->num_molecules; ++s)
     {
@@ -1189,6 +1207,11 @@ static int build_store(GasOptics_t *go)
     {
         /* the sweep methods work molecule by molecule (launch.c:78-159): one store each, sorted by centre */
         SortKey *mk = malloc(sizeof(SortKey)*total);
+        if (mk == NULL)
+        {
+            grt_err_begin(GRTCODE_NULL_ERR, __FILE__, __LINE__, "out of host memory for the per-molecule stores.%s", "");
+            rc = GRTCODE_NULL_ERR;
+        }
         for (int sl = 0; sl < go->num_molecules && rc == GRTCODE_SUCCESS; ++sl)
         {
             uint64_t n = 0;
@@ -1616,6 +1639,15 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
     {
         auto_tune(go, ncol, 0, &a->tile, &a->nslice);
     }
+    if (im->probe != NULL && a->fast == 3 && a->tree_levels == 0)
+    {
+        /* the instrumented instance of the two-pass first pass (cost analysis): 16 words per workgroup */
+        uint64_t const groups = ((a->nw + a->tile - 1)/a->tile)*(uint64_t)a->nslice*(uint64_t)go->num_layers*(uint64_t)ncol;
+        if (groups*16 <= im->probe_words)
+        {
+            a->probe = im->probe;
+        }
+    }
     if (grt_deterministic())
     {
         /* one line slice per tile (slices add to tau in the scheduler's order), one wave per workgroup on the lines, the
@@ -1886,6 +1918,20 @@ EXTERN int grt_debug_partition_functions(GasOptics_t *gas_optics, fp_t *pressure
         GRT_TRY(grt_dev_download(dev, q_out, im->colstate_d + im->layout.off_q, sizeof(double)*count, s));
     }
     GRT_TRY(grt_dev_sync(dev, s));
+    return GRTCODE_SUCCESS;
+}
+
+/* Cost analysis hook: with a device buffer of `words` 64-bit words (zeroed by the caller before each launch), launches of
+   the two-pass line kernel on single-level grids run an instrumented instance that leaves 16 words per workgroup --
+   clocks at entry and exit, candidate lines, near-field radius, event counts (grt_kernels.h: GrtGasOpticsArgs.probe) --
+   at record ((column L + layer) tiles + tile) nslice + slice.  NULL switches it off.  scripts/line_cost_by_wavenumber.py. */
+EXTERN int grt_gas_optics_probe(GasOptics_t *gas_optics, void *buffer_dev, uint64_t words)
+{
+    GRT_REQUIRE_PTR(gas_optics);
+    GRT_REQUIRE_PTR(gas_optics->impl);
+    GrtGasOpticsImpl *im = impl_of(gas_optics);
+    im->probe = buffer_dev;
+    im->probe_words = buffer_dev != NULL ? words : 0;
     return GRTCODE_SUCCESS;
 }
 

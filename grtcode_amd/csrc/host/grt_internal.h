@@ -100,6 +100,8 @@ typedef struct GrtGasOpticsImpl
     double *colstate_d;
     int tile, nslice, fast;        /* launch tuning (grt_gas_optics_tune) */
     int profile_tag;               /* 0: by grid size; the pipeline sets 1 (longwave) / 2 (shortwave) */
+    unsigned long long *probe;     /* grt_gas_optics_probe: device buffer for the instrumented line kernel, or NULL */
+    uint64_t probe_words;
 } GrtGasOpticsImpl;
 
 int grt_gas_optics_prepare(GasOptics_t *go, int ncol);   /* build store/tables/layout if stale */

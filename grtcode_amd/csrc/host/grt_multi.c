@@ -40,7 +40,7 @@ struct GrtMulti
     int transport, rank, world;
     Device_t device;
     char dir[DIR_PATH_LEN];
-    unsigned long long nonce;       /* file transport: this job's number, in every exchange file's name (see grt_multi_create) */
+    char tag[40];                   /* file transport: the job's tag (GRT_MULTI_JOB, default "0"), in every exchange file's name */
     unsigned long epoch;            /* one per collective call: names the files of that call */
     unsigned long seen_epoch;       /* file transport: the last grt_multi_max call whose marker file is still there */
     int have_seen;
@@ -175,27 +175,33 @@ static int read_file_wait(char const *path, void *data, size_t bytes, double tim
     }
 }
 
-/* Exchange files of the file transport: <kind>_<job nonce>_<epoch>_rank<r>.bin.  The nonce is drawn by rank 0 in
-   grt_multi_create and published as job.bin, so that no file of an earlier job in the same directory -- a marker left
-   behind, a block written before a crash -- can ever be taken for one of this job's. */
+/* Exchange files of the file transport: <kind>_<job tag>_<epoch>_rank<r>.bin.  Ranks of one job need not be alive at the
+   same time for a gather (a rank writes its block and leaves; rank 0 may start last), so the tag cannot be negotiated:
+   it comes from the launcher -- GRT_MULTI_JOB in the environment, the same for every rank of a job (letters, digits, '-';
+   default "0").  Two things keep a directory reusable: rank 0 removes everything its job wrote when it is destroyed
+   (grt_multi_destroy), and files of other tags are never looked at -- give every job its own tag and even the leftovers of
+   one that crashed are harmless. */
 static void exchange_name(GrtMulti_t const *m, char *path, size_t len, char const *kind, unsigned long epoch, int rank)
 {
-    snprintf(path, len, "%s/%s_%016llx_%lu_rank%d.bin", m->dir, kind, m->nonce, epoch, rank);
+    snprintf(path, len, "%s/%s_%s_%lu_rank%d.bin", m->dir, kind, m->tag, epoch, rank);
 }
 
-static unsigned long long draw_nonce(void)
+static void job_tag(char *tag, size_t len)
 {
-    unsigned long long v = 0;
-    int const fd = open("/dev/urandom", O_RDONLY);
-    if (fd >= 0)
+    char const *env = getenv("GRT_MULTI_JOB");
+    size_t n = 0;
+    for (char const *c = env; c != NULL && *c != '\0' && n + 1 < len; ++c)
     {
-        if (read(fd, &v, sizeof(v)) != (ssize_t)sizeof(v)) v = 0;
-        close(fd);
+        if ((*c >= '0' && *c <= '9') || (*c >= 'a' && *c <= 'z') || (*c >= 'A' && *c <= 'Z') || *c == '-')
+        {
+            tag[n++] = *c;
+        }
     }
-    struct timespec ts;
-    clock_gettime(CLOCK_REALTIME, &ts);
-    v ^= ((unsigned long long)ts.tv_sec << 32) ^ (unsigned long long)ts.tv_nsec ^ ((unsigned long long)getpid() << 48);
-    return v != 0 ? v : 1;
+    if (n == 0)
+    {
+        tag[n++] = '0';
+    }
+    tag[n] = '\0';
 }
 
 /* (quietly) wait for a file of `bytes` bytes: 1 when it is there, 0 after `timeout_s` */
@@ -277,20 +283,7 @@ EXTERN int grt_multi_create(GrtMulti_t **multi, int transport, Device_t device, 
         }
         if (rc == GRTCODE_SUCCESS) rc = rccl_check(rccl.CommInitRank(&m->comm, world, id, rank), "ncclCommInitRank");
     }
-    if (rc == GRTCODE_SUCCESS && transport == GRT_MULTI_FILES)
-    {
-        char path[DIR_PATH_LEN + 64];
-        snprintf(path, sizeof(path), "%s/job.bin", m->dir);
-        if (rank == 0)
-        {
-            m->nonce = draw_nonce();
-            rc = write_file_atomic(path, &m->nonce, sizeof(m->nonce));
-        }
-        else
-        {
-            rc = read_file_wait(path, &m->nonce, sizeof(m->nonce), multi_timeout());
-        }
-    }
+    job_tag(m->tag, sizeof(m->tag));
     if (rc != GRTCODE_SUCCESS)
     {
         grt_err_frame(__FILE__, __LINE__);
@@ -333,9 +326,9 @@ EXTERN int grt_multi_destroy(GrtMulti_t **multi)
     else
     {
         /* File transport: a rank's last seen_ marker (grt_multi_max) has to outlive the call -- a slower peer may still be
-           waiting for it -- so it is still there now.  Every rank says it is done; rank 0 waits for all of them (briefly:
-           a rank that died says nothing) and then removes what this job left in the directory, its nonce first, so that
-           the directory is reusable after a clean run.  Files of other jobs carry other nonces and are not touched. */
+           waiting for it -- so it is still there now.  Every rank says it is done and leaves; rank 0 waits for all of them
+           (briefly: a rank that died says nothing) and then removes what this job left in the directory, so that the
+           directory is reusable after a clean run.  Files of other jobs' tags are not touched. */
         double const one = 1.;
         exchange_name(m, path, sizeof(path), "done", 0, m->rank);
         int const r1 = write_file_atomic(path, &one, sizeof(one));
@@ -349,17 +342,27 @@ EXTERN int grt_multi_destroy(GrtMulti_t **multi)
                 exchange_name(m, path, sizeof(path), "done", 0, r);
                 all_done = file_appears(path, sizeof(double), patience);    /* (a peer that never got here is not this call's failure) */
             }
-            snprintf(path, sizeof(path), "%s/job.bin", m->dir);
-            remove(path);
-            char tag[32];
-            snprintf(tag, sizeof(tag), "_%016llx_", m->nonce);
+            char const *kinds[4] = {"fluxes", "max", "seen", "done"};
             DIR *d = opendir(m->dir);
             if (d != NULL)
             {
                 struct dirent *e;
                 while ((e = readdir(d)) != NULL)
                 {
-                    if (strstr(e->d_name, tag) != NULL)
+                    int ours = 0;
+                    for (int k = 0; k < 4 && !ours; ++k)
+                    {
+                        char prefix[64];
+                        int const n = snprintf(prefix, sizeof(prefix), "%s_%s_", kinds[k], m->tag);
+                        /* <kind>_<tag>_<digits>_rank<digits>.bin and nothing else */
+                        if (strncmp(e->d_name, prefix, (size_t)n) == 0)
+                        {
+                            char const *c = e->d_name + n;
+                            while (*c >= '0' && *c <= '9') ++c;
+                            ours = c > e->d_name + n && strncmp(c, "_rank", 5) == 0;
+                        }
+                    }
+                    if (ours)
                     {
                         char victim[DIR_PATH_LEN + 272];
                         snprintf(victim, sizeof(victim), "%s/%s", m->dir, e->d_name);

@@ -11,7 +11,13 @@
    driver.c:382-383, 424): hipMalloc + hipFree of 3 x 24 MB, the latter a device-wide synchronisation -- 0.4 ms of a
    6 ms column.  Destroyed device blocks are therefore parked (a handful, exact size match) and handed out again. */
 #define GRT_OPTICS_CACHE 6
-static struct { Device_t device; size_t bytes; void *block; } g_optics_cache[GRT_OPTICS_CACHE];
+/* What may stay parked: blocks of at most GRT_OPTICS_PARK_MAX bytes each (a 0.001 cm-1 grid's block is 4.7 GB: not worth
+   holding for the sake of 0.4 ms), oldest entry evicted when the slots are full, everything released by
+   grt_optics_cache_flush() (grt_ext.h).  Process-global and -- like the reference's error buffer and the rest of this
+   interface -- for one caller thread. */
+#define GRT_OPTICS_PARK_MAX ((size_t)512 << 20)
+static struct { Device_t device; size_t bytes; void *block; unsigned long stamp; } g_optics_cache[GRT_OPTICS_CACHE];
+static unsigned long g_optics_stamp = 0;
 
 static void *optics_cache_take(Device_t device, size_t bytes)
 {
@@ -27,19 +33,56 @@ static void *optics_cache_take(Device_t device, size_t bytes)
     return NULL;
 }
 
+/* 1 when the block was parked (possibly in the place of the oldest entry, which is freed) */
 static int optics_cache_put(Device_t device, size_t bytes, void *block)
 {
+    if (bytes > GRT_OPTICS_PARK_MAX)
+    {
+        return 0;
+    }
+    int slot = -1, oldest = 0;
     for (int i = 0; i < GRT_OPTICS_CACHE; ++i)
     {
         if (g_optics_cache[i].block == NULL)
         {
-            g_optics_cache[i].device = device;
-            g_optics_cache[i].bytes = bytes;
-            g_optics_cache[i].block = block;
-            return 1;
+            slot = i;
+            break;
+        }
+        if (g_optics_cache[i].stamp < g_optics_cache[oldest].stamp)
+        {
+            oldest = i;
         }
     }
-    return 0;
+    if (slot < 0)
+    {
+        /* full: the entry parked longest ago is of a size nobody has asked for since (another grid, another band) */
+        if (grt_dev_free(g_optics_cache[oldest].device, g_optics_cache[oldest].block) != GRTCODE_SUCCESS)
+        {
+            return 0;
+        }
+        slot = oldest;
+    }
+    g_optics_cache[slot].device = device;
+    g_optics_cache[slot].bytes = bytes;
+    g_optics_cache[slot].block = block;
+    g_optics_cache[slot].stamp = ++g_optics_stamp;
+    return 1;
+}
+
+EXTERN int grt_optics_cache_flush(void)
+{
+    int rc = GRTCODE_SUCCESS;
+    for (int i = 0; i < GRT_OPTICS_CACHE; ++i)
+    {
+        if (g_optics_cache[i].block != NULL)
+        {
+            int const r = grt_dev_free(g_optics_cache[i].device, g_optics_cache[i].block);
+            rc = rc != GRTCODE_SUCCESS ? rc : r;
+            g_optics_cache[i].block = NULL;
+        }
+    }
+    GRT_TRY(rc);
+    return GRTCODE_SUCCESS;
 }
 
 /* host_visible: the arrays live in host memory that the device reads and writes through the same pointers, so a
@@ -137,11 +180,9 @@ EXTERN int add_optics(Optics_t const * const * const optics, int const num_optic
 {
     GRT_REQUIRE_PTR(optics);
     GRT_REQUIRE_PTR(result);
-    GRT_REQUIRE_RANGE(num_optics, 1, 8);
+    GRT_REQUIRE_RANGE(num_optics, 1, 1 << 20);       /* (the reference has no limit: optics.c:84-124) */
     Optics_t const *first = optics[0];
     GRT_REQUIRE_PTR(first);
-    GrtOpticsPtrs in;
-    memset(&in, 0, sizeof(in));
     for (int j = 0; j < num_optics; ++j)
     {
         GRT_REQUIRE_PTR(optics[j]);
@@ -152,16 +193,56 @@ EXTERN int add_optics(Optics_t const * const * const optics, int const num_optic
             GRT_FAIL(GRTCODE_VALUE_ERR, "input optics objects (%p, %p) are incompatible.",
                      (void const *)first, (void const *)optics[j]);
         }
-        in.tau[j] = optics[j]->tau;
-        in.omega[j] = optics[j]->omega;
-        in.g[j] = optics[j]->g;
     }
     GRT_TRY(create_optics_in(result, first->num_layers, &first->grid, &first->device, 0));
     void *s = grt_dev_stream(first->device);
     uint64_t const n = (uint64_t)first->num_layers*first->grid.n;
-    GRT_TRY(grt_dev_check(grt_launch_add_optics(s, n, num_optics, &in, result->tau, result->omega,
-                                                result->g), "add_optics kernel"));
-    GRT_TRY(grt_dev_sync(first->device, s));
+    int rc;
+    if (num_optics <= 8)
+    {
+        /* the usual case (a driver combines 2 to 4 objects): array pointers travel as kernel arguments */
+        GrtOpticsPtrs in;
+        memset(&in, 0, sizeof(in));
+        for (int j = 0; j < num_optics; ++j)
+        {
+            in.tau[j] = optics[j]->tau;
+            in.omega[j] = optics[j]->omega;
+            in.g[j] = optics[j]->g;
+        }
+        rc = grt_dev_check(grt_launch_add_optics(s, n, num_optics, &in, result->tau, result->omega, result->g),
+                           "add_optics kernel");
+        if (rc == GRTCODE_SUCCESS) rc = grt_dev_sync(first->device, s);
+    }
+    else
+    {
+        /* any number of objects: the pointers go through a device table [3][K] */
+        size_t const K = (size_t)num_optics;
+        double const **tab_h = malloc(sizeof(double *)*3*K);
+        void *tab_d = NULL;
+        rc = tab_h != NULL ? GRTCODE_SUCCESS : GRTCODE_NULL_ERR;
+        for (size_t j = 0; j < K && rc == GRTCODE_SUCCESS; ++j)
+        {
+            tab_h[j] = optics[j]->tau;
+            tab_h[K + j] = optics[j]->omega;
+            tab_h[2*K + j] = optics[j]->g;
+        }
+        if (rc == GRTCODE_SUCCESS) rc = grt_dev_alloc(first->device, &tab_d, sizeof(double *)*3*K);
+        if (rc == GRTCODE_SUCCESS) rc = grt_dev_upload(first->device, tab_d, tab_h, sizeof(double *)*3*K, s);
+        if (rc == GRTCODE_SUCCESS) rc = grt_dev_check(grt_launch_add_optics_table(s, n, num_optics, (double const *const *)tab_d,
+                                                                                   result->tau, result->omega, result->g),
+                                                      "add_optics kernel (pointer table)");
+        if (rc == GRTCODE_SUCCESS) rc = grt_dev_sync(first->device, s);
+        grt_dev_free(first->device, tab_d);
+        free(tab_h);
+    }
+    if (rc != GRTCODE_SUCCESS)
+    {
+        grt_err_frame(__FILE__, __LINE__);
+        Optics_t dead = *result;
+        destroy_optics(&dead);
+        result->g = result->omega = result->tau = NULL;
+        return rc;
+    }
     return GRTCODE_SUCCESS;
 }
 

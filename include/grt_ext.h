@@ -116,7 +116,10 @@ EXTERN int grt_pipeline_create(GrtPipeline_t **pipeline, GasOptics_t *lw_gas, Ga
                                fp_t const *albedo, fp_t const *solar_flux);
 /* keep_spectra = 0 (what grt_pipeline_create does): production form -- the solvers form Rayleigh and the optics
    combination in registers from tau_gas, keep nothing spectral and integrate in-kernel; device memory per column is
-   tau_gas (+ 2 x [levels][n] scratch in the shortwave) instead of four optics and two flux arrays.
+   tau_gas -- plus, in the shortwave, the first sweep's parked rows [2 V + 5 L][n] per column (reflectances of V levels
+   twice, five properties of every layer: 422 rows at 60 layers, 1.35 GB for 8 columns of 50 000 points) and
+   6 x nblocks partial sums -- instead of four optics and two flux arrays.  (api.Pipeline in Python defaults to
+   spectral=True, i.e. keep_spectra = 1, because the parity tests want spectra; this C entry point defaults to 0.)
    keep_spectra = 1: tau, omega, g and flux_up/down are materialised as the reference's calls would leave them
    (grt_pipeline_views; parity tests, spectral output). */
 EXTERN int grt_pipeline_create_ex(GrtPipeline_t **pipeline, GasOptics_t *lw_gas, GasOptics_t *sw_gas,
@@ -144,9 +147,12 @@ EXTERN int grt_pipeline_views(GrtPipeline_t *pipeline, int band, fp_t **tau_gas,
  * communicator id travels through `rendezvous_dir`, a directory all ranks see); GRT_MULTI_FILES: per-rank files in
  * `rendezvous_dir` assembled by rank 0 (host or device pointers, synchronous) -- the reference's own scheme, and the
  * way the multi-rank path runs where there is no GPU.  GRT_MULTI_TIMEOUT [s] bounds every wait (default 600).
- * `rendezvous_dir` must hold nothing from another job when the ranks start: a job's exchange files are removed as
- * they are read and rank 0 removes the communicator id in grt_multi_destroy, so a directory is reusable after a
- * clean run; after a crash, empty it. */
+ * File transport: exchange files are named <kind>_<job tag>_<call number>_rank<r>.bin, the tag being GRT_MULTI_JOB in the
+ * environment (the same for all ranks of a job; letters, digits, '-'; default "0").  A gather needs no two ranks alive at
+ * the same time (a rank writes its block and leaves; rank 0 may start last); grt_multi_max is a barrier and does.  Rank 0
+ * removes everything its job wrote when it is destroyed, so a directory is reusable after a clean run; files under other
+ * tags are never touched or read, so with a tag of its own a job is also safe from the leftovers of one that crashed
+ * (without tags: empty the directory after a crash).  RCCL transport: rank 0 removes the communicator id on destroy. */
 enum grt_multi_transport { GRT_MULTI_RCCL = 0, GRT_MULTI_FILES = 1 };
 typedef struct GrtMulti GrtMulti_t;
 /* rank's block of a num_columns-column set: [first, first + count), count <= ceil(num_columns/world), 0 for ranks beyond the end */
@@ -168,6 +174,13 @@ EXTERN int grt_multi_max(GrtMulti_t *multi, double *value);    /* barrier + maxi
 EXTERN int grt_profile_enable(int on);
 EXTERN int grt_profile_read(int tag, double *total_ms, int *launches, int reset);
 
+/* ---- parked Optics_t blocks -------------------------------------------------------------
+ * destroy_optics parks a device block (at most six, none above 512 MB, oldest evicted first) so that the next
+ * create_optics / add_optics of the same size -- a driver's column loop does both per band and column
+ * (driver.c:382-383, 424) -- skips hipFree + hipMalloc.  grt_optics_cache_flush() gives the parked blocks back to the
+ * device, e.g. before a large allocation.  One caller thread, as everywhere in this interface. */
+EXTERN int grt_optics_cache_flush(void);
+
 /* ---- plain device-memory helpers for FFI callers (tests, bench) -------------------- */
 EXTERN int grt_device_malloc(Device_t device, void **ptr, size_t bytes);
 EXTERN int grt_device_free(Device_t device, void *ptr);
@@ -182,6 +195,15 @@ EXTERN int grt_debug_line_prep(GasOptics_t *gas_optics, fp_t *pressure, fp_t *te
                                uint64_t *num_lines, uint8_t *slot, double *v0, double *vnn,
                                double *snn, double *gamma, double *alpha, int64_t *win_s,
                                int64_t *win_e);
+
+/* ---- cost-analysis hook: per-workgroup clocks and event counts of the two-pass line kernel (single-level grids).
+ * buffer_dev: DEVICE memory of `words` 64-bit words, zeroed by the caller before each launch; 16 words per workgroup at
+ * record ((column L + layer) tiles + tile) nslice + slice: clock at entry, clock at exit, candidate lines,
+ * R | corrected << 16 | moments << 17, then sums over the workgroup's waves of 64-line blocks worked on, ring steps,
+ * near-centre points queued, moment reductions, lane-by-lane moment adds, region-1 correction steps, near-centre walk
+ * steps.  An instrumented instance of the kernel runs while a buffer is set (tile/nslice: grt_gas_optics_last_launch);
+ * NULL switches back to the production instance.  scripts/line_cost_by_wavenumber.py. */
+EXTERN int grt_gas_optics_probe(GasOptics_t *gas_optics, void *buffer_dev, uint64_t words);
 
 /* ---- parity hook: the strengths of the device line store (merged store order) as the kernels read them, i.e. after
  * the rescaling of parse_HITRAN_file.c:372-384 with the partition sums current at the last build.  Pass s0_out = NULL

@@ -59,6 +59,30 @@ def test_add_optics_bit_exact_and_gas_only_nan(oracle, device):
         o.destroy()
 
 
+@pytest.mark.parametrize("K", [8, 9, 23])
+def test_add_optics_any_number_of_objects(oracle, lib, device, K):
+    """The reference's add_optics has no limit on the number of objects (optics.c:84-124); eight travel as kernel
+    arguments, more through a device pointer table -- same sums in the same order, so bit-exact either way.  Also
+    exercises the parked-block cache: 23 objects of one size destroyed, evicted oldest-first, then flushed."""
+    rng = np.random.default_rng(100 + K)
+    grid = api.create_spectral_grid(100.0, 228.0, 0.5)
+    L, n = 4, grid.n
+    sets = [random_optics(rng, L, n) for _ in range(K)]
+    objs = []
+    for t, om, g in sets:
+        o = api.OpticsObject(L, grid, device)
+        o.update(t, om, g)
+        objs.append(o)
+    res = api.add_optics(objs)
+    tau, omega, g = res.read()
+    wt, wo, wg = oracle.add_optics([s[0] for s in sets], [s[1] for s in sets], [s[2] for s in sets])
+    assert np.array_equal(tau, wt) and np.array_equal(omega, wo) and np.array_equal(g, wg)
+    for o in objs + [res]:
+        o.destroy()
+    api.check(lib.grt_optics_cache_flush())
+    api.check(lib.grt_optics_cache_flush())        # idempotent
+
+
 def test_add_optics_rejects_incompatible(device):
     g1 = api.create_spectral_grid(100.0, 400.0, 0.5)
     g2 = api.create_spectral_grid(100.0, 400.0, 1.0)

@@ -139,27 +139,44 @@ def test_c_entry_points_gather_through_files(tmp_path, world, ncol):
 
 def test_rendezvous_directory_is_reusable_and_stale_files_are_ignored(tmp_path):
     """a job used to leave its last seen_<epoch>_rank*.bin markers behind; the next job in the same directory
-    restarted its epochs at 0, met them, passed a barrier early and hung its peer.  File names now carry a per-job nonce
-    (rank 0 draws it, job.bin publishes it) and grt_multi_destroy clears what the job wrote.  Here: the same directory
-    three times in a row, with leftovers of a job that crashed -- old-style names and names under a foreign nonce --
-    lying in it throughout."""
+    restarted its epochs at 0, met them, passed a barrier early and hung its peer.  Now rank 0 clears what its job wrote
+    when it is destroyed, and file names carry a job tag (GRT_MULTI_JOB) so that files of other jobs are never read.
+    Here: the same directory three times in a row under one tag, a fourth time under the default tag, with leftovers of
+    a crashed job under a third tag -- markers, blocks of the right size with wrong numbers -- lying in it throughout."""
     script = tmp_path / "rank.py"
     script.write_text(C_RANK % {"root": ROOT})
     rdv = tmp_path / "rdv"
     rdv.mkdir()
-    stale = ["seen_0_rank0.bin", "seen_0_rank1.bin", "max_1_rank1.bin", "fluxes_0_rank1.bin",
-             "seen_00000000deadbeef_1_rank1.bin", "max_00000000deadbeef_1_rank1.bin", "fluxes_00000000deadbeef_0_rank1.bin"]
+    stale = ["seen_crashed_0_rank0.bin", "seen_crashed_0_rank1.bin", "seen_crashed_1_rank1.bin", "max_crashed_1_rank1.bin",
+             "fluxes_crashed_0_rank1.bin", "done_crashed_0_rank1.bin", "notes.txt"]
     for name in stale:
-        (rdv / name).write_bytes(np.full(60, -7.0).tobytes()[: 8 if not name.startswith("fluxes") else 480])
+        (rdv / name).write_bytes(np.full(60, -7.0).tobytes()[: 384 if name.startswith("fluxes") else 8])
     world, ncol = 2, 9
-    env = dict(os.environ, GRT_MULTI_TIMEOUT="60")
-    for job in range(3):
+    for job, tag in enumerate(["nightly-7", "nightly-7", "nightly-7", None]):
+        env = dict(os.environ, GRT_MULTI_TIMEOUT="60")
+        env.pop("GRT_MULTI_JOB", None)
+        if tag:
+            env["GRT_MULTI_JOB"] = tag
         procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), str(ncol), str(rdv)], stdout=subprocess.PIPE,
                                   stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
         for r, p in enumerate(procs):
             out, err = p.communicate(timeout=200)
             assert p.returncode == 0, (job, r, out, err[-2000:])
         assert sorted(os.listdir(rdv)) == sorted(stale), (job, os.listdir(rdv))
+
+
+def test_ranks_need_not_be_alive_together_for_a_gather(tmp_path):
+    """Rank 1 writes its block, says it is done and exits before rank 0 even starts (how 8 ranks take turns on one GPU in
+    tests/test_gpu_baseline_configs.py): no step of the gather may wait for rank 0."""
+    script = tmp_path / "rank.py"
+    script.write_text(C_RANK.replace("assert m.max(10.0 + rank + step) == 10.0 + (world - 1) + step", "pass") % {"root": ROOT})
+    rdv = tmp_path / "rdv"
+    rdv.mkdir()
+    env = dict(os.environ, GRT_MULTI_TIMEOUT="30")
+    for r in (1, 0):
+        p = subprocess.run([sys.executable, str(script), str(r), "2", "5", str(rdv)], capture_output=True, text=True, timeout=120, env=env)
+        assert p.returncode == 0, (r, p.stdout, p.stderr[-2000:])
+    assert os.listdir(rdv) == []
 
 
 def test_c_gather_reports_a_missing_rank(tmp_path):
