@@ -70,6 +70,8 @@ def probe_band(api, wl, go, grid, tag, far_tag, cols, gcols):
         return {"ms_of_probe_launch": ms, "ms_of_production_launch": prod_ms * sel_cyc.sum() / total_cyc,
                 "share": sel_cyc.sum() / total_cyc, "line_layer_columns": nl,
                 "ns_per_line_layer_column": 1e6 * (prod_ms * sel_cyc.sum() / total_cyc) / max(nl, 1.0),
+                # VERDICT r2's normalisation: launch time over the lines of the store (a launch = L layers x cols columns)
+                "ns_per_line_per_launch": 1e6 * (prod_ms * sel_cyc.sum() / total_cyc) / max(nl / (L * cols), 1.0),
                 "workgroup_kcycles_per_64_lines": 1e-3 * sel_cyc.sum() / max(nl / 64.0, 1.0),
                 "ring_steps_per_block": sel_cnt["ring_steps"].sum() / blocks,
                 "near_points_per_line": sel_cnt["near_points"].sum() / max(nl, 1.0),
