@@ -674,8 +674,13 @@ EXTERN int create_gas_optics(GasOptics_t * const gas_optics, int const num_level
     }
     go->impl = im;
     {
-        /* arithmetic form of the line kernel for callers that cannot call grt_gas_optics_tune (an unchanged
-           reference driver): GRT_GAS_OPTICS_FAST=0|1|2 in the environment; default 0 (reference order) */
+        /* Arithmetic form of the line kernel.  A new object runs the PRODUCTION form (fast = 3: fused arithmetic, far wings
+           by cell moments, two passes): fluxes within ~1e-5 W m-2 of the reference's, two orders inside the 1e-3 the
+           interface promises, at 3.3x the speed of the reference-order form through these one-column calls.  Callers that
+           cannot call grt_gas_optics_tune (an unchanged reference driver) choose with GRT_GAS_OPTICS_FAST=0|1|2|3 in the
+           environment; 0 = the reference's operation order (tau within 1e-11).  The sweep methods always run in
+           reference order. */
+        im->fast = 3;
         char const *env = getenv("GRT_GAS_OPTICS_FAST");
         if (env != NULL && env[0] >= '0' && env[0] <= '3' && env[1] == '\0')
         {
@@ -1418,6 +1423,8 @@ static void auto_tune(GasOptics_t const *go, int ncol, int moments, int *tile, i
 {
     GrtGasOpticsImpl const *im = impl_of(go);
     uint64_t const nw = go->grid.n;
+    /* lines a workgroup of `cells` cells has to prepare, on average */
+    double const per_cell = nw > 0 ? (double)im->store.n/(double)nw : 0.;
     int t = im->tile;
     if (t == 0)
     {
@@ -1426,8 +1433,12 @@ static void auto_tune(GasOptics_t const *go, int ncol, int moments, int *tile, i
            1 cm-1: four workgroups per CU) */
         int want = moments == 2 ? 256 : (moments ? 512 : 1024);
         /* two-pass form on a short grid: narrower tiles before line slices (the G1 longwave band, 3 250 points x 60
-           layers x 8 columns: 64-cell tiles in one slice 5.75 ms, 256-cell tiles in four slices 5.92 ms) */
-        while (moments == 2 && want > 64 && ((nw + want - 1)/want)*(uint64_t)go->num_layers*(uint64_t)ncol < 16384)
+           layers x 8 columns: 64-cell tiles in one slice 5.75 ms, 256-cell tiles in four slices 5.92 ms) -- as long as
+           a tile keeps a few thousand lines: a workgroup's fixed costs (column state, the table of temperature powers,
+           clearing and flushing its accumulators) are paid per tile.  One column of the G1 shortwave band (30 lines per
+           cell): 256-cell tiles 1.91 ms, 128-cell tiles 1.98-2.14 ms. */
+        while (moments == 2 && want > 64 && ((nw + want - 1)/want)*(uint64_t)go->num_layers*(uint64_t)ncol < 16384
+               && per_cell*(double)(want/2) >= 6000.)
         {
             want >>= 1;
         }
@@ -1443,12 +1454,14 @@ static void auto_tune(GasOptics_t const *go, int ncol, int moments, int *tile, i
     int ns = im->nslice;
     if (ns == 0)
     {
-        /* enough workgroups to cover 256 CUs (1 024 resident workgroups) many times over: the G1 longwave band -- 13
-           tiles x 60 layers x 8 columns = 6 240 workgroups of 77 000 lines each -- measured 6.34 ms in one slice,
-           6.14 in two or four, 6.28 in eight */
+        /* enough workgroups to cover 256 CUs (1 024 resident workgroups) several times over, but no slice of fewer than
+           ~8 000 lines.  Measured, G1 longwave band (308 lines per cell), 8 columns x 256-cell tiles (6 240 workgroups
+           unsliced): one slice 6.34 ms, two or four 6.14, eight 6.28; ONE column x 64-cell tiles (3 060 workgroups,
+           19 700 lines each): one slice 0.85 ms, two 0.81, four 0.81, eight 0.90-0.99. */
         uint64_t const blocks = ((nw + t - 1)/t)*(uint64_t)go->num_layers*(uint64_t)ncol;
+        double const per_tile = per_cell*(double)t;
         ns = 1;
-        while (blocks*ns < 16384 && ns < 16)
+        while (blocks*ns < 16384 && ns < 16 && per_tile/(double)(2*ns) >= 8000.)
         {
             ns *= 2;
         }

@@ -56,12 +56,15 @@ EXTERN int grt_add_molecule_lines(GasOptics_t *gas_optics, int molecule_id, uint
                                   double const *nexp, double const *delta);
 
 /* ---- launch tuning for the line kernel (tile, nslice: 0 keeps the automatic value) --
- * fast: 0 = reference operation order (default of a new object: tau within 1e-11 of the
- *          reference's), 1 = fused arithmetic with the far wings summed by cell moments
- *          (production form of the batched pipeline: tau within 2e-6 of each layer's maximum,
- *          fluxes ~1e-6 W m-2), 2 = fused arithmetic, every window point evaluated, 3 = as 1 in two
- *          passes (every line prepared once; cell moments through a device buffer of 32 bytes per
- *          column, layer and wavenumber) -- the form bench.py runs. */
+ * fast: 3 = fused arithmetic, far wings summed by cell moments, two passes (every line prepared once; cell moments
+ *          through a device buffer of 32 bytes per column, layer and wavenumber) -- the production form, what bench.py
+ *          runs and THE DEFAULT OF A NEW OBJECT (tau within 2e-6 of each layer's maximum, fluxes ~1e-5 W m-2 from the
+ *          reference's: two orders inside the 1e-3 W m-2 of the interface's contract);
+ *       1 = the same in one pass; 2 = fused arithmetic, every window point evaluated;
+ *       0 = the reference's operation order (tau within 1e-11 of the reference's; 3.3x slower through the one-column
+ *          calls).  GRT_GAS_OPTICS_FAST=0|1|2|3 in the environment sets the default of new objects for callers that
+ *          cannot call this function (an unchanged reference driver).  optical_depth_method = wavenumber_sweep /
+ *          line_sweep always run in reference order. */
 EXTERN int grt_gas_optics_tune(GasOptics_t *gas_optics, int tile, int nslice, int fast);
 
 /* What the last line-by-line launch of this object actually ran (the fused forms fall back 3 -> 1 -> 2 where a

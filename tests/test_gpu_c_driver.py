@@ -70,10 +70,11 @@ def test_c_driver_on_static_archives_matches_oracle(tmp_path, oracle, lib):
         out = np.array([float(x) for x in line[0].split()[1:]])
         assert out.size == 12
         return out
-    got = fluxes({})
-    # the same unchanged binary with the production arithmetic selected from the environment
+    got = fluxes({"GRT_GAS_OPTICS_FAST": "0"})          # reference operation order: the strict comparison below
+    # the same unchanged binary as it runs by default -- the production arithmetic (fast = 3) -- and with the one-pass form
+    default = fluxes({})
     fast = fluxes({"GRT_GAS_OPTICS_FAST": "1"})
-    assert 0.0 < np.max(np.abs(fast - got)) < 1e-4
+    assert 0.0 < np.max(np.abs(fast - got)) < 1e-4 and 0.0 < np.max(np.abs(default - got)) < 1e-4
     from grtcode_amd import api
     grid_sw = api.create_spectral_grid(swb.w0, swb.wn, swb.dw)
     solar = api.create_solar_flux(grid_sw, swb.files["solar"])

@@ -24,7 +24,8 @@ def test_fortran_program_on_the_reference_binding_module(tmp_path, oracle, lib):
                ppmv={syn.H2O: 5.0 * 3000.0 ** k, syn.CO2: np.full(V, 400.0)})
     band = Band(str(tmp_path), 600.0, 900.0, 0.5, 3000, mols=[syn.H2O, syn.CO2], with_cfc=False, with_cia=False)
     r = subprocess.run([EXE, band.par, "600", "900", "0.5", band.h2o_dir, band.files["o3_ctm"]],
-                       capture_output=True, text=True, timeout=300)
+                       capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, GRT_GAS_OPTICS_FAST="0"))       # reference operation order: 1e-11 below
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     head = [ln for ln in r.stdout.splitlines() if ln.startswith("grid:")][0]
     assert f"n={band.nw} " in head and "molecules=2" in head

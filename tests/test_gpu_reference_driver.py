@@ -6,8 +6,9 @@ oracle/_ref/grtcode_driver = driver.c + the reference's utilities/src/argparse.c
 libclouds.a (entry points only) + libgrtcode_hip.so; built by oracle/Makefile in the container, shipped prebuilt.
 
 CIRC case 1 (circ/src/circ1.h numbers from tests/golden) plus a perturbed second column, synthetic spectroscopy:
-the fluxes main() writes must equal the oracle's for the same files -- <= 1e-6 W m-2 in the reference-order form an
-unchanged caller gets by default, <= 1e-3 W m-2 with GRT_GAS_OPTICS_FAST=3 in the environment.
+the fluxes main() writes must equal the oracle's for the same files -- <= 1e-3 W m-2 (the north star's tolerance) as an
+unchanged caller runs by default (production arithmetic, fast = 3), <= 1e-6 W m-2 with GRT_GAS_OPTICS_FAST=0 in the
+environment (the reference's operation order).
 """
 import copy
 import os
@@ -123,7 +124,10 @@ def test_unchanged_reference_driver_main_matches_oracle(tmp_path, oracle, lib):
     names = (("rlutcsaf", 0, 0), ("rluscsaf", 0, 1), ("rlucsaf_user_level", 0, 2), ("rldscsaf", 0, 4), ("rldcsaf_user_level", 0, 5),
              ("rsutcsaf", 1, 0), ("rsuscsaf", 1, 1), ("rsucsaf_user_level", 1, 2), ("rsdtcsaf", 1, 3), ("rsdscsaf", 1, 4),
              ("rsdcsaf_user_level", 1, 5))
-    for env, tol in (({}, 1e-6), ({"GRT_GAS_OPTICS_FAST": "3"}, 1e-3)):
+    # GRT_GAS_OPTICS_FAST=0: the reference's operation order; {}: what an unchanged driver gets by default, the production
+    # arithmetic (fast = 3), inside the north star's 1e-3 W m-2
+    strict = {"GRT_GAS_OPTICS_FAST": "0"}
+    for env, tol in ((strict, 1e-6), ({}, 1e-3), ({"GRT_GAS_OPTICS_FAST": "3"}, 1e-3)):
         got = run(["-integrated"], env, "integrated.txt")
         worst = 0.0
         for c in range(2):
@@ -133,19 +137,19 @@ def test_unchanged_reference_driver_main_matches_oracle(tmp_path, oracle, lib):
             assert np.array_equal(got[(c, "level_pressure")], cols[c]["p"])
             assert got[(c, "surface_temperature")][0] == cols[c]["t_surf"]
             assert np.allclose(got[(c, "h2o_vmr")], cols[c]["ppmv"][syn.H2O], rtol=1e-14)
-        print(f"reference driver.c main(), {env or 'default (reference order)'}: worst integrated flux difference {worst:.2e} W m-2")
+        print(f"reference driver.c main(), {env or 'default (production arithmetic)'}: worst integrated flux difference {worst:.2e} W m-2")
         assert worst < tol
     # the driver's aerosol pass (driver.c:426-472, add_optics of THREE objects): the reference's own aerosol optics are
     # zero (the body of calculate_aerosol_optics is commented out, driver.c:223-238), so its clear-sky fluxes must equal
     # the clear-clean-sky ones of the same run
-    got = run(["-integrated", "-aerosols"], {}, "aerosols.txt")
+    got = run(["-integrated", "-aerosols"], strict, "aerosols.txt")
     for c in range(2):
         for name, band, k in names:
             with_aerosols = got[(c, name.replace("csaf", "cs"))]
             assert with_aerosols.size == 1 and with_aerosols[0] == got[(c, name)][0], (c, name)
             assert abs(got[(c, name)][0] - want[c][band]["integ"][k]) < 1e-6
     # one column only (-x/-X as run-rfmip-irf.sh shards: GRTworkflow/run-rfmip-irf.sh:121-122), spectral output
-    got = run(["-x", "1", "-X", "1"], {}, "spectral.txt")
+    got = run(["-x", "1", "-X", "1"], strict, "spectral.txt")
     w = want[1]
     assert got[(0, "rlutcsaf")].size == lwb.nw and got[(0, "rsdscsaf")].size == swb.nw
     assert np.max(np.abs(got[(0, "rlutcsaf")] - w[0]["up"][0])) < 1e-10 * np.abs(w[0]["up"]).max()
@@ -200,7 +204,7 @@ def test_reference_driver_cloud_pass_through_the_library(tmp_path, oracle, lib):
            "-a", repr(albedo), "-e", repr(emissivity), "-flux-at-level", str(user_level + 1), "-integrated", "-clouds",
            "-beta-path", "beta.nc", "-ice-path", "ice.nc", "-liquid-path", "liquid.nc",
            "-w-lw", "1", "-W-lw", "2000", "-r-lw", "1", "-w-sw", "1", "-W-sw", "8000", "-r-sw", "2", "-o", out]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, GRT_OPTICS_HOST_VISIBLE="1"))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, GRT_OPTICS_HOST_VISIBLE="1", GRT_GAS_OPTICS_FAST="0"))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     assert "clouds_double: initialised (beta.nc, ice.nc, liquid.nc)" in r.stderr
     got = parse_output(out)
