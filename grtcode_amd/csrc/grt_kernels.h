@@ -97,8 +97,9 @@ typedef struct GrtGasOpticsArgs
                                  kernel runs and leaves 16 words per workgroup at record ((col L + layer) tiles + tile) nslice +
                                  slice: clock at entry, clock at exit, candidate lines, R | corrected << 16 | moments << 17,
                                  then sums over its waves of: 64-line blocks worked on, ring steps, near-centre points queued,
-                                 moment reductions, lane-by-lane moment adds, region-1 correction steps, near-centre walk steps.
-                                 Zeroed by the caller. */
+                                 moment reductions, lane-by-lane moment adds, region-1 correction steps, near-centre walk steps;
+                                 word 11: clock when the prologue is done, 12: when every wave has left the line loop (the
+                                 epilogue starts), 13: when the last wave left it.  Zeroed by the caller. */
     int tile_phase, tile_nphase;   /* set by the launcher: this launch takes cell tiles t with t % tile_nphase == tile_phase
                                  (tile_nphase <= 1: all of them) */
 } GrtGasOpticsArgs;

@@ -421,6 +421,10 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         candidate_range_wave(a, lay, F0l, F1l, TWO_PASS ? 0 : fsteps_ll, slice, range, lane);
     }
     __syncthreads();
+    if constexpr (PROBE)
+    {
+        if (tid == 0) probe_rec[11] = __builtin_readcyclecounter();      // prologue done
+    }
     uint64_t const jbeg = (uint64_t)range[0];
     uint64_t const jend = (uint64_t)range[1];
 
@@ -919,7 +923,15 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
     {
         drain(q, 0, qcount[q]);
     }
+    if constexpr (PROBE)
+    {
+        if (lane == 0) atomicMax(&probe_rec[13], (unsigned long long)__builtin_readcyclecounter());   // last wave out of the line loop
+    }
     __syncthreads();
+    if constexpr (PROBE)
+    {
+        if (tid == 0) probe_rec[12] = __builtin_readcyclecounter();      // all waves out of the line loop: epilogue starts
+    }
 
     if (TWO_PASS)
     {

@@ -1,33 +1,459 @@
-/* grt_clouds.c -- libclouds.a: the cloud-optics entry points driver.c links against, NOT implemented
- * (see include/clouds_lib.h).  Every call reports GRTCODE_COMPILER_ERR; because driver.c
- * discards the return code of initialize_clouds_lib (driver.c:667), that one ends the process -- a cloudy run must
- * never continue on optics nobody computed. */
+/* grt_clouds.c -- libclouds.a: the cloud-optics library framework/src/driver.c links against.
+ *
+ * Host C99, as in the reference (clouds/ is CPU code there too: the driver's cloud pass, driver.c:474-597, fills the
+ * liquid / ice Optics_t arrays in place on the host -- run with GRT_OPTICS_HOST_VISIBLE=1 -- and everything downstream,
+ * add_optics of four objects and the solvers, is this library's GPU path).  What is restated here, and from where:
+ *
+ *   initialize / finalize_clouds_lib   clouds/clouds_lib.c:18-45        three parameter files, a (5, 5) water PDF
+ *   cloud_optics                       clouds/clouds_lib.c:84-139       per Pade band: one stochastic sample of the
+ *                                      condensate, then per layer the liquid and ice optics of that band, written to
+ *                                      the wavenumbers the band covers
+ *   ice particle size                  clouds/clouds_lib.c:47-82        eight temperature classes; radius = size/2
+ *   Pade optics                        clouds/cloud_pade_optics.c:152-213   size regime by radius, Horner numerator over
+ *                                      Horner denominator in (r - r_ref): extinction x water content, albedo, asymmetry
+ *   band -> wavenumber mapping         clouds/optics_utils.c:118-169    lower/upper binary searches, first and last band
+ *                                      extended to the ends of the grid; the grid point a band's upper limit falls on
+ *                                      is left to the next band, as there
+ *   condensate sampling                clouds/stochastic_clouds.c:11-28, 94-120  rand()-driven maximum-random overlap
+ *                                      (same calls to rand() in the same order: the same subcolumns for the same seed),
+ *                                      in-cloud water from the beta-distributed total water (doi:10.1175/MWR3257.1, A1-A2)
+ *   incomplete beta tables             clouds/incomplete_beta.c:32-64   linear interpolation, extrapolating at the ends
+ *   overlap parameter                  clouds/stochastic_clouds.c:79-91 exp(-|dz|/scale)
+ *
+ * The reference reads its three parameter files with netCDF, which this image does not have: here they are GRTDUMP1 files
+ * (grtcode_amd/dumpfile.py; scripts/netcdf_to_dump.py converts the reference's files variable by variable) holding the
+ * same variables under the same names -- beta file: p, q (shape), x, data, inverse (q, p, x); Pade files: Band_limits_lwr,
+ * Band_limits_upr (Band), Effective_Radius_limits_lwr/_upr, Effective_Radius_Ref (Re_range), Pade_{ext,ssa,asy}_{p,q}
+ * (coefficient, Re_range, Band).  Parity status: clouds/ cannot be compiled here (it includes netcdf.h) and the reference
+ * holds no test vectors for it, so this file is checked against an independent numpy restatement
+ * (tests/test_gpu_clouds.py): "parity unpinned" for this row, and said so in DESIGN.md.
+ *
+ * Not reproduced: the reference's debugging prints (clouds_lib.c:113-118, optics_utils.c:12, stochastic_clouds.c:61), and
+ * one out-of-range write -- optics_utils.c:163 starts at index offset - 1 when the LAST band's upper limit lies below the
+ * whole grid (upper_bound returns -1); here that loop starts at the layer's first point.
+ */
+#include <math.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include "clouds_lib.h"
-#include "grt_internal.h"
 
-static int unavailable(char const *what)
+/* ---- parameter files ------------------------------------------------------------------------------------------------ */
+typedef struct Table
 {
-    grt_err_begin(GRTCODE_COMPILER_ERR, __FILE__, __LINE__, "%s: cloud optics are not part of this build (the "
-                  "reference's clouds library needs netCDF parametrisation tables); run clear-sky or link the "
-                  "reference's libclouds.a.", what);
-    return GRTCODE_COMPILER_ERR;
+    char name[64];
+    int ndims;
+    int64_t dims[4];
+    double *data;
+} Table;
+
+typedef struct TableFile
+{
+    int n;
+    Table *t;
+} TableFile;
+
+static void fatal(char const *what, char const *arg)
+{
+    fprintf(stderr, "clouds library: %s%s\n", what, arg ? arg : "");
+    exit(EXIT_FAILURE);
 }
+
+static TableFile tables_open(char const *path)
+{
+    FILE *f = fopen(path, "rb");
+    if (f == NULL)
+    {
+        fatal("cannot open parameter file ", path);
+    }
+    char magic[8];
+    int32_t n = 0;
+    if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "GRTDUMP1", 8) != 0 || fread(&n, 4, 1, f) != 1 || n < 0 || n > 4096)
+    {
+        fprintf(stderr, "clouds library: %s is not a GRTDUMP1 file (the reference's netCDF parameter files are converted "
+                "with scripts/netcdf_to_dump.py).\n", path);
+        exit(EXIT_FAILURE);
+    }
+    TableFile tf = {n, calloc((size_t)(n ? n : 1), sizeof(Table))};
+    for (int i = 0; i < n; ++i)
+    {
+        Table *t = &tf.t[i];
+        char units[32];
+        int32_t nd = 0;
+        if (fread(t->name, 1, 64, f) != 64 || fread(units, 1, 32, f) != 32 || fread(&nd, 4, 1, f) != 1 ||
+            fread(t->dims, 8, 4, f) != 4 || nd < 0 || nd > 4)
+        {
+            fatal("truncated header in ", path);
+        }
+        t->name[63] = '\0';
+        t->ndims = nd;
+        size_t count = 1;
+        for (int k = 0; k < nd; ++k)
+        {
+            if (t->dims[k] < 0 || t->dims[k] > ((int64_t)1 << 32))
+            {
+                fatal("bad dimension in ", path);
+            }
+            count *= (size_t)t->dims[k];
+        }
+        t->data = malloc(sizeof(double)*(count ? count : 1));
+        if (t->data == NULL || fread(t->data, sizeof(double), count, f) != count)
+        {
+            fatal("truncated data in ", path);
+        }
+    }
+    fclose(f);
+    return tf;
+}
+
+static void tables_close(TableFile *tf)
+{
+    for (int i = 0; i < tf->n; ++i)
+    {
+        free(tf->t[i].data);
+    }
+    free(tf->t);
+    tf->t = NULL;
+    tf->n = 0;
+}
+
+static Table const *table(TableFile const *tf, char const *name, int ndims, char const *path)
+{
+    for (int i = 0; i < tf->n; ++i)
+    {
+        if (strcmp(tf->t[i].name, name) == 0)
+        {
+            if (tf->t[i].ndims != ndims)
+            {
+                fprintf(stderr, "clouds library: variable %s of %s has %d dimensions, expected %d\n", name, path, tf->t[i].ndims, ndims);
+                exit(EXIT_FAILURE);
+            }
+            return &tf->t[i];
+        }
+    }
+    fprintf(stderr, "clouds library: %s has no variable %s\n", path, name);
+    exit(EXIT_FAILURE);
+}
+
+/* ---- incomplete beta tables (incomplete_beta.c) ----------------------------------------------------------------------- */
+typedef struct BetaTables
+{
+    int num_shape, num_x;
+    double *x, *value, *inverse;        /* value / inverse: [q - 1][p - 1][x] */
+} BetaTables;
+
+static void beta_load(BetaTables *b, char const *path)
+{
+    TableFile tf = tables_open(path);
+    Table const *p = table(&tf, "p", 1, path), *x = table(&tf, "x", 1, path);
+    Table const *y = table(&tf, "data", 3, path), *yi = table(&tf, "inverse", 3, path);
+    b->num_shape = (int)p->dims[0];
+    b->num_x = (int)x->dims[0];
+    size_t const all = (size_t)b->num_shape*(size_t)b->num_shape*(size_t)b->num_x;
+    if (b->num_x < 2 || (size_t)(y->dims[0]*y->dims[1]*y->dims[2]) != all || (size_t)(yi->dims[0]*yi->dims[1]*yi->dims[2]) != all)
+    {
+        fatal("the beta tables' shapes disagree in ", path);
+    }
+    b->x = malloc(sizeof(double)*(size_t)b->num_x);
+    b->value = malloc(sizeof(double)*all);
+    b->inverse = malloc(sizeof(double)*all);
+    memcpy(b->x, x->data, sizeof(double)*(size_t)b->num_x);
+    memcpy(b->value, y->data, sizeof(double)*all);
+    memcpy(b->inverse, yi->data, sizeof(double)*all);
+    tables_close(&tf);
+}
+
+static void beta_free(BetaTables *b)
+{
+    free(b->x); free(b->value); free(b->inverse);
+    memset(b, 0, sizeof(*b));
+}
+
+/* the segment [x_{i-1}, x_i] with the first x_i > at (the last one beyond the table), extended as a straight line */
+static double beta_lookup(BetaTables const *b, double const *rows, int p, int q, double at)
+{
+    if (p < 1 || q < 1 || p > b->num_shape || q > b->num_shape)
+    {
+        fatal("beta shape parameter outside the table", NULL);
+    }
+    double const *y = rows + ((size_t)(q - 1)*(size_t)b->num_shape + (size_t)(p - 1))*(size_t)b->num_x;
+    int i = 1;
+    while (i < b->num_x - 1 && !(b->x[i] > at))
+    {
+        ++i;
+    }
+    double const slope = (y[i] - y[i - 1])/(b->x[i] - b->x[i - 1]);
+    double const intercept = y[i] - slope*b->x[i];
+    return slope*at + intercept;
+}
+
+/* ---- Pade optics of one water phase (cloud_pade_optics.c) -------------------------------------------------------- */
+typedef struct PadeOptics
+{
+    int nband, nsize, np, nq;
+    double *band_lo, *band_hi;              /* [nband] cm-1 */
+    double *size_lo, *size_hi, *size_ref;   /* [nsize] microns */
+    double *coef[6];                        /* ext_p, ext_q, ssa_p, ssa_q, asy_p, asy_q: [band][size][coefficient] */
+    double *ext, *ssa, *asy;                /* [nband]: the band values of the layer in hand */
+} PadeOptics;
+
+/* the files hold single-precision numbers (the reference reads them with nc_get_var_float) */
+static double as_float(double v)
+{
+    return (double)(float)v;
+}
+
+static void pade_load(PadeOptics *o, char const *path)
+{
+    static char const *const names[6] = {"Pade_ext_p", "Pade_ext_q", "Pade_ssa_p", "Pade_ssa_q", "Pade_asy_p", "Pade_asy_q"};
+    TableFile tf = tables_open(path);
+    Table const *lo = table(&tf, "Band_limits_lwr", 1, path), *hi = table(&tf, "Band_limits_upr", 1, path);
+    Table const *slo = table(&tf, "Effective_Radius_limits_lwr", 1, path), *shi = table(&tf, "Effective_Radius_limits_upr", 1, path);
+    Table const *sref = table(&tf, "Effective_Radius_Ref", 1, path);
+    o->nband = (int)lo->dims[0];
+    o->nsize = (int)slo->dims[0];
+    if (o->nband < 1 || o->nsize < 1 || hi->dims[0] != lo->dims[0] || shi->dims[0] != slo->dims[0] || sref->dims[0] != slo->dims[0])
+    {
+        fatal("band or size-regime tables of different lengths in ", path);
+    }
+    size_t const B = (size_t)o->nband, S = (size_t)o->nsize;
+    o->band_lo = malloc(sizeof(double)*B); o->band_hi = malloc(sizeof(double)*B);
+    o->size_lo = malloc(sizeof(double)*S); o->size_hi = malloc(sizeof(double)*S); o->size_ref = malloc(sizeof(double)*S);
+    o->ext = calloc(B, sizeof(double)); o->ssa = calloc(B, sizeof(double)); o->asy = calloc(B, sizeof(double));
+    for (size_t b = 0; b < B; ++b)
+    {
+        o->band_lo[b] = as_float(lo->data[b]);
+        o->band_hi[b] = as_float(hi->data[b]);
+    }
+    for (size_t s = 0; s < S; ++s)
+    {
+        o->size_lo[s] = as_float(slo->data[s]);
+        o->size_hi[s] = as_float(shi->data[s]);
+        o->size_ref[s] = as_float(sref->data[s]);
+    }
+    for (int k = 0; k < 6; ++k)
+    {
+        Table const *c = table(&tf, names[k], 3, path);
+        if (c->dims[1] != (int64_t)S || c->dims[2] != (int64_t)B || c->dims[0] < 1)
+        {
+            fprintf(stderr, "clouds library: %s of %s is not (coefficient, Re_range = %zu, Band = %zu)\n", names[k], path, S, B);
+            exit(EXIT_FAILURE);
+        }
+        int const order = (int)c->dims[0];
+        if (k % 2 == 0) o->np = order; else o->nq = order;
+        if ((k >= 2) && order != (k % 2 == 0 ? o->np : o->nq))
+        {
+            fatal("Pade tables of different orders in ", path);
+        }
+        /* file order (coefficient, size regime, band) -> [band][size regime][coefficient] */
+        o->coef[k] = malloc(sizeof(double)*B*S*(size_t)order);
+        for (size_t b = 0; b < B; ++b)
+            for (size_t s = 0; s < S; ++s)
+                for (int i = 0; i < order; ++i)
+                {
+                    o->coef[k][(b*S + s)*(size_t)order + (size_t)i] = as_float(c->data[((size_t)i*S + s)*B + b]);
+                }
+    }
+    tables_close(&tf);
+}
+
+static void pade_free(PadeOptics *o)
+{
+    free(o->band_lo); free(o->band_hi); free(o->size_lo); free(o->size_hi); free(o->size_ref);
+    free(o->ext); free(o->ssa); free(o->asy);
+    for (int k = 0; k < 6; ++k) free(o->coef[k]);
+    memset(o, 0, sizeof(*o));
+}
+
+static double horner(double const *c, int n, double x)
+{
+    double v = c[0];
+    for (int i = 1; i < n; ++i)
+    {
+        v = c[i] + x*v;
+    }
+    return v;
+}
+
+/* band `b` of a layer with water content `content` [g m-3] in particles of radius `radius` [microns] */
+static void pade_band(PadeOptics *o, double content, double radius, int b)
+{
+    o->ext[b] = o->ssa[b] = o->asy[b] = 0.;
+    if (!(content > 0.))
+    {
+        return;
+    }
+    int s = 0;
+    while (s < o->nsize && !(o->size_lo[s] <= radius && o->size_hi[s] >= radius))
+    {
+        ++s;
+    }
+    if (s == o->nsize)
+    {
+        return;                 /* a radius no size regime holds: no optics (cloud_pade_optics.c:166-171) */
+    }
+    double const dr = radius - o->size_ref[s];
+    size_t const at = (size_t)b*(size_t)o->nsize + (size_t)s;
+    o->ext[b] = content*(horner(o->coef[0] + at*(size_t)o->np, o->np, dr)/horner(o->coef[1] + at*(size_t)o->nq, o->nq, dr));
+    o->ssa[b] = horner(o->coef[2] + at*(size_t)o->np, o->np, dr)/horner(o->coef[3] + at*(size_t)o->nq, o->nq, dr);
+    o->asy[b] = horner(o->coef[4] + at*(size_t)o->np, o->np, dr)/horner(o->coef[5] + at*(size_t)o->nq, o->nq, dr);
+}
+
+/* first index in [0, n) whose value is >= target (n if none) */
+static int first_not_below(double const *w, int n, double target)
+{
+    int lo = 0, hi = n;
+    while (lo < hi)
+    {
+        int const mid = (lo + hi)/2;
+        if (w[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+/* last index in [0, n) whose value is <= target (-1 if none) */
+static int last_not_above(double const *w, int n, double target)
+{
+    int lo = 0, hi = n;
+    while (lo < hi)
+    {
+        int const mid = (lo + hi)/2;
+        if (w[mid] <= target) lo = mid + 1; else hi = mid;
+    }
+    return lo - 1;
+}
+
+/* band b's values -> the points of one layer's row the band covers (optics_utils.c:118-169) */
+static void spread_band(PadeOptics const *o, int b, double const *w, int n, double *beta, double *omega, double *g)
+{
+    int const from = first_not_below(w, n, o->band_lo[b]);
+    int const upto = last_not_above(w, n, o->band_hi[b]);     /* (exclusive below: that point is the next band's) */
+    if (b == 0)
+    {
+        for (int j = 0; j < from; ++j)
+        {
+            beta[j] = o->ext[0]; omega[j] = o->ssa[0]; g[j] = o->asy[0];
+        }
+    }
+    for (int j = from; j < upto; ++j)
+    {
+        beta[j] = o->ext[b]; omega[j] = o->ssa[b]; g[j] = o->asy[b];
+    }
+    if (b == o->nband - 1)
+    {
+        for (int j = upto < 0 ? 0 : upto; j < n; ++j)
+        {
+            beta[j] = o->ext[b]; omega[j] = o->ssa[b]; g[j] = o->asy[b];
+        }
+    }
+}
+
+/* ---- the library's state (clouds_lib.c:10-15) ---------------------------------------------------------------------- */
+static struct
+{
+    int ready;
+    BetaTables beta;
+    PadeOptics ice, liquid;
+    int pdf_p, pdf_q;
+} lib;
 
 int initialize_clouds_lib(char const *beta_path, char const *ice_path, char const *liquid_path)
 {
-    (void)beta_path; (void)ice_path; (void)liquid_path;
-    int const rc = unavailable("initialize_clouds_lib");
-    char buf[1024];
-    grtcode_errstr(rc, buf, (int)sizeof(buf));
-    fprintf(stderr, "%s\n", buf);
-    exit(EXIT_FAILURE);
+    if (beta_path == NULL || ice_path == NULL || liquid_path == NULL)
+    {
+        fatal("initialize_clouds_lib needs three parameter files", NULL);
+    }
+    if (lib.ready)
+    {
+        finalize_clouds_lib();      /* (driver.c:759-764 initialises a second time on its way out) */
+    }
+    beta_load(&lib.beta, beta_path);
+    pade_load(&lib.ice, ice_path);
+    pade_load(&lib.liquid, liquid_path);
+    lib.pdf_p = lib.pdf_q = 5;
+    if (lib.beta.num_shape < lib.pdf_p + 1)
+    {
+        fatal("the beta tables must reach shape parameter 6 (the water PDF uses (5, 5) and (6, 5)): ", beta_path);
+    }
+    if (lib.ice.nband < lib.liquid.nband)
+    {
+        fatal("the ice parametrisation has fewer bands than the liquid one, whose bands drive the loop: ", ice_path);
+    }
+    lib.ready = 1;
+    return 0;
 }
 
 int finalize_clouds_lib()
 {
-    return unavailable("finalize_clouds_lib");
+    if (lib.ready)
+    {
+        beta_free(&lib.beta);
+        pade_free(&lib.ice);
+        pade_free(&lib.liquid);
+        lib.ready = 0;
+    }
+    return 0;
+}
+
+int calculate_overlap(int const num_layers, double const *altitude, double const scale_length, double *alpha)
+{
+    for (int i = 0; i + 1 < num_layers; ++i)
+    {
+        alpha[i] = exp(-1.*fabs(altitude[i] - altitude[i + 1])/scale_length);
+    }
+    return 0;
+}
+
+/* ice crystal size [microns] by temperature class (clouds_lib.c:47-82) */
+static double ice_size(double t)
+{
+    static double const below_freezing[7] = {25., 30., 35., 40., 45., 50., 55.};
+    static double const size[8] = {100.6, 80.8, 93.5, 63.9, 42.5, 39.9, 21.6, 20.2};
+    double const tfreeze = 273.16;
+    int k = 0;
+    while (k < 7 && !(t > tfreeze - below_freezing[k]))
+    {
+        ++k;
+    }
+    return size[k];
+}
+
+/* one subcolumn's in-cloud liquid and ice water per layer (stochastic_clouds.c:11-28, 94-120) */
+static void sample_subcolumn(int L, double const *cf, double const *lwc, double const *iwc, double const *overlap,
+                             double *rank, double *ql, double *qi)
+{
+    for (int i = 0; i < L; ++i)
+    {
+        rank[i] = ((double)(rand()))/((double)RAND_MAX);
+    }
+    for (int i = 0; i + 1 < L; ++i)
+    {
+        /* (all the decisions are drawn before any rank is copied down, as in the reference) */
+        ql[i] = ((double)(rand()))/((double)RAND_MAX);
+    }
+    for (int i = 0; i + 1 < L; ++i)
+    {
+        if (ql[i] <= overlap[i])
+        {
+            rank[i + 1] = rank[i];
+        }
+    }
+    int const p = lib.pdf_p, q = lib.pdf_q;
+    for (int i = 0; i < L; ++i)
+    {
+        ql[i] = qi[i] = 0.;
+        if (rank[i] > (1. - cf[i]))
+        {
+            double const qs = beta_lookup(&lib.beta, lib.beta.inverse, p, q, 1. - cf[i]);
+            double const width = (lwc[i] + iwc[i])/((((double)p)/((double)(p + q)))*
+                                 (1. - beta_lookup(&lib.beta, lib.beta.value, p + 1, q, qs)) - qs*cf[i]);
+            double const total = width*(beta_lookup(&lib.beta, lib.beta.inverse, p, q, rank[i]) - qs);
+            double const liquid_fraction = lwc[i]/(lwc[i] + iwc[i]);
+            ql[i] = total*liquid_fraction;
+            qi[i] = total*(1. - liquid_fraction);
+        }
+    }
 }
 
 int cloud_optics(const double *wavenum, int num_wavenum, int num_layers, const double *mean_cloud_fraction,
@@ -35,14 +461,38 @@ int cloud_optics(const double *wavenum, int num_wavenum, int num_layers, const d
                  const double liquid_radius, const double *temperature, double *beta_liquid, double *omega_liquid,
                  double *g_liquid, double *beta_ice, double *omega_ice, double *g_ice)
 {
-    (void)wavenum; (void)num_wavenum; (void)num_layers; (void)mean_cloud_fraction; (void)mean_liquid_content;
-    (void)mean_ice_content; (void)overlap; (void)liquid_radius; (void)temperature; (void)beta_liquid;
-    (void)omega_liquid; (void)g_liquid; (void)beta_ice; (void)omega_ice; (void)g_ice;
-    return unavailable("cloud_optics");
-}
-
-int calculate_overlap(int const num_layers, double const *altitude, double const scale_length, double *alpha)
-{
-    (void)num_layers; (void)altitude; (void)scale_length; (void)alpha;
-    return unavailable("calculate_overlap");
+    if (!lib.ready)
+    {
+        fatal("cloud_optics called before initialize_clouds_lib", NULL);
+    }
+    if (num_layers < 1 || num_wavenum < 1)
+    {
+        return 0;
+    }
+    size_t const L = (size_t)num_layers;
+    double *work = malloc(sizeof(double)*4*L);
+    if (work == NULL)
+    {
+        fatal("out of memory", NULL);
+    }
+    double *ice_radius = work, *rank = work + L, *ql = work + 2*L, *qi = work + 3*L;
+    for (size_t i = 0; i < L; ++i)
+    {
+        ice_radius[i] = ice_size(temperature[i])/2.0;
+    }
+    for (int band = 0; band < lib.liquid.nband; ++band)
+    {
+        /* a fresh subcolumn for every band */
+        sample_subcolumn(num_layers, mean_cloud_fraction, mean_liquid_content, mean_ice_content, overlap, rank, ql, qi);
+        for (size_t i = 0; i < L; ++i)
+        {
+            size_t const row = i*(size_t)num_wavenum;
+            pade_band(&lib.liquid, ql[i], liquid_radius, band);
+            spread_band(&lib.liquid, band, wavenum, num_wavenum, beta_liquid + row, omega_liquid + row, g_liquid + row);
+            pade_band(&lib.ice, qi[i], ice_radius[i], band);
+            spread_band(&lib.ice, band, wavenum, num_wavenum, beta_ice + row, omega_ice + row, g_ice + row);
+        }
+    }
+    free(work);
+    return 0;
 }

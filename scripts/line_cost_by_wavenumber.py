@@ -54,6 +54,8 @@ def probe_band(api, wl, go, grid, tag, far_tag, cols, gcols):
     buf.free()
     tau.free()
     cyc = rec[..., 1] - rec[..., 0]
+    phase = {"prologue": rec[..., 11] - rec[..., 0], "line_loop_until_last_wave": rec[..., 12] - rec[..., 11],
+             "epilogue": rec[..., 1] - rec[..., 12]}
     assert np.all(rec[..., 1] > 0) and np.all(cyc > 0), "a workgroup left no record"
     total_cyc = cyc.sum()
     names = ["blocks64", "ring_steps", "near_points", "moment_reductions", "moment_lane_adds", "reg1_steps", "walk_steps"]
@@ -104,7 +106,11 @@ def probe_band(api, wl, go, grid, tag, far_tag, cols, gcols):
     return {"n": int(grid.n), "tile": tile, "nslice": nslice, "tiles": ntiles, "workgroups": int(nrec),
             "production_first_pass_ms": prod_ms, "production_gather_ms": far_ms, "probe_first_pass_ms": probe_ms,
             "lines_in_store": int(sum(v["v0"].size for v in (wl.lw_lines if tag == 1 else wl.sw_lines).values())),
-            "whole_launch": pick(), "by_wavenumber": by_w, "by_layer": by_layer}
+            "whole_launch": pick(), "by_wavenumber": by_w, "by_layer": by_layer,
+            # where a workgroup's own clock goes: prologue (column state, temperature-power table, candidate range, clearing
+            # LDS) | the loop over its lines, until the LAST of its four waves is through | epilogue (flush to tau and gmom)
+            "workgroup_phases_share": {k: float(v.sum() / cyc.sum()) for k, v in phase.items()},
+            "workgroup_kcycles_mean": float(cyc.mean() * 1e-3)}
 
 
 def main():
@@ -139,6 +145,7 @@ def main():
         print(f"{name} all    " + " ".join(f"{band['whole_launch'][k]:14.3f}" for k in keys))
         for d in band["by_wavenumber"]:
             print(f"{d['w_lo']:6.0f}    " + " ".join(f"{d[k]:14.3f}" for k in keys) + f"  {d['ms_of_production_launch']:.3f} ms")
+    print("workgroup phases lw", out["lw"]["workgroup_phases_share"], "sw", out["sw"]["workgroup_phases_share"])
     print("production first pass ms: lw", out["lw"]["production_first_pass_ms"], "sw", out["sw"]["production_first_pass_ms"],
           "probe:", out["lw"]["probe_first_pass_ms"], out["sw"]["probe_first_pass_ms"])
 

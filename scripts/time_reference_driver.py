@@ -9,7 +9,7 @@ Grids: LW 1-3250, SW 1-50 000 cm-1 at 1 cm-1, 61 levels, -integrated, 7 molecule
 The driver prints no timings, so runs of N1 and N2 columns are timed whole and the per-column time is the difference
 quotient (start-up -- parsing 240 MB of line list, building the stores -- cancels).
 
-    python scripts/time_reference_driver.py [--columns 4 24] [--out profiles/r3_reference_driver_timing.json]
+    python scripts/time_reference_driver.py [--columns 40 240] [--out profiles/r3_reference_driver_timing.json]
 """
 import argparse
 import json
@@ -59,7 +59,7 @@ def column_text(c, V):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--columns", type=int, nargs=2, default=[4, 24])
+    ap.add_argument("--columns", type=int, nargs=2, default=[40, 240])
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r3_reference_driver_timing.json"))
     args = ap.parse_args()
     V = W.NUM_LEVELS
@@ -84,11 +84,13 @@ def main():
                    "-w-lw", "1", "-W-lw", "3250", "-r-lw", "1", "-w-sw", "1", "-W-sw", "50000", "-r-sw", "1",
                    "-integrated", "-o", os.path.join(root, f"out_{fast}_{n}.txt")]
             env = dict(os.environ, GRT_GAS_OPTICS_FAST=fast, GRT_TIPS_QUIET="1", GRT_HITRAN_CACHE_DIR=root)
-            t0 = time.perf_counter()
-            r = subprocess.run(cmd, capture_output=True, text=True, env=env)
-            wall = time.perf_counter() - t0
-            if r.returncode != 0:
-                raise SystemExit(r.stderr[-3000:])
+            wall = 1e30
+            for attempt in range(3):            # (the first run of all also writes the line-list index; best of three)
+                t0 = time.perf_counter()
+                r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+                wall = min(wall, time.perf_counter() - t0)
+                if r.returncode != 0:
+                    raise SystemExit(r.stderr[-3000:])
             runs[f"fast{fast}_{n}_columns_wall_s"] = wall
             print(f"fast={fast} {n} columns: {wall:.2f} s", file=sys.stderr, flush=True)
     n1, n2 = args.columns

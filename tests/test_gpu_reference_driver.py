@@ -241,3 +241,76 @@ def test_reference_driver_cloud_pass_through_the_library(tmp_path, oracle, lib):
                 assert abs(cloudy - got[(0, name + "csaf" + suffix)][0]) > 0.5          # the clouds matter
     print(f"reference driver.c cloud pass (clouds double): worst all-sky flux difference {worst_cloudy:.2e}, clear-sky {worst_clear:.2e} W m-2")
     assert worst_cloudy < 1e-6 and worst_clear < 1e-6
+
+
+@needs_driver
+@pytest.mark.gpu
+def test_reference_driver_cloud_pass_with_this_repositorys_clouds_library(tmp_path, oracle, lib):
+    """SURVEY §8(f)-4 complete: the UNCHANGED driver's cloud pass on libclouds.a of THIS repository
+    (grtcode_amd/csrc/host/grt_clouds.c: Pade optics, stochastic condensate sampling, band-to-grid mapping; parameter
+    files as GRTDUMP1) -- no test double.  The oracle gets its cloud optics from tests/cloud_model.py, drawing the same
+    libc rand() sequence the driver process draws (never seeded: srand(1); longwave pass first, then shortwave)."""
+    from cloud_model import LibcRand, cloud_optics, synthetic_tables
+    col1, v1 = circ1_column()
+    L = col1["p"].size - 1
+    cf, lwc, iwc = np.zeros(L), np.zeros(L), np.zeros(L)
+    cf[38:44], lwc[38:44] = 0.6, 0.2
+    cf[14:19], iwc[14:19] = 0.4, 0.05
+    cf[30], lwc[30], iwc[30] = 1.0, 0.05, 0.01                      # an overcast mixed-phase layer
+    swb = Band(str(tmp_path / "data"), 1.0, 8000.0, 2.0, 8000, sw=True)
+    lwb = Band(str(tmp_path / "lw_view"), 1.0, 2000.0, 1.0, 0, sw=True)
+    lwb.par, lwb.h2o_dir, lwb.files, lwb.tab = swb.par, swb.h2o_dir, swb.files, swb.tab
+    lwb.lines = {m: {k: a[(ln["v0"] >= lwb.w0) & (ln["v0"] <= lwb.wn)] for k, a in ln.items()} for m, ln in swb.lines.items()}
+    paths, tables = synthetic_tables(str(tmp_path), seed=4, band_edges=[50.0, 400.0, 1000.0, 2200.0, 4000.0, 7000.0])
+    dump = str(tmp_path / "columns.txt")
+    write_column(dump, v1)
+    with open(dump, "a") as f:
+        for name, vals in (("cloud_fraction", cf), ("liquid_water_content", lwc), ("ice_water_content", iwc)):
+            f.write(name + ": " + " ".join(repr(float(x)) for x in vals) + "\n")
+    user_level, albedo, emissivity = 20, 0.196, 0.97
+    out = str(tmp_path / "cloudy.txt")
+    cmd = [DRIVER, swb.par, swb.files["solar"], dump, *("-" + NAME[m] for m in swb.mols),
+           "-h2o-ctm", swb.h2o_dir, "-o3-ctm", swb.files["o3_ctm"], "-CFC-11", swb.files["cfc11"], "-CFC-12", swb.files["cfc12"],
+           "-N2-N2", swb.files["cia_n2n2"], "-O2-N2", swb.files["cia_o2n2"], "-O2-O2", swb.files["cia_o2o2"],
+           "-a", repr(albedo), "-e", repr(emissivity), "-flux-at-level", str(user_level + 1), "-integrated", "-clouds",
+           "-beta-path", paths["beta"], "-ice-path", paths["ice"], "-liquid-path", paths["liquid"],
+           "-w-lw", "1", "-W-lw", "2000", "-r-lw", "1", "-w-sw", "1", "-W-sw", "8000", "-r-sw", "2", "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, GRT_OPTICS_HOST_VISIBLE="1", GRT_GAS_OPTICS_FAST="0"))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    got = parse_output(out)
+    grid_sw = api.create_spectral_grid(swb.w0, swb.wn, swb.dw)
+    solar = api.create_solar_flux(grid_sw, swb.files["solar"])
+    thick = np.abs(np.log(col1["p"][:-1]) - np.log(col1["p"][1:])) * col1["t_layer"] * 8.314462 / (28.9647 * 0.001 * 9.81)
+    play = np.array(v1["layer_pressure_mb"])
+    overlap = np.exp(-1.0 * np.abs(np.diff(np.log(100.0 * play) * 7.3)) / 2.0)         # driver.c:170-181
+    rand = LibcRand()
+    rand.seed(1)                                                                      # a process that never calls srand
+    worst_cloudy = worst_clear = 0.0
+    for band, lw, names in ((lwb, True, ("rlut", "rlus", "rlu", None, "rlds", "rld")), (swb, False, ("rsut", "rsus", "rsu", "rsdt", "rsds", "rsd"))):
+        emis, alb = np.full(band.nw, emissivity), np.full(band.nw, albedo)
+        clear = oracle_column(oracle, lib, band, col1, lw, emis, alb, solar, user_level)
+        centres = band.w0 + np.arange(band.nw) * band.dw
+        limits = np.empty(band.nw + 1)
+        limits[1:-1] = 0.5 * (centres[:-1] + centres[1:])
+        limits[0] = max(centres[0] - band.dw, 0.0)
+        limits[-1] = centres[-1] + band.dw
+        bl, ol, gl, bi, oi, gi = cloud_optics(tables, rand, limits[:band.nw], cf, lwc, iwc, overlap, 10.0, col1["t_layer"])
+        tl, ti = bl * thick[:, None], bi * thick[:, None]
+        tr, om_r, g_r = oracle.rayleigh(L, col1["p"], band.w0, band.dw, band.nw)
+        z = np.zeros_like(tr)
+        tau, omega, g = oracle.add_optics([clear["tau_gas"], tr, tl, ti], [z, om_r, ol, oi], [z, g_r, gl, gi])
+        up, dn = (oracle.lw_fluxes(band.w0, band.dw, col1["t_surf"], col1["t_layer"], col1["t"], tau, omega, emis) if lw else
+                  oracle.sw_fluxes(omega, g, tau, col1["mu0"], 0.5, alb, alb, col1["tsi"], solar))
+        rows = (up[0], up[-1], up[user_level], dn[0], dn[-1], dn[user_level])
+        assert np.any(tl > 0) and np.any(ti > 0)
+        for k, name in enumerate(names):
+            if name is None:
+                continue
+            suffix = "_user_level" if k in (2, 5) else ""
+            want = oracle.integrate_row(rows[k], band.dw)
+            cloudy = got[(0, name + "af" + suffix)][0]
+            worst_cloudy = max(worst_cloudy, abs(cloudy - want))
+            worst_clear = max(worst_clear, abs(got[(0, name + "csaf" + suffix)][0] - clear["integ"][k]))
+    print(f"reference driver.c cloud pass (this repository's clouds library): worst all-sky flux difference {worst_cloudy:.2e}, clear-sky {worst_clear:.2e} W m-2")
+    assert worst_cloudy < 1e-6 and worst_clear < 1e-6
+    assert abs(got[(0, "rlutaf")][0] - got[(0, "rlutcsaf")][0]) > 0.5 and abs(got[(0, "rsdsaf")][0] - got[(0, "rsdscsaf")][0]) > 0.5
