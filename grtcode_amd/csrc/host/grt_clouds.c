@@ -26,7 +26,8 @@
  * Band_limits_upr (Band), Effective_Radius_limits_lwr/_upr, Effective_Radius_Ref (Re_range), Pade_{ext,ssa,asy}_{p,q}
  * (coefficient, Re_range, Band).  Parity status: clouds/ cannot be compiled here (it includes netcdf.h) and the reference
  * holds no test vectors for it, so this file is checked against an independent numpy restatement
- * (tests/test_gpu_clouds.py): "parity unpinned" for this row, and said so in DESIGN.md.
+ * (tests/cloud_model.py; tests/test_clouds_library.py on the CPU, tests/test_gpu_reference_driver.py through the unchanged
+ * driver's cloud pass): "parity unpinned" for this row, and said so in DESIGN.md.
  *
  * Not reproduced: the reference's debugging prints (clouds_lib.c:113-118, optics_utils.c:12, stochastic_clouds.c:61), and
  * one out-of-range write -- optics_utils.c:163 starts at index offset - 1 when the LAST band's upper limit lies below the
@@ -379,6 +380,14 @@ int initialize_clouds_lib(char const *beta_path, char const *ice_path, char cons
     if (lib.ice.nband < lib.liquid.nband)
     {
         fatal("the ice parametrisation has fewer bands than the liquid one, whose bands drive the loop: ", ice_path);
+    }
+    /* The reference never seeds: its subcolumns follow libc's default sequence from wherever the process's other users of
+       rand() have left it (the GPU runtime draws from it while it starts up).  GRT_CLOUDS_SEED=<n> in the environment
+       calls srand(n) here, so that a run's subcolumns can be reproduced (tests; debugging a cloudy column). */
+    char const *seed = getenv("GRT_CLOUDS_SEED");
+    if (seed != NULL && seed[0] != '\0')
+    {
+        srand((unsigned)strtoul(seed, NULL, 10));
     }
     lib.ready = 1;
     return 0;

@@ -1,13 +1,14 @@
-/* clouds_lib.h -- entry points of the reference's cloud-optics library as framework/src/driver.c calls them
- * (clouds/clouds_lib.h; driver.c:181, 507, 667, 759).
+/* clouds_lib.h -- entry points of the cloud-optics library as framework/src/driver.c calls them
+ * (clouds/clouds_lib.h; driver.c:181, 507, 667, 759), implemented in libclouds.a of this repository
+ * (grtcode_amd/csrc/host/grt_clouds.c: host C99, like the reference's clouds/): Pade cloud optics per band, stochastic
+ * sampling of the condensate from a beta-distributed total water with maximum-random overlap (libc rand(), the same
+ * draws in the same order), band-to-grid mapping.
  *
- * the cloud pass is NOT built here -- the reference's parametrisations (clouds/clouds_lib.c:18-149)
- * read netCDF tables this image cannot open.  The symbols exist (libclouds.a, the reference's archive name) so that the
- * unchanged driver.c links; a cloudy run fails loudly with GRTCODE_COMPILER_ERR's message instead of computing
- * anything, exactly as disort_shortwave does without --enable-disort.  Link the reference's own libclouds.a in its
- * place where netCDF exists, and run with GRT_OPTICS_HOST_VISIBLE=1: the driver's cloud pass fills Optics_t arrays in
- * place on the host (driver.c:507-525), so create_optics must hand out host-visible memory (INTEGRATION.md §2;
- * tests/test_gpu_reference_driver.py runs that pass with a test double of this library).
+ * Parameter files: the reference's three netCDF files (-beta-path, -ice-path, -liquid-path) as GRTDUMP1 flat files with
+ * the same variable names (scripts/netcdf_to_dump.py converts them on a box that has netCDF4).  The driver's cloud pass
+ * fills Optics_t arrays in place on the host (driver.c:507-525): run it with GRT_OPTICS_HOST_VISIBLE=1 so that
+ * create_optics hands out host-visible memory.  GRT_CLOUDS_SEED=<n> makes initialize_clouds_lib call
+ * srand(n) (the reference never seeds).
  */
 #ifndef CLOUDS_LIB_H
 #define CLOUDS_LIB_H

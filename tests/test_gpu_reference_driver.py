@@ -249,7 +249,8 @@ def test_reference_driver_cloud_pass_with_this_repositorys_clouds_library(tmp_pa
     """SURVEY §8(f)-4 complete: the UNCHANGED driver's cloud pass on libclouds.a of THIS repository
     (grtcode_amd/csrc/host/grt_clouds.c: Pade optics, stochastic condensate sampling, band-to-grid mapping; parameter
     files as GRTDUMP1) -- no test double.  The oracle gets its cloud optics from tests/cloud_model.py, drawing the same
-    libc rand() sequence the driver process draws (never seeded: srand(1); longwave pass first, then shortwave)."""
+    libc rand() sequence the driver process draws: GRT_CLOUDS_SEED makes initialize_clouds_lib call srand (the reference
+    never seeds, and the GPU runtime has drawn from rand() by then); longwave pass first, then shortwave."""
     from cloud_model import LibcRand, cloud_optics, synthetic_tables
     col1, v1 = circ1_column()
     L = col1["p"].size - 1
@@ -275,7 +276,7 @@ def test_reference_driver_cloud_pass_with_this_repositorys_clouds_library(tmp_pa
            "-a", repr(albedo), "-e", repr(emissivity), "-flux-at-level", str(user_level + 1), "-integrated", "-clouds",
            "-beta-path", paths["beta"], "-ice-path", paths["ice"], "-liquid-path", paths["liquid"],
            "-w-lw", "1", "-W-lw", "2000", "-r-lw", "1", "-w-sw", "1", "-W-sw", "8000", "-r-sw", "2", "-o", out]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, GRT_OPTICS_HOST_VISIBLE="1", GRT_GAS_OPTICS_FAST="0"))
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, GRT_OPTICS_HOST_VISIBLE="1", GRT_GAS_OPTICS_FAST="0", GRT_CLOUDS_SEED="20261004"))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     got = parse_output(out)
     grid_sw = api.create_spectral_grid(swb.w0, swb.wn, swb.dw)
@@ -284,7 +285,7 @@ def test_reference_driver_cloud_pass_with_this_repositorys_clouds_library(tmp_pa
     play = np.array(v1["layer_pressure_mb"])
     overlap = np.exp(-1.0 * np.abs(np.diff(np.log(100.0 * play) * 7.3)) / 2.0)         # driver.c:170-181
     rand = LibcRand()
-    rand.seed(1)                                                                      # a process that never calls srand
+    rand.seed(20261004)
     worst_cloudy = worst_clear = 0.0
     for band, lw, names in ((lwb, True, ("rlut", "rlus", "rlu", None, "rlds", "rld")), (swb, False, ("rsut", "rsus", "rsu", "rsdt", "rsds", "rsd"))):
         emis, alb = np.full(band.nw, emissivity), np.full(band.nw, albedo)
