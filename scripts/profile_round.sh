@@ -6,7 +6,7 @@ TAG=${1:-r1}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-ARGS="--steps 4 --warmup 1 --no-cpu-baseline --no-extras"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_under_trace.json 2> $OUT/trace.err || exit 1
 # HBM traffic: FETCH_SIZE and WRITE_SIZE need separate passes on gfx950 (TCC slot budget)
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py $ARGS > /dev/null 2> $OUT/pmc_fetch.err || exit 1

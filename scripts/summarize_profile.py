@@ -62,7 +62,7 @@ fetch = counters("pmc_fetch", {"FETCH_SIZE"})
 write = counters("pmc_write", {"WRITE_SIZE"})
 sq = counters("pmc_sq", {"SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY",
                          "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES"})
-summary = {"tag": tag, "command": "python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-extras",
+summary = {"tag": tag, "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras  (64 columns per step in launches of 8)",
            "bench_line_under_trace": {k: bench[k] for k in ("value", "ms_per_step", "kernel_ms_per_step", "config")},
            "kernels": {}}
 mean = lambda v: sum(v) / len(v)
@@ -88,7 +88,7 @@ if gas:
     cfg = bench["config"]
     # the solvers, for roofline_solvers.traffic
     solv = {k.split("@")[0]: v for k, v in summary["kernels"].items() if k.startswith(("sw_kernel", "lw_kernel"))}
-    json.dump({"tag": tag, "cols": cfg["columns_per_gpu_per_step"], "fast": cfg["fast"], "solvers": solv,
+    json.dump({"tag": tag, "cols": cfg["chunk_columns"], "fast": cfg["fast"], "solvers": solv,
                "gas_optics_sw": gas[sw_key], "gas_optics_lw": gas[lw_key]},
               open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1)[:1800])
