@@ -147,7 +147,8 @@ def reference_abi_rate(wl, ncol=3):
     """What an UNCHANGED caller of the reference's one-column interface gets (framework/src/driver.c:360-424): per band
     set_*_ppmv -> calculate_optical_depth -> rayleigh_scattering -> add_optics -> calculate_{lw,sw}_fluxes with HOST flux
     arrays (2 V n doubles over PCIe per call) -> the caller's trapezoid -> destroy_optics.  Reference-order arithmetic
-    (fast = 0, the default of a new gas-optics object) unless GRT_GAS_OPTICS_FAST is set; here both are timed."""
+    The production arithmetic (fast = 3) is the default of a new gas-optics object, GRT_GAS_OPTICS_FAST=0 selects the
+    reference's operation order; here both are timed."""
     from grtcode_amd import api, synthetic as syn, workload as W
     V = W.NUM_LEVELS
     lw = api.LongwaveObject(V, wl.grid_lw, wl.device)
@@ -189,8 +190,9 @@ def reference_abi_rate(wl, ncol=3):
             fl = column(c)
         out["fast%d_columns_per_s" % fast] = ncol / (time.perf_counter() - t0)
     out["note"] = ("one column per call, synchronous, 2*V*n doubles of spectral flux copied to the host per solver call "
-                   "(49 MB per shortwave column); fast0 = what an unchanged driver gets, fast3 = the same driver with "
-                   "GRT_GAS_OPTICS_FAST=3 in its environment")
+                   "(49 MB per shortwave column); fast3 = what an unchanged driver gets (the default of a new object), fast0 = the same "
+                   "driver with GRT_GAS_OPTICS_FAST=0 in its environment (the reference's operation order); the real binary: "
+                   "profiles/r3_reference_driver_timing.json")
     for o in (lw, sw):
         o.destroy()
     for name in objs:
