@@ -100,6 +100,8 @@ typedef struct GrtGasOpticsArgs
                                  moment reductions, lane-by-lane moment adds, region-1 correction steps, near-centre walk steps;
                                  word 11: clock when the prologue is done, 12: when every wave has left the line loop (the
                                  epilogue starts), 13: when the last wave left it.  Zeroed by the caller. */
+    int direct_near;          /* set by the launcher: seven-point near fields (R = 3) by direct evaluation + row reduction
+                                 instead of the ring (GRT_DIRECT_NEAR=0 in the environment switches it off) */
     int tile_phase, tile_nphase;   /* set by the launcher: this launch takes cell tiles t with t % tile_nphase == tile_phase
                                  (tile_nphase <= 1: all of them) */
 } GrtGasOpticsArgs;

@@ -779,6 +779,99 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         // ---- near field: |f - c| <= R, clipped to the line's window and the tile ----
         int const lo_n = valid ? (lo > near_lo ? lo : near_lo) : 1;
         int const hi_n = valid ? (hi < near_hi ? hi : near_hi) : 0;
+        if constexpr (!TREE && LEAN)
+        {
+            // (measured on G1, 8 columns: longwave launch 5.94 -> 5.80 ms; on the shortwave band, where a row straddles two
+            // cells and takes two reduction passes, 14.50 -> 14.90 ms: so only the instance of the dense longwave band has it)
+            if (R == 3 && a.direct_near != 0)
+            {
+                // ---- seven-point near fields (R = 3: every (tile, layer) of the 1 cm-1 grids but the lowest layers')
+                // WITHOUT the ring.  Every lane evaluates its own line at r = -3 .. 3 -- the same expressions as a ring
+                // step, no tokens to pass on -- and the lanes of a row that share a cell add up their eight values (seven
+                // points and a blank) with the transposed row reduction the moments use: 7 x 12 + ~35 instructions per
+                // pass instead of 8.8 ring steps x 20 + the spans' bookkeeping.  Lines are sorted, so a row sits in one
+                // cell (longwave: 308 lines per cell) or two (shortwave: 30); a row's fp32 sum of at most 16 lines' values
+                // goes to the fp64 accumulators, as a ring token does.
+                if (__ballot(lo_n <= hi_n) == 0ull)
+                {
+                    continue;
+                }
+                float const amp_f32 = (float)amp;
+                bool lean = false;
+                if constexpr (LEAN)
+                {
+                    // (1 - |delta|) wr >= XLIM0 for every line of the wave: only a line's own grid point can be anything
+                    // but Lorentzian (the longwave band: Doppler widths far below the grid step)
+                    lean = __ballot(valid & !lorentz & !((1.f - fabsf(delta_c))*wr >= 1.001f*xlim0)) == 0ull;
+                }
+                float nv[8];
+#pragma unroll
+                for (int k = 0; k < 7; ++k)
+                {
+                    int const f = c + (k - 3);
+                    float const xi = fmaf((float)(k - 3), wr, ndcr);
+                    float const xq = xi*xi;
+                    float const d = fmaf(xi, xi, yq);
+                    bool const inside = (f >= lo_n) & (f <= hi_n);
+                    float kf;
+                    if (LEAN && lean && k != 3)
+                    {
+                        kf = cl*__builtin_amdgcn_rcpf(d);                     // beyond XLIM0: the Lorentzian (RFM_voigt.c:103)
+                    }
+                    else
+                    {
+                        // region 1 (RFM_voigt.c:172-183): K = c (A0+XQ)/(D0+XQ(D2+XQ)); beyond it the Lorentzian; the
+                        // near-centre points (|x| < XLIM1) are the queue's alone
+                        bool const outer = xq >= xq_near;
+                        bool const reg1 = outer & (xq < x0q);
+                        float const den = reg1 ? fmaf(xq, d2r + xq, d0r) : d;
+                        float const num = reg1 ? cl*(a0 + xq) : cl;
+                        kf = outer ? num*__builtin_amdgcn_rcpf(den) : 0.f;
+                    }
+                    nv[k] = inside ? amp_f32*kf : 0.f;
+                }
+                nv[7] = 0.f;
+                if constexpr (PROBE) pc_ring += 4;          // (counted as four ring steps' worth: see the cost script)
+                bool pending = lo_n <= hi_n;
+                unsigned long long const pmask = __ballot(pending);
+                bool const sparse = __builtin_amdgcn_readlane(c, 63 - __builtin_clzll(pmask)) - __builtin_amdgcn_readlane(c, __builtin_ctzll(pmask)) >= 24;
+                for (int pass = 0; pass < kCellLoop && !sparse && __ballot(pending) != 0ull; ++pass)
+                {
+                    int cr = pending ? c : 0x7fffffff;
+                    cr = min(cr, dpp_i<0x121>(cr));
+                    cr = min(cr, dpp_i<0x122>(cr));
+                    cr = min(cr, dpp_i<0x124>(cr));
+                    cr = min(cr, dpp_i<0x128>(cr));                      // the row's lowest pending cell, in every lane
+                    bool const mine = pending & (c == cr);
+                    float nn[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                    {
+                        nn[k] = mine ? nv[k] : 0.f;
+                    }
+                    float const t = row_sum_transposed(nn, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0);
+                    // lane l of the row holds the sum of value (l >> 1) & 7: grid point cr - 3 + that; a sum that is not
+                    // zero has a contribution from inside some line's clipped near field, i.e. inside the accumulator
+                    if (((lane & 1) == 0) & (cr != 0x7fffffff) & (t != 0.f))
+                    {
+                        GRT_ACC_ADD(&acc[cr - 3 + ((lane >> 1) & 7) - A0], (double)t);
+                    }
+                    pending = pending & !mine;
+                }
+                if (pending)
+                {
+#pragma unroll
+                    for (int k = 0; k < 7; ++k)
+                    {
+                        if (nv[k] != 0.f)
+                        {
+                            GRT_ACC_ADD(&acc[c + (k - 3) - A0], (double)nv[k]);
+                        }
+                    }
+                }
+                continue;
+            }
+        }
         // Each row of 16 lanes is a ring of its own, so each row covers the span of ITS lines (sorted lines:
         // a row's 16 centres sit in one or two cells, the wave's 64 in two to four); the wave only shares the
         // number of steps, the longest row's.
@@ -1820,6 +1913,18 @@ size_t far_lds_bytes(int tile, int ncell, int fsteps, int num_slots, int cell_sh
            + sizeof(int)*((size_t)(ncell >> cell_shift) + 3);
 }
 
+// GRT_DIRECT_NEAR=0 in the environment: seven-point near fields through the ring as well (comparison runs)
+int direct_near_wanted()
+{
+    static int want = -1;
+    if (want < 0)
+    {
+        char const *env = getenv("GRT_DIRECT_NEAR");
+        want = (env != NULL && env[0] == '0') ? 0 : 1;
+    }
+    return want;
+}
+
 int log2_exact(int v)
 {
     int s = 0;
@@ -1927,6 +2032,7 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
         }
         GrtGasOpticsArgs b = *a;
         b.halo = halo;
+        b.direct_near = direct_near_wanted();
         b.near_block = (tree && tree_gather_by_wave(fsteps)) ? 64 : 0;
         b.mom_terms = wide ? kMomWide : kMom;
         if (!tree)
@@ -2035,6 +2141,7 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
     size_t const lds = mp_lds_bytes(a->tile, ncell, (int)fsteps, a->lay.num_slots);
     GrtGasOpticsArgs b = *a;
     b.rcap = kRcap;
+    b.direct_near = direct_near_wanted();
     hipLaunchKernelGGL((gas_optics_mp_kernel_w4<false, false, kMom>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b, fsteps,
                        (unsigned)ngroups, golden_stride(ngroups), ncell, a->tile, 0);
     return (int)hipGetLastError();
