@@ -78,6 +78,23 @@ def test_under_a_launcher_the_ranks_are_not_spawned_again():
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
 
 
+def test_under_torch_distributed_run_as_the_driver_launches_it():
+    """The driver's N > 1 command line: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e["GRT_BENCH_REHEARSAL"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--cols", "4"],
+                       capture_output=True, text=True, timeout=300, env=e, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = only_line(r)
+    assert line["n_gpus"] == 2 and line["config"]["shards"] == [[0, 4], [4, 4]] and line["collective"]["gathers_in_timed_region"] == 1
+
+
 def test_the_parent_never_imports_torch():
     """The launcher must not initialise anything GPU-related before it starts the ranks: spawn_ranks and everything
     main() runs before it import neither torch nor the library."""
