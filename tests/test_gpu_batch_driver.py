@@ -92,6 +92,14 @@ def test_batched_c_driver_matches_oracle(tmp_path, oracle, lib):
             "-chunk", "3", "-fast", "3"]
     r = run_driver(args)
     assert r.returncode == 0, r.stderr[-3000:]
+    # soak (GRT_TEST_REPEAT_DRIVER=N): a crash on the way in or out shows its backtrace; in the deterministic mode the
+    # whole C driver's output repeats to the last digit
+    first = None
+    for _ in range(int(os.environ.get("GRT_TEST_REPEAT_DRIVER", 2))):
+        again = run_driver(args, env=dict(os.environ, GRT_DETERMINISTIC="1"))
+        assert again.returncode == 0, again.stderr[-3000:]
+        first = first or again.stdout
+        assert again.stdout == first
     got = {}
     for line in r.stdout.splitlines():
         if line.startswith("col "):
