@@ -145,11 +145,9 @@ def window_case(dw):
     return w0, wn, n, centres, deltas
 
 
-@pytest.mark.parametrize("dw", [1.0, 0.5, 0.05, 0.01, 0.002])       # (0.002 cm-1: 12 500-point windows, the wave-shared tree gather)
-@pytest.mark.parametrize("fast", [1, 2, 3])
+# (0.002 cm-1: 12 500-point windows, the wave-shared tree gather -- there for the tree form only)
+@pytest.mark.parametrize("fast,dw", [(f, d) for f in (1, 2, 3) for d in (1.0, 0.5, 0.05, 0.01, 0.002) if d >= 0.01 or f == 3])
 def test_windows_bit_exact_through_production_kernels(tmp_path, oracle, lib, device, dw, fast, monkeypatch):
-    if dw < 0.01 and fast != 3:
-        pytest.skip("the finest grid is there for the tree form")
     w0, wn, n, centres, deltas = window_case(dw)
     band = isolated_lines_band(str(tmp_path), w0, wn, dw, centres, deltas)
     assert band.nw == n
