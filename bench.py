@@ -119,6 +119,18 @@ def fine_grid_column(wl, dw, reps, compare_layers=0):
            "voigt_points_per_column": float(L) * wl.total_lines["lw"] * (2 * fsteps + 1),
            # B_band = 60 S + n (8 C_tab + 48 L + 16 V), C_tab = 11 in the longwave
            "hbm_algorithmic_gb_per_s": (60.0 * wl.total_lines["lw"] + n * (88.0 + 48.0 * L + 16.0 * (L + 1))) / (kern_ms * 1e-3) / 1e9}
+    if dw == 0.001:
+        # the vector pipe's share in the two kernels of this column, from the PMC run of scripts/profile_g3.sh (carried,
+        # like roofline_valu.issue_utilisation: counters cannot be read inside an ordinary run)
+        try:
+            g3 = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json"))).get("g3")
+            if g3:
+                out["issue_utilisation"] = {k: {"avg_launch_ms": v["avg_launch_ms"], "issue_utilisation": v.get("issue_utilisation"),
+                                                "valu_wave_instructions": v.get("sq", {}).get("SQ_INSTS_VALU")}
+                                            for k, v in g3["kernels"].items()}
+                out["issue_utilisation"]["source"] = f"profiles/traffic_latest.json: rocprofv3 --pmc pass of scripts/fine_grid.py --dw 0.001, round tag {g3['tag']} (not measured in this run)"
+        except Exception:
+            pass
     opt.destroy()
     go.destroy()
     if compare_layers:

@@ -80,7 +80,8 @@ EXTERN int grt_gas_optics_last_launch(GasOptics_t const *gas_optics, long long i
  * environment (read at every launch), or grt_set_deterministic(1), every sum is formed in one fixed order and repeated
  * runs are bit-identical: one wave of each workgroup takes all of its lines in store order, tiles are never cut into
  * line slices, and the first pass of the two-pass form runs as a sequence of launches over non-overlapping cell tiles.
- * The values are as good as the default mode's (same formulas, another order); the line kernel is ~4x slower.
+ * The values are as good as the default mode's (same formulas, another order); throughput is about a third (G1: 123
+ * instead of 360 columns/s).
  * grt_set_deterministic(-1) returns control to the environment variable. */
 EXTERN int grt_set_deterministic(int on);
 EXTERN int grt_deterministic(void);

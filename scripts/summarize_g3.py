@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""gpurun_out/prof_g3_<tag>/ (scripts/profile_g3.sh) -> profiles/<tag>_g3_kernel_stats.csv and the "g3" entry of
+profiles/traffic_latest.json (per kernel: average launch ms from the trace, SQ_INSTS_VALU per launch), which bench.py
+carries into fine_grid.G3 as issue utilisation -- labelled as coming from the profiled run."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
+src = os.path.join(ROOT, "gpurun_out", f"prof_g3_{tag}")
+newest = lambda pat: sorted(glob.glob(pat), key=os.path.getmtime)[-1]
+shutil.copy(newest(os.path.join(src, "trace", "*", "*kernel_stats.csv")), os.path.join(ROOT, "profiles", f"{tag}_g3_kernel_stats.csv"))
+
+
+def short(name):
+    for k in ("gas_optics_mp_kernel", "gas_optics_tree_kernel", "gas_optics_tree_lane_kernel", "moment_up_kernel"):
+        if k in name:
+            return k
+    return None
+
+
+dur = collections.defaultdict(list)
+for r in csv.DictReader(open(newest(os.path.join(src, "trace", "*", "*kernel_trace.csv")))):
+    if short(r["Kernel_Name"]):
+        dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+cnt = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(newest(os.path.join(src, "pmc_sq", "*", "*counter_collection.csv")))):
+    if short(r["Kernel_Name"]):
+        cnt[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+mean = lambda v: sum(v) / len(v)
+g3 = {"tag": tag, "command": "python3 scripts/fine_grid.py --dw 0.001 (one 60-layer longwave column, 10^6 lines)", "kernels": {}}
+for k, v in dur.items():
+    ms = mean(v[1:] if len(v) > 1 else v)                         # (the first launch carries the allocations' page faults)
+    e = {"avg_launch_ms": ms, "launches_seen": len(v)}
+    if k in cnt:
+        e["sq"] = {c: mean(x) for c, x in cnt[k].items()}
+        if "SQ_INSTS_VALU" in e["sq"]:
+            e["issue_utilisation"] = e["sq"]["SQ_INSTS_VALU"] / (1024 * ms * 1e-3 * 2.4e9 * 0.5)
+    g3["kernels"][k] = e
+path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+t = json.load(open(path))
+t["g3"] = g3
+json.dump(t, open(path, "w"), indent=1)
+print(json.dumps(g3, indent=1))
