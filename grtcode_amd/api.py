@@ -139,7 +139,7 @@ grt_tips_load grt_tips_reset grt_tips_is_table grt_tips_source grt_sizeof grt_ad
 grt_optical_depth_batch grt_pipeline_create grt_pipeline_create_ex grt_pipeline_destroy grt_pipeline_run grt_pipeline_sync
 grt_pipeline_stream grt_pipeline_views grt_device_malloc grt_device_free grt_device_to_host
 grt_host_to_device grt_debug_line_prep grt_debug_partition_functions grt_debug_voigt grt_debug_line_strengths grt_profile_enable grt_profile_read
-grt_set_deterministic grt_deterministic grt_gas_optics_probe grt_optics_cache_flush
+grt_set_deterministic grt_deterministic grt_gas_optics_probe grt_optics_cache_flush grt_device_use_lane grt_device_synchronize
 grt_multi_shard grt_multi_create grt_multi_destroy grt_multi_gather_fluxes grt_multi_broadcast grt_multi_max
 grt_err_begin grt_err_frame grt_log grt_gmalloc grt_gfree grt_gmemset grt_gmemcpy
 """.split()
@@ -475,6 +475,15 @@ def debug_voigt(device, fast, w_start, npts, wres, center, gamma, alpha):
     lib.grt_debug_voigt.argtypes = [C.c_int, C.c_int, C.c_double, C.c_uint64, C.c_double, C.c_double, C.c_double, C.c_double, c_double_p]
     check(lib.grt_debug_voigt(device, int(fast), w_start, npts, wres, center, gamma, alpha, _dp(K)))
     return K
+
+
+def use_lane(device, lane):
+    """Calls that follow enqueue on stream `lane` (0..3) of the device: several batches in flight (grt_ext.h)."""
+    check(load_library().grt_device_use_lane(device, lane))
+
+
+def device_synchronize(device):
+    check(load_library().grt_device_synchronize(device))
 
 
 def profile_enable(on=True):

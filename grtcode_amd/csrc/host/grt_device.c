@@ -9,7 +9,27 @@
 #include "grt_internal.h"
 
 #define GRT_MAX_DEVICES 64
-static hipStream_t g_streams[GRT_MAX_DEVICES];
+#define GRT_NUM_LANES 4
+/* Every call of this library enqueues on ONE stream per device, so that calls are ordered as they are made.  A caller that
+   keeps several batches in flight (grt_ext.h: grt_device_use_lane) selects which of a few such streams ("lanes") the calls
+   that follow use; objects that are used together must be used on the same lane, or with a device synchronisation between. */
+static hipStream_t g_streams[GRT_MAX_DEVICES][GRT_NUM_LANES];
+static int g_lane[GRT_MAX_DEVICES];
+
+EXTERN int grt_device_use_lane(Device_t device, int lane)
+{
+    GRT_TRY(grt_dev_require(device));
+    GRT_REQUIRE_RANGE(lane, 0, GRT_NUM_LANES - 1);
+    g_lane[device] = lane;
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN int grt_device_synchronize(Device_t device)
+{
+    GRT_TRY(grt_dev_require(device));
+    GRT_TRY(grt_dev_check((int)hipDeviceSynchronize(), "hipDeviceSynchronize"));
+    return GRTCODE_SUCCESS;
+}
 
 int grt_dev_check(int hip_error, char const *what)
 {
@@ -93,15 +113,15 @@ void *grt_dev_stream(Device_t device)
     {
         return NULL;
     }
-    if (g_streams[device] == NULL)
+    hipStream_t *s = &g_streams[device][g_lane[device]];
+    if (*s == NULL)
     {
-        if (hipSetDevice(device) != hipSuccess ||
-            hipStreamCreateWithFlags(&g_streams[device], hipStreamNonBlocking) != hipSuccess)
+        if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(s, hipStreamNonBlocking) != hipSuccess)
         {
-            g_streams[device] = NULL;
+            *s = NULL;
         }
     }
-    return (void *)g_streams[device];
+    return (void *)*s;
 }
 
 int grt_dev_alloc(Device_t device, void **p, size_t bytes)

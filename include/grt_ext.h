@@ -185,6 +185,16 @@ EXTERN int grt_profile_read(int tag, double *total_ms, int *launches, int reset)
  * device, e.g. before a large allocation.  One caller thread, as everywhere in this interface. */
 EXTERN int grt_optics_cache_flush(void);
 
+/* ---- several batches in flight ----------------------------------------------------------
+ * Every call enqueues on one HIP stream per device, in call order.  grt_device_use_lane(device, k), k = 0..3, makes the
+ * calls that follow use stream k of that device: a caller with two pipelines (each with gas-optics objects of its own)
+ * alternates lanes batch by batch, and the end of one batch -- far-field gather, solvers -- can overlap the next batch's
+ * line kernel (bench.py --lanes: +0.7 % with two lanes, +1.4 % with three on G1: those kernels keep the vector pipe busy
+ * themselves, so there is little to hide; the mechanism is for callers whose batches leave the GPU idler).  Objects used
+ * together must be used on the same lane; grt_device_synchronize(device) waits for all lanes. */
+EXTERN int grt_device_use_lane(Device_t device, int lane);
+EXTERN int grt_device_synchronize(Device_t device);
+
 /* ---- plain device-memory helpers for FFI callers (tests, bench) -------------------- */
 EXTERN int grt_device_malloc(Device_t device, void **ptr, size_t bytes);
 EXTERN int grt_device_free(Device_t device, void *ptr);

@@ -184,3 +184,44 @@ def test_fused_production_pipeline_equals_materialised_pipeline(bands, oracle, l
         assert np.all(got[False][:, [2, 5, 8, 11]] == 0.0)
     go_lw.destroy()
     go_sw.destroy()
+
+
+def test_two_pipelines_on_two_lanes_equal_one(bands, lib, device):
+    """grt_device_use_lane (grt_ext.h): two pipelines with gas-optics objects of their own, each on a stream of its own,
+    batches alternating between them without a wait in between -- the fluxes are those of one pipeline run batch by batch."""
+    lwb, swb = bands
+    V, ncol, nbatch = 16, 3, 4
+    emis, alb = np.full(lwb.nw, 0.98), np.full(swb.nw, 0.2)
+    batches = [api.make_columns([syn.profile(40 + 3 * b + c, V) for c in range(ncol)], MOL_ORDER, cfc_order=(0, 1)) for b in range(nbatch)]
+    made = []
+    for lane in (0, 1):
+        api.use_lane(device, lane)
+        go_lw, _ = lwb.gas_optics(device, V)
+        go_sw, grid_sw = swb.gas_optics(device, V)
+        go_lw.tune(fast=3)
+        go_sw.tune(fast=3)
+        solar = api.create_solar_flux(grid_sw, swb.files["solar"])
+        made.append((api.Pipeline(go_lw, go_sw, ncol, -1, emis, alb, solar, spectral=False), go_lw, go_sw))
+    out = [api.DeviceBuffer(device, 8 * ncol * api.GRT_FLUXES_PER_COLUMN) for _ in range(nbatch)]
+    try:
+        api.check(lib.grt_set_deterministic(1))                 # (so that "equal" can mean equal)
+        for b, (gcols, keep) in enumerate(batches):             # in flight together: no sync between the launches
+            api.use_lane(device, b % 2)
+            made[b % 2][0].run(gcols, out[b].ptr)
+        api.device_synchronize(device)
+        two = [o.to_host((ncol, api.GRT_FLUXES_PER_COLUMN)) for o in out]
+        api.use_lane(device, 0)
+        for b, (gcols, keep) in enumerate(batches):
+            made[0][0].run(gcols, out[b].ptr)
+            made[0][0].sync()
+            assert np.array_equal(out[b].to_host((ncol, api.GRT_FLUXES_PER_COLUMN)), two[b]), b
+        assert np.all(two[0][:, 0] > 0) and not np.array_equal(two[0], two[1])
+    finally:
+        api.check(lib.grt_set_deterministic(-1))
+        api.use_lane(device, 0)
+    for o in out:
+        o.free()
+    for pipe, go_lw, go_sw in made:
+        pipe.destroy()
+        go_lw.destroy()
+        go_sw.destroy()
