@@ -236,10 +236,13 @@ def test_full_3m_point_grid_against_the_reference_c(tmp_path, lib, device):
     if kind != "reference":
         pytest.skip("needs the prebuilt reference library oracle/_ref/libgrtref_omp.so (3.2e9 evaluations: a minute for the scalar restatement)")
     RC.set_omp_threads(min(os.cpu_count() or 1, 16))
-    V = 5
-    band = Band(str(tmp_path), 1.0, 3250.0, 0.001, 16000, physical=True)
+    # GRT_G3_REF_LINES / GRT_G3_REF_LEVELS: a bigger case for a one-off run (10^6 lines x 4 layers = 2e11 evaluations: ~3
+    # minutes of the reference's C on 16 threads; profiles/r3_g3_vs_reference.json)
+    nlines = int(os.environ.get("GRT_G3_REF_LINES", 16000))
+    V = int(os.environ.get("GRT_G3_REF_LEVELS", 5))
+    band = Band(str(tmp_path), 1.0, 3250.0, 0.001, nlines, physical=True)
     assert band.nw == 3249001
-    col = syn.profile(7, V)
+    col = syn.profile(int(os.environ.get("GRT_G3_REF_PROFILE", 7)), V)
     go, grid = band.gas_optics(device, V, from_file=False)
     band.set_column(go, col)
     go.tune(fast=3)
@@ -248,10 +251,30 @@ def test_full_3m_point_grid_against_the_reference_c(tmp_path, lib, device):
     tau = opt.read()[0]
     info = go.last_launch()
     assert info["fast"] == 3 and info["tree_levels"] == 12 and info["moments"] == 12 and info["tile"] >= 1024, info
+    beat = None
+    if os.environ.get("GRT_G3_REF_OUT"):
+        # (a one-off run of many minutes inside one C call: say so once a minute, or the GPU box takes the run for hung)
+        import threading
+        import time
+        stop = threading.Event()
+
+        def heartbeat():
+            t0 = time.time()
+            while not stop.wait(45.0):
+                with open(os.environ["GRT_G3_REF_OUT"] + ".progress", "a") as f:
+                    f.write(f"reference C running, {time.time() - t0:.0f} s\n")
+        beat = threading.Thread(target=heartbeat, daemon=True)
+        beat.start()
     want = band.oracle_tau(chk, orc, lib, col)
+    if beat is not None:
+        stop.set()
     from oracle.reference_column import tau_metrics
     m = tau_metrics(tau, want)
-    print(f"G3 grid, full width, 16 000 lines x 4 layers, tree form vs {kind}: {m}")
+    print(f"G3 grid, full width, {nlines} lines x {V - 1} layers, tree form vs {kind}: {m}")
+    if os.environ.get("GRT_G3_REF_OUT"):
+        import json
+        json.dump({"grid": {"w0": 1.0, "wn": 3250.0, "dw": 0.001, "n": band.nw}, "lines": int(sum(v["v0"].size for v in band.lines.values())),
+                   "layers": V - 1, "ran": info, "checker": kind, "tau_vs_reference": m}, open(os.environ["GRT_G3_REF_OUT"], "w"), indent=1)
     assert m["of_layer_max"] < 2e-6 and m["transmission"] < 4e-5
     opt.destroy()
     go.destroy()
