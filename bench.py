@@ -147,7 +147,7 @@ def fine_grid_column(wl, dw, reps, compare_layers=0):
         scale = np.abs(taus[2]).max(axis=1, keepdims=True)
         out["tree_vs_ring"] = {"layers": compare_layers, "max_diff_of_layer_max": float(np.max(np.abs(taus[3] - taus[2]) / scale)),
                                "what": "SELF-COMPARISON of two forms of this library (cell hierarchy vs every window point in the ring), not "
-                                       "parity.  Parity of THIS column -- all 60 layers, 10^6 lines, n = 3 249 001 -- against the reference's own C "
+                                       "parity.  Parity of a column of THIS size -- the same grid (n = 3 249 001), atmosphere and 60 layers, 10^6 lines of the physically scaled list -- against the reference's own C "
                                        "(18 minutes on 16 host threads, a one-off run): profiles/r3_g3_vs_reference.json, tau within 2.6e-7 of "
                                        "each layer's maximum, 2.9e-6 in transmission; in every suite run: "
                                        "tests/test_gpu_moment_tree.py::test_full_3m_point_grid_against_the_reference_c (16 000 lines x 4 layers)"}
