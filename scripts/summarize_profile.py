@@ -88,7 +88,11 @@ if gas:
     cfg = bench["config"]
     # the solvers, for roofline_solvers.traffic
     solv = {k.split("@")[0]: v for k, v in summary["kernels"].items() if k.startswith(("sw_kernel", "lw_kernel"))}
-    json.dump({"tag": tag, "cols": cfg["chunk_columns"], "fast": cfg["fast"], "solvers": solv,
-               "gas_optics_sw": gas[sw_key], "gas_optics_lw": gas[lw_key]},
-              open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1)
+    latest = os.path.join(dst, "traffic_latest.json")
+    keep = {}
+    if os.path.exists(latest):
+        keep = {k: v for k, v in json.load(open(latest)).items() if k == "g3"}        # (scripts/summarize_g3.py's entry)
+    json.dump(dict({"tag": tag, "cols": cfg["chunk_columns"], "fast": cfg["fast"], "solvers": solv,
+                    "gas_optics_sw": gas[sw_key], "gas_optics_lw": gas[lw_key]}, **keep),
+              open(latest, "w"), indent=1)
 print(json.dumps(summary, indent=1)[:1800])
