@@ -1210,7 +1210,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_far_kernel(GrtGasOpticsArgs
     double *acc = reinterpret_cast<double *>(smem);                               // [tile]
     double *ms_l = acc + a.tile;                                                  // [num_slots][4]
     double *q_l = ms_l + 4*a.lay.num_slots;                                       // [num_slots][GRT_MAX_ISO] (unused here)
-    float *mom = reinterpret_cast<float *>(q_l + GRT_MAX_ISO*a.lay.num_slots);    // [kMom][ncell]
+    float *mom = reinterpret_cast<float *>(q_l + GRT_MAX_ISO*a.lay.num_slots);    // [ncell][kMom]: cell-major, as in global memory
     float *invr = mom + (size_t)kMom*ncell;                                       // [fsteps + 1]
     int *rtab = reinterpret_cast<int *>(invr + fsteps + 1);                       // [cell tiles touched]
     int const tid = threadIdx.x;
@@ -1229,11 +1229,14 @@ __global__ __launch_bounds__(kBlock) void gas_optics_far_kernel(GrtGasOpticsArgs
     }
     int const cell0 = F0 - fsteps;
     float const *gm = a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*a.gmom_stride;       // [cell][8]
-    for (int i = tid; i < kMom*ncell; i += kBlock)
+    // the cells' moments stay cell-major in LDS, as they lie in global memory: [cell][8] -- staged 16 bytes per lane, and read
+    // by the gather two ds_read_b128 per cell instead of eight ds_read_b32 (the gather was LDS-issue-bound: 0.90 -> 0.68 ms
+    // per shortwave launch)
+    for (int i = tid; i < 2*ncell; i += kBlock)
     {
-        int const ci = i >> 3, k = i & 7;
-        long long const c = (long long)cell0 + ci;
-        mom[k*ncell + ci] = (c >= 0 && c < nw) ? gm[(uint64_t)c*kMom + k] : 0.f;
+        long long const c = (long long)cell0 + (i >> 1);
+        float4 const v = (c >= 0 && c < nw) ? reinterpret_cast<float4 const *>(gm + (uint64_t)c*kMom)[i & 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float4 *>(mom)[i] = v;
     }
     for (int i = tid; i < F1 - F0; i += kBlock)
     {
@@ -1281,14 +1284,26 @@ __global__ __launch_bounds__(kBlock) void gas_optics_far_kernel(GrtGasOpticsArgs
         for (int r = r_from; r <= r_to; ++r)
         {
             float const u = invr[r];
-            float const *ma = mom + (i + fsteps - r);           // cell f - r: offset +r
-            float const *mb = mom + (i + fsteps + r);           // cell f + r: offset -r
-            float pa = ma[(TERMS - 1)*ncell], pb = mb[(TERMS - 1)*ncell];
+            float4 const *ma = reinterpret_cast<float4 const *>(mom) + 2*(i + fsteps - r);    // cell f - r: offset +r
+            float4 const *mb = reinterpret_cast<float4 const *>(mom) + 2*(i + fsteps + r);    // cell f + r: offset -r
+            float a[8], b[8];
+            {
+                float4 const a0 = ma[0], b0 = mb[0];
+                a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w;
+                b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w;
+                if (TERMS > 4)
+                {
+                    float4 const a1 = ma[1], b1 = mb[1];
+                    a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
+                    b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+                }
+            }
+            float pa = a[TERMS - 1], pb = b[TERMS - 1];
 #pragma unroll
             for (int k = TERMS - 2; k >= 0; --k)
             {
-                pa = fmaf(pa, u, ma[k*ncell]);
-                pb = fmaf(pb, -u, mb[k*ncell]);
+                pa = fmaf(pa, u, a[k]);
+                pb = fmaf(pb, -u, b[k]);
             }
             if (r <= rmax)
             {
