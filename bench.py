@@ -324,7 +324,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cols", type=int, default=int(os.environ.get("GRT_BENCH_COLS", 64)), help="columns per GPU per step (weak scaling)")
-    ap.add_argument("--chunk", type=int, default=int(os.environ.get("GRT_BENCH_CHUNK", 8)), help="columns per launch of the pipeline")
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("GRT_BENCH_CHUNK", 64)), help="columns per launch of the pipeline "
+                    "(measured on G1: 8 -> 363.5, 32 -> 367.7, 64 -> 368.7 columns/s: fewer launch tails)")
     ap.add_argument("--fast", type=int, default=int(os.environ.get("GRT_BENCH_FAST", 3)),
                     help="3: fused form, far wings by cell moments, two passes (production); 1: the same in one pass; "
                          "2: fused form, ring kernel; 0: reference operation order")

@@ -62,7 +62,7 @@ fetch = counters("pmc_fetch", {"FETCH_SIZE"})
 write = counters("pmc_write", {"WRITE_SIZE"})
 sq = counters("pmc_sq", {"SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY",
                          "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES"})
-summary = {"tag": tag, "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras  (64 columns per step in launches of 8)",
+summary = {"tag": tag, "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras  (%d columns per step in launches of %d)" % (bench["config"]["columns_per_step"], bench["config"]["chunk_columns"]),
            "bench_line_under_trace": {k: bench[k] for k in ("value", "ms_per_step", "kernel_ms_per_step", "config")},
            "kernels": {}}
 mean = lambda v: sum(v) / len(v)
