@@ -94,12 +94,14 @@ typedef struct GrtGasOpticsArgs
                                  lines in store order, one line slice, and the two-pass form's first pass runs in
                                  tile_nphase launches of non-overlapping cell tiles.  A verification mode: ~4x slower. */
     unsigned long long *probe;     /* != NULL (grt_gas_optics_probe; cell-moment kernels only): an instrumented instance of the
-                                 kernel runs and leaves 16 words per workgroup at record ((col L + layer) tiles + tile) nslice +
+                                 kernel runs and leaves 24 words per workgroup at record ((col L + layer) tiles + tile) nslice +
                                  slice: clock at entry, clock at exit, candidate lines, R | corrected << 16 | moments << 17,
                                  then sums over its waves of: 64-line blocks worked on, ring steps, near-centre points queued,
                                  moment reductions, lane-by-lane moment adds, region-1 correction steps, near-centre walk steps;
                                  word 11: clock when the prologue is done, 12: when every wave has left the line loop (the
-                                 epilogue starts), 13: when the last wave left it.  Zeroed by the caller. */
+                                 epilogue starts), 13: when the last wave left it; 14-21: clocks the waves spent in preparation,
+                                 moment reduction and adds, near-centre walk and queue pushes, region-1 corrections, near
+                                 field, the rest of the line loop, evaluating queued points, moment terms.  Zeroed by the caller. */
     int direct_near;          /* set by the launcher: seven-point near fields (R = 3) by direct evaluation + row reduction
                                  instead of the ring (GRT_DIRECT_NEAR=0 in the environment switches it off) */
     int tile_phase, tile_nphase;   /* set by the launcher: this launch takes cell tiles t with t % tile_nphase == tile_phase

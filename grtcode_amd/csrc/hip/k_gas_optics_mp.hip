@@ -315,7 +315,7 @@ __device__ __forceinline__ void drain_class(double *acc, Queue const *q, int wav
 // the ring has a lean form for waves in which only a line's OWN grid point can be anything but Lorentzian.
 // PROBE: the instrumented instance (GrtGasOpticsArgs.probe): per-workgroup clocks and event counts, for the cost
 // analysis of scripts/line_cost_by_wavenumber.py; the production instances carry none of it.
-constexpr int kProbeWords = 16;
+constexpr int kProbeWords = 24;
 template <bool TWO_PASS, bool TREE, int K, bool LEAN = false, bool PROBE = false>
 __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long long fsteps_ll, unsigned ngroups,
                                                unsigned perm_stride, int ncell, int nacc, int halo)
@@ -332,6 +332,9 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
     double *ptab = q_l + GRT_MAX_ISO*a.lay.num_slots;                             // [kPowTable]: (296/T)^(k/100)
     float *mom = reinterpret_cast<float *>(ptab + kPowTable);                     // [kMom][ncell]
     float *invr = mom + (size_t)kMom*ncell;                                       // [fsteps + 1]
+    // tree form, moments straight to global memory: which of the tile's cells hold a line at all / more than one
+    unsigned *occ_any = reinterpret_cast<unsigned *>(invr + 1);                   // [tile/32]
+    unsigned *occ_many = occ_any + (a.tile >> 5);                                 // [tile/32]
 
     int const tid = threadIdx.x;
     int const lane = tid & 63;
@@ -347,7 +350,18 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
     long long const F1l = (F0l + a.tile < nw) ? F0l + a.tile : nw;                // [F0,F1)
     int const F0 = (int)F0l, F1 = (int)F1l;
     unsigned long long *probe_rec = nullptr;
-    unsigned pc_blocks = 0, pc_ring = 0, pc_near = 0, pc_momred = 0, pc_momlane = 0, pc_pre2 = 0, pc_walk = 0;    // wave-uniform
+    unsigned pc_ring_inside = 0, pc_ring_lorentz = 0, pc_blocks = 0, pc_ring = 0, pc_near = 0, pc_momred = 0, pc_momlane = 0, pc_pre2 = 0, pc_walk = 0;    // wave-uniform
+    unsigned long long pt[8] = {}, pt_last = 0;         // clocks a wave spent in: preparation, moment reduction and adds, walk and
+                                                        // queue pushes, pre-pass 2, near field, the rest, queued points, moment terms
+    auto phase_mark = [&](int idx)
+    {
+        if constexpr (PROBE)
+        {
+            unsigned long long const now = __builtin_readcyclecounter();
+            pt[idx] += now - pt_last;
+            pt_last = now;
+        }
+    };
     if constexpr (PROBE)
     {
         unsigned long long const ntiles = ((unsigned long long)a.nw + a.tile - 1)/a.tile;
@@ -370,6 +384,12 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                 atomicAdd(&probe_rec[8], (unsigned long long)pc_momlane);
                 atomicAdd(&probe_rec[9], (unsigned long long)pc_pre2);
                 atomicAdd(&probe_rec[10], (unsigned long long)pc_walk);
+                for (int i = 0; i < 8; ++i)
+                {
+                    atomicAdd(&probe_rec[14 + i], pt[i]);
+                }
+                atomicAdd(&probe_rec[22], (unsigned long long)pc_ring_inside);
+                atomicAdd(&probe_rec[23], (unsigned long long)pc_ring_lorentz);
             }
             if (tid == 0)
             {
@@ -395,13 +415,9 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
     }
     if (TREE && K == kMomWide && ncell == 0)
     {
-        // moments straight to global memory: this workgroup is the only one that adds to its tile's level-0 cells
-        // (one slice; a line belongs to the tile of its centre index), so it clears them itself -- stores that hide
-        // behind the arithmetic instead of a 2 ms pass of their own (the barrier below orders them before the adds)
-        float4 *z = reinterpret_cast<float4 *>(a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*a.gmom_stride + (uint64_t)F0*K);
-        for (int i = tid; i < (F1 - F0)*(K/4); i += kBlock)
+        for (int i = tid; i < 2*(a.tile >> 5); i += kBlock)
         {
-            z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            occ_any[i] = 0u;
         }
     }
     for (int i = tid; i <= fsteps && !TWO_PASS; i += kBlock)
@@ -433,6 +449,54 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
     float const inv_wres_f = (float)inv_wres;
     int const nw_i = (int)nw;
 
+    if constexpr (TREE && K == kMomWide)
+    {
+        if (ncell == 0)
+        {
+            // Moments straight to global memory.  This workgroup is the only one that writes its tile's level-0 cells (one
+            // slice; a line belongs to the tile of its centre index), and with two cells and more per line most lines
+            // have their cell to themselves: a first pass over the tile's lines marks the cells that hold a line / more
+            // than one (centre indices exactly as the line loop forms them), then
+            //   a cell with ONE line   is written by that line's lane, 48 bytes in three stores;
+            //   a cell with none       is cleared here;
+            //   a cell with several    is cleared here and added to with atomics -- which this chip carries out at the
+            //                          memory side, one 64-byte request each (TCC_EA0_ATOMIC = TCC_ATOMIC: 726 M per
+            //                          column at 0.001 cm-1, 44 GB of write traffic, before the cells were told apart).
+            for (uint64_t j = jbeg + tid; j < jend; j += kBlock)
+            {
+                double const wnoadj = a.lines.v0[j] + (double)a.lines.delta[j]*lay[0];
+                double const dv = wnoadj - a.w0;
+                double u = (2*(dv*inv_wres) + 1)/2;
+                if (fabs(u - rint(u)) <= 4e-15*fmax(1., fabs(u)))
+                {
+                    u = (2*(dv/a.wres) + 1)/2;
+                }
+                double const fc = floor(u);
+                if ((fc >= (double)F0) & (fc < (double)F1))
+                {
+                    int const i = (int)fc - F0;
+                    unsigned const bit = 1u << (i & 31);
+                    if (atomicOr(&occ_any[i >> 5], bit) & bit)
+                    {
+                        atomicOr(&occ_many[i >> 5], bit);
+                    }
+                }
+            }
+            __syncthreads();
+            float4 *z = reinterpret_cast<float4 *>(a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*a.gmom_stride + (uint64_t)F0*K);
+            for (int i = tid; i < (F1 - F0)*(K/4); i += kBlock)
+            {
+                int const cell = i/(K/4);
+                unsigned const bit = 1u << (cell & 31);
+                if (!(occ_any[cell >> 5] & bit) || (occ_many[cell >> 5] & bit))
+                {
+                    z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+            __syncthreads();        // (orders the clearing stores before other waves' adds)
+        }
+    }
+
     bool use_moments;
     bool corrected;
     int const R = near_radius(a, lay, ms_l, TWO_PASS ? F0l : F0l - fsteps_ll, F1l, fsteps, &use_moments, &corrected);
@@ -456,16 +520,27 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
     int qcount[Queue::classes] = {};     // wave-uniform
     auto drain = [&](int cls, int first, int count)
     {
+        unsigned long long t0 = 0;
+        if constexpr (PROBE) t0 = __builtin_readcyclecounter();
         {
             if (cls == 0) drain_class<0, kSplit ? 4 : 0>(acc, nq, wave, first, count, lane);
             else if (cls == 1) drain_class<1, 1>(acc, nq, wave, first, count, lane);
             else if (cls == 2) drain_class<2, 2>(acc, nq, wave, first, count, lane);
             else if constexpr (kSplit) drain_class<3, 3>(acc, nq, wave, first, count, lane);
         }
+        if constexpr (PROBE)
+        {
+            // (evaluating the queued points: a phase of its own, taken out of the one that called)
+            unsigned long long const dt = __builtin_readcyclecounter() - t0;
+            pt[6] += dt;
+            pt_last += dt;
+        }
     };
 
+    if constexpr (PROBE) pt_last = __builtin_readcyclecounter();
     for (uint64_t base = line_walk_first(a, jbeg, jend, wave); base < jend; base += line_walk_stride(a))
     {
+        phase_mark(5);
         // Lanes past the end of the range prepare the last line again and are masked at the end: straight
         // line code for the whole wave instead of nested divergent regions.
         uint64_t const j = base + lane;
@@ -575,6 +650,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         bool const fold = corrected & reg1_far & (fabsf(delta_c)*wr <= 0.5f*kFoldWrMax);
         bool const direct_reg1 = valid & !lorentz & (corrected ? reg1_far & !fold : true);
 
+        phase_mark(0);
         // ---- moments of the Lorentzian about the cell centre ----
         if (use_moments)
         {
@@ -621,6 +697,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                     }
                 }
             }
+            phase_mark(7);
             if constexpr (K == kMom)
             {
                 // lines are sorted by centre: most waves sit in one cell (longwave: ~300 lines per cell)
@@ -678,14 +755,34 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
             {
                 // twelve moments: only on sparse lines (tiles of 1 024 cells and more), where a wave's 64 lines sit
                 // in dozens of cells -- lane by lane
-#pragma unroll
-                for (int k = 0; k < K; ++k)
+                bool shared = true;
+                if (direct)
                 {
-                    mom_add(k, c, m[k]);
+                    int const i = c - F0;
+                    shared = (occ_many[i >> 5] >> (i & 31)) & 1u;
+                }
+                if (!shared)
+                {
+                    // the cell's only line: its moments ARE the cell
+                    float4 *dst = reinterpret_cast<float4 *>(gcell + (size_t)c*K);
+#pragma unroll
+                    for (int q = 0; q < K/4; ++q)
+                    {
+                        dst[q] = make_float4(m[4*q], m[4*q + 1], m[4*q + 2], m[4*q + 3]);
+                    }
+                }
+                else
+                {
+#pragma unroll
+                    for (int k = 0; k < K; ++k)
+                    {
+                        mom_add(k, c, m[k]);
+                    }
                 }
             }
         }
         moments_done:
+        phase_mark(1);
 
         // ---- pre-pass 1: near-centre points (|x| < XLIM1: Humlicek regions 2-4) go to the queue.
         // Each lane walks the few grid points around ITS OWN line centre: the integers r with
@@ -750,6 +847,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
             }
         }
 
+        phase_mark(2);
         // ---- pre-pass 2: region-1 points beyond the near field (Doppler widths of several grid steps:
         // fine grids, high wavenumbers), as a correction to the Lorentzian the moments supply:
         // cl (1.5 XQ - 0.5 A0) / [(D0+XQ(D2+XQ)) (XQ+YQ)]   (see k_gas_optics.hip) ----
@@ -776,6 +874,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
             }
         }
 
+        phase_mark(3);
         // ---- near field: |f - c| <= R, clipped to the line's window and the tile ----
         int const lo_n = valid ? (lo > near_lo ? lo : near_lo) : 1;
         int const hi_n = valid ? (hi < near_hi ? hi : near_hi) : 0;
@@ -919,7 +1018,12 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         {
             constexpr int PERIOD = decltype(period_tag)::value;
             constexpr int MODE = decltype(mode_tag)::value;
-            if constexpr (PROBE) pc_ring += PERIOD;
+            if constexpr (PROBE)
+            {
+                pc_ring += PERIOD;
+                pc_ring_inside += MODE == 1 ? PERIOD : 0;       // (tree form) steps without the range test
+                pc_ring_lorentz += MODE == 2 ? PERIOD : 0;      // ... and with the Lorentzian alone
+            }
             float token = 0.f;
             float slotf = (float)(lane & (PERIOD - 1));
             float const base_rel = (float)(fbp - c);
@@ -1010,12 +1114,14 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                 done += 16;
             }
         }
+        phase_mark(4);
     }
 #pragma unroll
     for (int q = 0; q < Queue::classes; ++q)
     {
         drain(q, 0, qcount[q]);
     }
+    phase_mark(2);          // (what is left in the queues counts with the walk that filled them)
     if constexpr (PROBE)
     {
         if (lane == 0) atomicMax(&probe_rec[13], (unsigned long long)__builtin_readcyclecounter());   // last wave out of the line loop
@@ -1188,6 +1294,14 @@ void gas_optics_mp_kernel_w4(GrtGasOpticsArgs a, long long fsteps_ll, unsigned n
                              int nacc, int halo)
 {
     mp_kernel_body<TWO_PASS, TREE, K, LEAN>(a, fsteps_ll, ngroups, perm_stride, ncell, nacc, halo);
+}
+
+// The instrumented instance of the tree form on sparse lines (twelve moments), see mp_kernel_body<..., PROBE>.
+__global__ __launch_bounds__(kBlock)
+void gas_optics_mp_probe_wide_kernel(GrtGasOpticsArgs a, long long fsteps_ll, unsigned ngroups, unsigned perm_stride, int ncell,
+                                     int nacc, int halo)
+{
+    mp_kernel_body<true, true, kMomWide, false, true>(a, fsteps_ll, ngroups, perm_stride, ncell, nacc, halo);
 }
 
 // The instrumented instance of the two-pass first pass (single-level form), see mp_kernel_body<..., PROBE>.
@@ -1917,7 +2031,7 @@ void launch_tree(hipStream_t s, GrtGasOpticsArgs const &b, long long fsteps, int
 size_t mp_lds_bytes(int nacc, int ncell, int fsteps, int num_slots, bool tree = false, int subtree_tile = 0)
 {
     size_t const main_loop = sizeof(double)*nacc + (tree ? sizeof(MpQueueTree) : sizeof(MpQueueFlat)) + 2*sizeof(long long) + sizeof(double)*(num_slots*(4 + GRT_MAX_ISO) + kPowTable)
-                             + sizeof(float)*((size_t)kMom*ncell + fsteps + 1);
+                             + sizeof(float)*((size_t)kMom*ncell + fsteps + 1) + sizeof(unsigned)*2*((size_t)subtree_tile >> 5);
     size_t const subtree = sizeof(float)*kMomWide*((size_t)(subtree_tile >> 1) + (size_t)(subtree_tile >> 2));
     return main_loop > subtree ? main_loop : subtree;
 }
@@ -2070,7 +2184,12 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
         {
             b.tile_phase = phase;
             b.tile_nphase = nphase;
-            if (wide)
+            if (wide && a->probe != NULL)
+            {
+                hipLaunchKernelGGL(gas_optics_mp_probe_wide_kernel, dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
+                                   fsteps, (unsigned)ngroups, golden_stride(ngroups), ncell, nacc, halo);
+            }
+            else if (wide)
             {
                 hipLaunchKernelGGL((gas_optics_mp_kernel<true, true, kMomWide>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
                                    fsteps, (unsigned)ngroups, golden_stride(ngroups), ncell, nacc, halo);

@@ -1652,11 +1652,11 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
     {
         auto_tune(go, ncol, 0, &a->tile, &a->nslice);
     }
-    if (im->probe != NULL && a->fast == 3 && a->tree_levels == 0)
+    if (im->probe != NULL && a->fast == 3 && (a->tree_levels == 0 || a->mom_terms == 12))
     {
-        /* the instrumented instance of the two-pass first pass (cost analysis): 16 words per workgroup */
+        /* the instrumented instance of the two-pass first pass (cost analysis): 24 words per workgroup */
         uint64_t const groups = ((a->nw + a->tile - 1)/a->tile)*(uint64_t)a->nslice*(uint64_t)go->num_layers*(uint64_t)ncol;
-        if (groups*16 <= im->probe_words)
+        if (groups*24 <= im->probe_words)
         {
             a->probe = im->probe;
         }

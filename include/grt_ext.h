@@ -210,12 +210,17 @@ EXTERN int grt_debug_line_prep(GasOptics_t *gas_optics, fp_t *pressure, fp_t *te
                                double *snn, double *gamma, double *alpha, int64_t *win_s,
                                int64_t *win_e);
 
-/* ---- cost-analysis hook: per-workgroup clocks and event counts of the two-pass line kernel (single-level grids).
- * buffer_dev: DEVICE memory of `words` 64-bit words, zeroed by the caller before each launch; 16 words per workgroup at
+/* ---- cost-analysis hook: per-workgroup clocks and event counts of the two-pass line kernel (single-level grids, and
+ * the cell hierarchy's twelve-moment form of sparse lines).
+ * buffer_dev: DEVICE memory of `words` 64-bit words, zeroed by the caller before each launch; 24 words per workgroup at
  * record ((column L + layer) tiles + tile) nslice + slice: clock at entry, clock at exit, candidate lines,
  * R | corrected << 16 | moments << 17, then sums over the workgroup's waves of 64-line blocks worked on, ring steps,
  * near-centre points queued, moment reductions, lane-by-lane moment adds, region-1 correction steps, near-centre walk
- * steps.  An instrumented instance of the kernel runs while a buffer is set (tile/nslice: grt_gas_optics_last_launch);
+ * steps; words 11-13: clock when the prologue is done, when every wave has left the line loop, when the last wave left
+ * it; words 14-21: clocks the waves spent in preparation, moment reduction and adds, near-centre walk and queue
+ * pushes, region-1 corrections, near field (ring), the rest of the line loop, evaluating queued points, moment terms
+ * (each mark waits for the wave's outstanding LDS operations: phases that end in LDS adds look longer than they are);
+ * words 22-23: ring steps taken without the range test / with the Lorentzian alone (cell hierarchy form).  An instrumented instance of the kernel runs while a buffer is set (tile/nslice: grt_gas_optics_last_launch);
  * NULL switches back to the production instance.  scripts/line_cost_by_wavenumber.py. */
 EXTERN int grt_gas_optics_probe(GasOptics_t *gas_optics, void *buffer_dev, uint64_t words);
 

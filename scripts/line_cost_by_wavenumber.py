@@ -19,7 +19,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-WORDS = 16
+WORDS = 24
 
 
 def probe_band(api, wl, go, grid, tag, far_tag, cols, gcols):
@@ -65,8 +65,12 @@ def probe_band(api, wl, go, grid, tag, far_tag, cols, gcols):
     corrected = ((rec[..., 3].astype(np.uint64) >> np.uint64(16)) & np.uint64(1)).astype(np.float64)
     w0, dw = float(grid.w0), float(grid.dw)
 
-    def summarise(sel_cyc, sel_lines, sel_cnt, sel_R, sel_corr):
+    inside_names = ["preparation", "moment_reduction_and_adds", "walk_and_queue_pushes", "region1_corrections", "near_field", "rest", "queue_evaluation", "moment_terms"]
+    inside = {n: rec[..., 14 + i] for i, n in enumerate(inside_names)}
+
+    def summarise(sel_cyc, sel_lines, sel_cnt, sel_R, sel_corr, sel_inside):
         nl = sel_lines.sum()
+        tot_inside = max(sum(v.sum() for v in sel_inside.values()), 1.0)
         blocks = max(sel_cnt["blocks64"].sum(), 1.0)
         ms = probe_ms * sel_cyc.sum() / total_cyc
         return {"ms_of_probe_launch": ms, "ms_of_production_launch": prod_ms * sel_cyc.sum() / total_cyc,
@@ -83,11 +87,14 @@ def probe_band(api, wl, go, grid, tag, far_tag, cols, gcols):
                 "walk_steps_per_block": sel_cnt["walk_steps"].sum() / blocks,
                 "blocks64_per_workgroup": blocks / max(sel_cyc.size, 1),
                 "lines_per_block_worked": nl / blocks,
-                "mean_R": float(sel_R.mean()), "corrected_fraction": float(sel_corr.mean())}
+                "mean_R": float(sel_R.mean()), "corrected_fraction": float(sel_corr.mean()),
+                # the waves' own clocks inside the line loop, by phase (shares)
+                "wave_clock_shares_in_line_loop": {n: float(v.sum() / tot_inside) for n, v in sel_inside.items()}}
 
     def pick(idx_tiles=slice(None), idx_layers=slice(None)):
         sub = lambda a: a[:, idx_layers][:, :, idx_tiles]
-        return summarise(sub(cyc), sub(lines), {k: sub(v) for k, v in cnt.items()}, sub(R), sub(corrected))
+        return summarise(sub(cyc), sub(lines), {k: sub(v) for k, v in cnt.items()}, sub(R), sub(corrected),
+                         {k: sub(v) for k, v in inside.items()})
 
     # by wavenumber: groups of tiles covering ~1 000 cm-1 (whole band for the longwave in ~250 cm-1 steps)
     span = 1000.0 if grid.n > 10000 else 256.0
