@@ -43,8 +43,9 @@ def main():
     api.profile_enable(True)
     for _ in range(2):
         go.calculate_optical_depth(col["p"], col["t"], opt)
-    prod = {t: api.profile_read(t, reset=True) for t in (1, 2, 6, 7)}
+    prod = {t: api.profile_read(t) for t in (1, 2, 6, 7)}
     tag = 1 if prod[1][1] else 2
+    api.profile_read(tag, reset=True)              # (a reset clears every tag)
     info = go.last_launch()
     tile, nslice = int(info["tile"]), int(info["nslice"])
     ntiles = (int(grid.n) + tile - 1) // tile

@@ -33,6 +33,13 @@ for r in csv.DictReader(open(newest(os.path.join(src, "pmc_sq", "*", "*counter_c
     if short(r["Kernel_Name"]):
         cnt[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 mean = lambda v: sum(v) / len(v)
+# traffic passes (optional): FETCH_SIZE / WRITE_SIZE in KiB (FETCH doubled on gfx950, as in summarize_profile.py), L2 atomics
+for sub in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_TCC_ATOMIC_sum_TCC_EA0_ATOMIC_sum"):
+    files = glob.glob(os.path.join(src, sub, "*", "*counter_collection.csv"))
+    if files:
+        for r in csv.DictReader(open(sorted(files, key=os.path.getmtime)[-1])):
+            if short(r["Kernel_Name"]):
+                cnt[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 g3 = {"tag": tag, "command": "python3 scripts/fine_grid.py --dw 0.001 (one 60-layer longwave column, 10^6 lines)", "kernels": {}}
 for k, v in dur.items():
     ms = mean(v[1:] if len(v) > 1 else v)                         # (the first launch carries the allocations' page faults)
@@ -41,6 +48,9 @@ for k, v in dur.items():
         e["sq"] = {c: mean(x) for c, x in cnt[k].items()}
         if "SQ_INSTS_VALU" in e["sq"]:
             e["issue_utilisation"] = e["sq"]["SQ_INSTS_VALU"] / (1024 * ms * 1e-3 * 2.4e9 * 0.5)
+        if "FETCH_SIZE" in e["sq"] and "WRITE_SIZE" in e["sq"]:
+            e["hbm_bytes_per_launch"] = 1024.0 * (2.0 * e["sq"]["FETCH_SIZE"] + e["sq"]["WRITE_SIZE"])
+            e["hbm_gb_per_s"] = e["hbm_bytes_per_launch"] / (ms * 1e-3) / 1e9
     g3["kernels"][k] = e
 path = os.path.join(ROOT, "profiles", "traffic_latest.json")
 t = json.load(open(path))
