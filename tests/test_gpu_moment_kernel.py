@@ -192,6 +192,8 @@ def test_one_column_launch_shape_keeps_a_few_thousand_lines_per_workgroup(tmp_pa
     opt = api.OpticsObject(V - 1, grid, device)
     go.calculate_optical_depth(col["p"], col["t"], opt)
     info = go.last_launch()
+    if api.load_library().grt_deterministic():
+        want = (want[0], 1)        # (the verification mode never cuts a tile into line slices)
     assert (info["fast"], info["tile"], info["nslice"]) == (3,) + want, info
     opt.destroy()
     go.destroy()
