@@ -119,10 +119,14 @@ __device__ __forceinline__ float row_sum_transposed(float const (&m)[8], bool b3
 // (1 cm-1 shortwave launch 14.8 -> 14.4 ms).  Entries are 14 bytes so that four queues fit where three of 22 did.
 constexpr int kClasses = 3;
 constexpr int kClassesSplit = 4;
-// entries per (class, wave): batches of 64 leave at most 63 behind.  88 (80 ... 96 measured the same, 104 costs the
-// fourth workgroup of a CU: 14.4 -> 16.6 ms) where lines are dense; 64 in the tree form, whose first pass is short of
-// LDS (0.001 cm-1: four workgroups per CU instead of three, 42 -> 39 ms) and whose pushes mostly come as full batches
-constexpr int kMpQueue = 88;
+// entries per (class, wave): batches of 64 leave at most 63 behind, so 64 is the least a queue can have.  At four
+// workgroups per CU 80 ... 96 measured the same (104 cost the fourth workgroup: 14.4 -> 16.6 ms); at five (see
+// gas_optics_mp_kernel_w5) the LDS they take is what decides: 64 entries.  The tree form's first pass is short of LDS
+// anyway (0.001 cm-1: four workgroups per CU instead of three, 42 -> 39 ms) and its pushes mostly come as full batches
+#ifndef GRT_MP_QUEUE
+#define GRT_MP_QUEUE 64
+#endif
+constexpr int kMpQueue = GRT_MP_QUEUE;
 constexpr int kMpQueueTree = 64;
 
 template <int CAP, int NCLS>
@@ -1286,11 +1290,19 @@ __global__ __launch_bounds__(kBlock) void gas_optics_mp_kernel(GrtGasOpticsArgs 
     mp_kernel_body<TWO_PASS, TREE, K>(a, fsteps_ll, ngroups, perm_stride, ncell, nacc, halo);
 }
 
-// The same, told to fit four waves per SIMD: the 8-moment instantiations come out a register over the 128-VGPR
-// line otherwise (three waves per SIMD: 1 cm-1 302 instead of 348 columns/s, 0.01 cm-1 6.5 instead of 5.8 ms).
+// The same, told to fit FIVE waves per SIMD (96 VGPRs, 8-16 of them spilled to scratch; five workgroups per CU with the
+// queues at 64 entries).  The line loop is one long chain of dependent instructions -- fp64 preparation, transcendentals,
+// DPP -- so a wave issues every ~13 cycles and what fills the vector pipe is the number of waves: removing instructions
+// (64-bit addressing of the line loads, their scalar reloads: -12 per block) or prefetching the next block's lines changed
+// nothing at four waves; measured on G1 (64 columns, LW + SW launch): 4 waves (120 VGPRs, 88-entry queues) 44.7 + 114.9 ms,
+// **5 waves 42.1 + 108.0** (80-entry queues: 43.3 + 109.1), 6 waves (80 VGPRs, 96 bytes of scratch) 43.1 + 110.7,
+// 7 waves 46.8 + 113.1.  (GRT_MP_WAVES / GRT_MP_QUEUE on the compiler's command line: exploration only.)
 template <bool TWO_PASS, bool TREE, int K, bool LEAN = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void gas_optics_mp_kernel_w4(GrtGasOpticsArgs a, long long fsteps_ll, unsigned ngroups, unsigned perm_stride, int ncell,
+#ifndef GRT_MP_WAVES
+#define GRT_MP_WAVES 5
+#endif
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GRT_MP_WAVES, GRT_MP_WAVES)))
+void gas_optics_mp_kernel_w5(GrtGasOpticsArgs a, long long fsteps_ll, unsigned ngroups, unsigned perm_stride, int ncell,
                              int nacc, int halo)
 {
     mp_kernel_body<TWO_PASS, TREE, K, LEAN>(a, fsteps_ll, ngroups, perm_stride, ncell, nacc, halo);
@@ -2196,7 +2208,7 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
             }
             else if (tree)
             {
-                hipLaunchKernelGGL((gas_optics_mp_kernel_w4<true, true, kMom>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
+                hipLaunchKernelGGL((gas_optics_mp_kernel_w5<true, true, kMom>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
                                    fsteps, (unsigned)ngroups, golden_stride(ngroups), ncell, nacc, halo);
             }
             else
@@ -2218,12 +2230,12 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
                 }
                 else if (a->w0 + (double)a->nw*a->wres <= 4000.)
                 {
-                    hipLaunchKernelGGL((gas_optics_mp_kernel_w4<true, false, kMom, true>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
+                    hipLaunchKernelGGL((gas_optics_mp_kernel_w5<true, false, kMom, true>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
                                        fsteps, (unsigned)ngroups, golden_stride(ngroups), ncell, nacc, halo);
                 }
                 else
                 {
-                    hipLaunchKernelGGL((gas_optics_mp_kernel_w4<true, false, kMom>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
+                    hipLaunchKernelGGL((gas_optics_mp_kernel_w5<true, false, kMom>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
                                        fsteps, (unsigned)ngroups, golden_stride(ngroups), ncell, nacc, halo);
                 }
             }
@@ -2276,7 +2288,7 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
     GrtGasOpticsArgs b = *a;
     b.rcap = kRcap;
     b.direct_near = direct_near_wanted();
-    hipLaunchKernelGGL((gas_optics_mp_kernel_w4<false, false, kMom>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b, fsteps,
+    hipLaunchKernelGGL((gas_optics_mp_kernel_w5<false, false, kMom>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b, fsteps,
                        (unsigned)ngroups, golden_stride(ngroups), ncell, a->tile, 0);
     return (int)hipGetLastError();
 }
