@@ -43,10 +43,16 @@
 
 namespace {
 
-// Register budget: the fused form needs 128 VGPRs (4 waves per SIMD), the reference-order form
-// 146 (3 waves per SIMD); neither spills.  (Forcing 128 on the reference-order form costs 72 B/lane
-// of scratch, which showed up as ~1.4 GB of extra WRITE_SIZE per shortwave launch.)
+// Register budget.  Both forms are chains of dependent instructions, so what fills the vector pipe is the number of waves
+// (k_gas_optics_mp.hip, gas_optics_mp_kernel_w5): the reference-order form, 150 VGPRs and three waves per SIMD left to
+// itself, runs at FOUR (128 VGPRs, 60 bytes per lane spilled to scratch): 65.1 -> 72.0 columns/s on G1 (five: 71.8); the
+// fused form has its four waves in 127 VGPRs without spilling (five, 96 VGPRs and 116 bytes of scratch: 132.9 -> 134.9,
+// not taken).  GRT_RING_WAVES on the compiler's command line: exploration only.
 template <bool FAST>
+#ifndef GRT_RING_WAVES
+#define GRT_RING_WAVES 4
+#endif
+__attribute__((amdgpu_waves_per_eu(GRT_RING_WAVES, GRT_RING_WAVES)))
 __global__ __launch_bounds__(kBlock) void gas_optics_kernel(GrtGasOpticsArgs a, long long fsteps, unsigned ngroups,
                                                                                           unsigned perm_stride)
 {
