@@ -882,10 +882,8 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         // ---- near field: |f - c| <= R, clipped to the line's window and the tile ----
         int const lo_n = valid ? (lo > near_lo ? lo : near_lo) : 1;
         int const hi_n = valid ? (hi < near_hi ? hi : near_hi) : 0;
-        if constexpr (!TREE && LEAN)
+        if constexpr (!TREE)
         {
-            // (measured on G1, 8 columns: longwave launch 5.94 -> 5.80 ms; on the shortwave band, where a row straddles two
-            // cells and takes two reduction passes, 14.50 -> 14.90 ms: so only the instance of the dense longwave band has it)
             if (R == 3 && a.direct_near != 0)
             {
                 // ---- seven-point near fields (R = 3: every (tile, layer) of the 1 cm-1 grids but the lowest layers')
@@ -945,21 +943,37 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                     cr = min(cr, dpp_i<0x122>(cr));
                     cr = min(cr, dpp_i<0x124>(cr));
                     cr = min(cr, dpp_i<0x128>(cr));                      // the row's lowest pending cell, in every lane
+                    // Eight slots: the grid points cr - 3 .. cr + 4.  The lines of cell cr fill slots 0 .. 6; where a row
+                    // straddles two cells (the shortwave band: 30 lines per cell) the lines of cell cr + 1 fill slots 1 .. 7
+                    // -- their seven values one slot up -- and ONE reduction serves both cells.
                     bool const mine = pending & (c == cr);
+                    bool const next = pending & (c - cr == 1);
                     float nn[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k)
+                    if (__ballot(next) == 0ull)
                     {
-                        nn[k] = mine ? nv[k] : 0.f;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                        {
+                            nn[k] = mine ? nv[k] : 0.f;
+                        }
+                    }
+                    else
+                    {
+                        nn[0] = mine ? nv[0] : 0.f;
+#pragma unroll
+                        for (int k = 1; k < 8; ++k)
+                        {
+                            nn[k] = mine ? nv[k] : (next ? nv[k - 1] : 0.f);
+                        }
                     }
                     float const t = row_sum_transposed(nn, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0);
-                    // lane l of the row holds the sum of value (l >> 1) & 7: grid point cr - 3 + that; a sum that is not
+                    // lane l of the row holds the sum of slot (l >> 1) & 7: grid point cr - 3 + that; a sum that is not
                     // zero has a contribution from inside some line's clipped near field, i.e. inside the accumulator
                     if (((lane & 1) == 0) & (cr != 0x7fffffff) & (t != 0.f))
                     {
                         GRT_ACC_ADD(&acc[cr - 3 + ((lane >> 1) & 7) - A0], (double)t);
                     }
-                    pending = pending & !mine;
+                    pending = pending & !(mine | next);
                 }
                 if (pending)
                 {
