@@ -111,6 +111,44 @@ __device__ __forceinline__ float row_sum_transposed(float const (&m)[8], bool b3
     return y + dpp_f<0xB1>(y);                          // quad_perm:[1,0,3,2]
 }
 
+// Row sums of eight values per lane for TWO groups of lanes at once: every lane hands in its eight values and says
+// whether it belongs to group 0, group 1 or neither.  On return lane l of the row holds, for group b3 (bit 3 of l & 15),
+// the sum over the group's lanes of m[l & 7]: sixteen sums in sixteen lanes, none twice.  The first exchange
+// (partner = lane ^ 15) sends each half of the row the other group's values; the three halving exchanges of
+// row_sum_transposed follow inside the halves.  15 DPP adds + 30 selects, where two calls of row_sum_transposed take
+// 18 + 28 + 16 for the masks -- and one chain of dependent exchanges instead of two.
+__device__ __forceinline__ float row_sum_transposed_pair(float const (&m)[8], bool in0, bool in1, bool b3, bool b2, bool b1, bool b0)
+{
+    bool const keep_mine = b3 ? in1 : in0, send_mine = b3 ? in0 : in1;
+    float w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+    {
+        float const keep = keep_mine ? m[i] : 0.f;
+        float const send = send_mine ? m[i] : 0.f;
+        w[i] = keep + dpp_f<0x140>(send);               // row_mirror: the partner is in the other half
+    }
+    float x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+    {
+        float const keep = b2 ? w[i + 4] : w[i];
+        float const send = b2 ? w[i] : w[i + 4];
+        x[i] = keep + dpp_f<0x141>(send);               // row_half_mirror: lane ^ 7, other b2
+    }
+    float y[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+    {
+        float const keep = b1 ? x[i + 2] : x[i];
+        float const send = b1 ? x[i] : x[i + 2];
+        y[i] = keep + dpp_f<0x1B>(send);                // quad_perm:[3,2,1,0]: lane ^ 3, other b1
+    }
+    float const keep = b0 ? y[1] : y[0];
+    float const send = b0 ? y[0] : y[1];
+    return keep + dpp_f<0xB1>(send);                    // quad_perm:[1,0,3,2]: lane ^ 1, other b0
+}
+
 // Near-centre points (Humlicek regions 1-4 inside XLIM1) wait in per-wave LDS queues, one queue per
 // class of formula (voigt_class), so that a batch of 64 points runs ONE formula with all lanes busy:
 // evaluated unsorted, a batch pays for every formula present in it (~4x the work of the usual mix).
@@ -717,9 +755,11 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                     }
                     goto moments_done;
                 }
-                // Several cells in the wave: every row of 16 lanes works on ITS lowest pending cell, so one pass
-                // serves four cells at once; sorted lines rarely put more than two cells in a row.  Whatever is
-                // still pending after kCellLoop passes (sparse spectra: a cell per line) is added lane by lane.
+                // Several cells in the wave: every row of 16 lanes works on ITS lowest pending cell AND the next one, each
+                // half of the row ending up with one cell's eight sums (row_sum_transposed_pair), so one pass serves
+                // eight cells at once; sorted lines rarely put more than two cells in a row (shortwave band: 30 lines
+                // per cell).  Whatever is still pending after kCellLoop passes (sparse spectra: a cell per line) is
+                // added lane by lane.
                 bool pending = valid;
                 // (a wave spread over two dozen cells or more -- fine grids -- goes lane by lane at once)
                 bool const sparse = __builtin_amdgcn_readlane(c, 63 - __builtin_clzll(vmask)) - c_ref >= 24;    // (sorted lines)
@@ -731,19 +771,15 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                     cr = min(cr, dpp_i<0x124>(cr));
                     cr = min(cr, dpp_i<0x128>(cr));                      // the row's lowest pending cell, in every lane
                     bool const mine = pending & (c == cr);
+                    bool const next = pending & (c - cr == 1);
                     if constexpr (PROBE) ++pc_momred;
-                    float mm[kMom];
-    #pragma unroll
-                    for (int k = 0; k < kMom; ++k)
+                    float const t = row_sum_transposed_pair(m, mine, next, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0, (lane & 1) != 0);
+                    // (a sum of nothing -- no line of that cell in this row -- is an exact zero: nothing to add)
+                    if ((cr != 0x7fffffff) & (t != 0.f))
                     {
-                        mm[k] = mine ? m[k] : 0.f;
+                        mom_add(lane & 7, cr + ((lane >> 3) & 1), t);
                     }
-                    float const t = row_sum_transposed(mm, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0);
-                    if (((lane & 1) == 0) & (cr != 0x7fffffff))
-                    {
-                        mom_add((lane >> 1) & 7, cr, t);
-                    }
-                    pending = pending & !mine;
+                    pending = pending & !(mine | next);
                 }
                 if constexpr (PROBE) pc_momlane += (unsigned)__popcll(__ballot(pending));
                 if (pending)
