@@ -43,6 +43,12 @@ __host__ __device__ inline double moment_separation(int terms)
 {
     return terms == kMomWide ? 3.95 : 7.8;        // 3.95^-12 = 7e-8 = 7.8^-8
 }
+// LDS a workgroup of these kernels may ask for.  gfx950 would let one workgroup declare 160 KB (opt-in per kernel), but every
+// form here lives on several workgroups per CU (five of 27 KB for the 1 cm-1 first pass, four of 38 KB for the 0.001 cm-1
+// one): a form that does not fit 64 KB hands over to the next one -- single level -> cell hierarchy at windows of 200
+// points a side, eight moments in LDS -> twelve straight to global memory -- and those crossovers were MEASURED earlier than
+// the cap would force them, so the cap only guards odd hand-made tilings (tests, grt_gas_optics_tune).
+constexpr size_t kLdsPerWorkgroup = 64*1024;
 constexpr int kRcap = 12;       // widest near field taken for the sake of region 1 unless the host says otherwise (args.rcap)
 constexpr int kPowTable = 128;  // tabulated temperature exponents n = k/100 (kernels.c:105)
 constexpr int kCellLoop = 3;    // passes of the in-register moment reduction before falling back to per-lane adds
@@ -2147,9 +2153,9 @@ extern "C" int grt_gas_optics_mp_applicable(GrtGasOpticsArgs const *a)
                && a->gmom_stride >= level_offset(a->nw, a->tree_levels + 1, terms, a->tree_levels)
                && level_offset(a->nw, a->tree_levels + 1, terms, a->tree_levels) < 0xffffffffull
                && a->tile + 2*a->halo <= 32767
-               && mp_lds_bytes(a->tile + 2*a->halo, direct ? 0 : a->tile, 0, a->lay.num_slots, true, direct ? a->tile : 0) <= 64*1024
-               && tree_lds_bytes(tree_gather_tile(), a->lay.num_slots, tree_gather_ntab(a->tile, a->halo)) <= 64*1024
-               && tree_lds_bytes(a->tile, a->lay.num_slots, (a->tile + 2*a->halo)/a->tile + 2) <= 64*1024;
+               && mp_lds_bytes(a->tile + 2*a->halo, direct ? 0 : a->tile, 0, a->lay.num_slots, true, direct ? a->tile : 0) <= kLdsPerWorkgroup
+               && tree_lds_bytes(tree_gather_tile(), a->lay.num_slots, tree_gather_ntab(a->tile, a->halo)) <= kLdsPerWorkgroup
+               && tree_lds_bytes(a->tile, a->lay.num_slots, (a->tile + 2*a->halo)/a->tile + 2) <= kLdsPerWorkgroup;
     }
     if (fsteps > 4096)
     {
@@ -2163,10 +2169,10 @@ extern "C" int grt_gas_optics_mp_applicable(GrtGasOpticsArgs const *a)
     {
         int const shift = log2_exact(a->tile);
         return shift >= 6 && a->gmom != NULL && a->gmom_stride >= (uint64_t)kMom*a->nw
-               && mp_lds_bytes(a->tile + 2*(int)fsteps, a->tile, 0, a->lay.num_slots) <= 64*1024
-               && far_lds_bytes(a->tile, a->tile + 2*(int)fsteps, (int)fsteps, a->lay.num_slots, shift) <= 64*1024;
+               && mp_lds_bytes(a->tile + 2*(int)fsteps, a->tile, 0, a->lay.num_slots) <= kLdsPerWorkgroup
+               && far_lds_bytes(a->tile, a->tile + 2*(int)fsteps, (int)fsteps, a->lay.num_slots, shift) <= kLdsPerWorkgroup;
     }
-    return mp_lds_bytes(a->tile, a->tile + 2*(int)fsteps, (int)fsteps, a->lay.num_slots) <= 64*1024;
+    return mp_lds_bytes(a->tile, a->tile + 2*(int)fsteps, (int)fsteps, a->lay.num_slots) <= kLdsPerWorkgroup;
 }
 
 // floats per (column, layer) block of gmom that `levels` coarse levels need (the host sizes the buffer with it)
@@ -2320,7 +2326,7 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
             }
             int far_tile = a->tile;
             while (2*far_tile <= far_want && (uint64_t)far_tile < a->nw
-                   && far_lds_bytes(2*far_tile, 2*far_tile + 2*(int)fsteps, (int)fsteps, a->lay.num_slots, shift) <= 64*1024)
+                   && far_lds_bytes(2*far_tile, 2*far_tile + 2*(int)fsteps, (int)fsteps, a->lay.num_slots, shift) <= kLdsPerWorkgroup)
             {
                 far_tile *= 2;
             }
