@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--fast", type=int, default=3)
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--pscale", type=float, default=1.0, help="exploration: pressures scaled by this factor")
     ap.add_argument("--compare", type=int, default=None, help="also run this form and report the largest difference")
     args = ap.parse_args()
 
@@ -33,6 +34,7 @@ def main():
     lines = W.band_lines(args.lines, grid_spec, 20261003)
     go, grid = W.build_band(device, grid_spec, lines, files, args.levels)
     col = syn.profile(0, args.levels)
+    col["p"] = col["p"] * args.pscale
     for m in W.MOL_ORDER:
         go.set_molecule_ppmv(m, col["ppmv"][m])
     go.set_cfc_ppmv(0, col["cfc_ppmv"][0])
