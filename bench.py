@@ -239,6 +239,21 @@ def parity_of_column0(wl, fluxes, bands, kind):
     return out
 
 
+# What a rank needs in its environment before torch / HIP / RCCL exist in it, whoever started it -- spawn_ranks below or
+# `python -m torch.distributed.run` (the driver): set by the rank ITSELF, first thing, so that the two launch paths cannot
+# differ (tests/test_bench_launcher.py diffs them).  HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver only supports dmabuf
+# IPC; without it RCCL's cross-process buffers fail with hipIpcGetMemHandle: invalid argument.
+RANK_ENVIRONMENT = {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+
+
+def rank_environment():
+    for k, v in RANK_ENVIRONMENT.items():
+        os.environ.setdefault(k, v)
+    if os.environ.get("GRT_BENCH_DUMP_ENV"):            # test hook: what this rank will run under
+        with open(os.environ["GRT_BENCH_DUMP_ENV"] + f".rank{os.environ.get('RANK', '0')}", "w") as f:
+            json.dump({k: os.environ.get(k) for k in sorted(RANK_ENVIRONMENT)}, f)
+
+
 def spawn_ranks(ngpus):
     """`python bench.py --gpus N` with no launcher around it: start the N ranks ourselves, as plain child processes --
     the way the reference fans out its column shards (GRTworkflow/run-rfmip-irf.sh:103-132: one process per -x/-X block).
@@ -256,7 +271,6 @@ def spawn_ranks(ngpus):
     for r in range(ngpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(ngpus), LOCAL_WORLD_SIZE=str(ngpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GRT_BENCH_SPAWNED="1")
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
 
@@ -367,6 +381,7 @@ def main():
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    rank_environment()
     import torch
     import torch.distributed as dist
     from grtcode_amd import multi
@@ -500,7 +515,16 @@ def main():
             gather()
     barrier()
     elapsed = time.perf_counter() - t0
+    own_elapsed = elapsed
     elapsed = multi.max_over_ranks(elapsed, torch.device("cpu") if rehearsal else dev_t)
+    # every rank's own time, for the line (load balance of the shards): one more tiny gather, after the timed region
+    rank_ms = [1e3 * own_elapsed / args.steps]
+    if use_dist:
+        mine = torch.tensor([rank_ms[0]], dtype=torch.float64, device=torch.device("cpu") if rehearsal else dev_t)
+        every = [torch.zeros_like(mine) for _ in range(world)] if rank == 0 else None
+        dist.gather(mine, every, dst=0)
+        if rank == 0:
+            rank_ms = [float(t.item()) for t in every]
 
     if rank == 0:
         fluxes = job[(args.steps - 1) % slots].cpu().numpy()           # this rank's block of the last step
@@ -515,7 +539,7 @@ def main():
                 want = np.array([[PlaceholderEngine.expected(c, k) for k in range(nfl)] for c in range(total_per_step)])
                 assert all(np.array_equal(allf[sl], want) for sl in range(slots)), "gathered blocks are not the columns in order"
         total_cols = total_per_step * args.steps
-        dist_info = {"n_gpus": world, "rccl_ranks": world if backend == "nccl" else 0,
+        dist_info = {"n_gpus": world, "rccl_ranks": world if backend == "nccl" else 0, "ms_per_step_by_rank": rank_ms,
                      "collective": {"backend": backend, "gathers_in_timed_region": gathers["count"],
                                     "bytes_per_rank_per_gather": int(job.numel()) * 8 if use_dist else 0,
                                     "what": "one gather of the job's [steps][columns][12] integrated fluxes to rank 0" if use_dist else None}}

@@ -106,3 +106,32 @@ def test_the_parent_never_imports_torch():
     assert "import torch" not in main_head and "grtcode_amd" not in main_head
     top = src[: src.index("def cpu_baseline")]
     assert "import torch" not in top and "from grtcode_amd" not in top
+
+
+def test_both_launch_paths_give_a_rank_the_same_environment(tmp_path):
+    """`python bench.py --gpus 2` (spawn_ranks) and `python -m torch.distributed.run ... bench.py --gpus 2` (the driver) must not
+    differ in what a rank runs under: the rank sets RANK_ENVIRONMENT itself, before torch exists in it (task 6).
+    Both paths start from an environment WITHOUT the variable; each rank dumps what it ended up with."""
+    import json
+    import socket
+    base = {k: v for k, v in os.environ.items()
+            if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")}
+    base["GRT_BENCH_REHEARSAL"] = "1"
+    dumps = {}
+    for how in ("spawned", "torchrun"):
+        e = dict(base, GRT_BENCH_DUMP_ENV=str(tmp_path / how))
+        if how == "spawned":
+            cmd = [sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--cols", "2"]
+        else:
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                port = so.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                   "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--cols", "2"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=e, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = only_line(r)
+        assert len(line["ms_per_step_by_rank"]) == 2 and all(t > 0. for t in line["ms_per_step_by_rank"])
+        dumps[how] = [json.load(open(str(tmp_path / how) + f".rank{k}")) for k in range(2)]
+    assert dumps["spawned"] == dumps["torchrun"]
+    assert all(d == {"HSA_ENABLE_IPC_MODE_LEGACY": "0"} for d in dumps["spawned"])
