@@ -242,8 +242,13 @@ static void pade_load(PadeOptics *o, char const *path)
             exit(EXIT_FAILURE);
         }
         int const order = (int)c->dims[0];
-        if (k % 2 == 0) o->np = order; else o->nq = order;
-        if ((k >= 2) && order != (k % 2 == 0 ? o->np : o->nq))
+        /* the first numerator and denominator tables set the orders; the other four must have them (the reference reads
+           all six with the file's n and m dimensions) */
+        if (k < 2)
+        {
+            if (k == 0) o->np = order; else o->nq = order;
+        }
+        else if (order != (k % 2 == 0 ? o->np : o->nq))
         {
             fatal("Pade tables of different orders in ", path);
         }
@@ -463,6 +468,35 @@ static void sample_subcolumn(int L, double const *cf, double const *lwc, double 
             qi[i] = total*(1. - liquid_fraction);
         }
     }
+}
+
+/* ---- test hooks (include/clouds_lib.h): what the reference's stochastic_clouds.c, compiled where it lies into
+   oracle/_ref/libstochastic_ref.so, is compared with bit for bit (tests/test_clouds_library.py) ---- */
+int grt_clouds_sample_subcolumn(int num_layers, const double *cloud_fraction, const double *lwc, const double *iwc,
+                                const double *overlap, double *ql, double *qi)
+{
+    if (!lib.ready || num_layers < 1)
+    {
+        return 1;
+    }
+    double *rank = malloc(sizeof(double)*(size_t)num_layers);
+    if (rank == NULL)
+    {
+        return 1;
+    }
+    sample_subcolumn(num_layers, cloud_fraction, lwc, iwc, overlap, rank, ql, qi);
+    free(rank);
+    return 0;
+}
+
+/* the loaded incomplete-beta tables: inverse != 0 -> the inverse table (incomplete_beta.c: beta_inverse), else beta_value */
+double grt_clouds_beta(int inverse, int p, int q, double x)
+{
+    if (!lib.ready)
+    {
+        fatal("grt_clouds_beta called before initialize_clouds_lib", NULL);
+    }
+    return beta_lookup(&lib.beta, inverse ? lib.beta.inverse : lib.beta.value, p, q, x);
 }
 
 int cloud_optics(const double *wavenum, int num_wavenum, int num_layers, const double *mean_cloud_fraction,

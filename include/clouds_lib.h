@@ -21,4 +21,12 @@ int cloud_optics(const double *wavenum, int num_wavenum, int num_layers, const d
                  double *g_liquid, double *beta_ice, double *omega_ice, double *g_ice);
 int calculate_overlap(int const num_layers, double const *altitude, double const scale_length, double *alpha);
 
+/* Test hooks (not part of the reference's interface): one subcolumn's condensate exactly as cloud_optics draws it per band
+   (clouds/stochastic_clouds.c:94-120), and a look-up in the loaded incomplete-beta tables.  tests/test_clouds_library.py
+   compares the first with the reference's own stochastic_clouds.c (oracle/_ref/libstochastic_ref.so), which gets its
+   beta_inverse / beta_value from the second (tests/support/beta_bridge.c) -- the reference's incomplete_beta.c needs netCDF. */
+int grt_clouds_sample_subcolumn(int num_layers, const double *cloud_fraction, const double *lwc, const double *iwc,
+                                const double *overlap, double *ql, double *qi);
+double grt_clouds_beta(int inverse, int p, int q, double x);
+
 #endif

@@ -97,6 +97,35 @@ def main():
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_fixtures.npz")
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path), "bytes,", len(out), "arrays")
+    stochastic_clouds()
+
+
+def stochastic_clouds():
+    """What the reference's clouds/stochastic_clouds.c (oracle/_ref/libstochastic_ref.so, compiled where it lies) returns
+    for the cases of tests/test_clouds_library.py::stochastic_cases -- overlap parameter and three successive subcolumns per
+    case after srand(seed); doubles as hex strings (bit-exact).  Inputs are regenerated by the test from the same seeds."""
+    import json
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_clouds_library as T
+    from cloud_model import LibcRand, synthetic_tables
+    tables_seed = 5
+    with tempfile.TemporaryDirectory() as tmp:
+        paths, _ = synthetic_tables(tmp, seed=tables_seed)
+        ref = T.reference_sampler()
+        assert ref.initialize_clouds_lib(paths["beta"].encode(), paths["ice"].encode(), paths["liquid"].encode()) == 0
+        rand = LibcRand()
+        cases = []
+        for case in T.stochastic_cases():
+            out = T.run_sampler(ref, rand, case, reference=True)
+            cases.append({"seed": case["seed"], "cf": case["cf"].tolist(), "out": [[float(v).hex() for v in a] for a in out]})
+        ref.finalize_clouds_lib()
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stochastic_clouds_ref.json")
+    json.dump({"what": "overlap_parameter + sample_condensate of /root/reference/clouds/stochastic_clouds.c (built unchanged into "
+                       "oracle/_ref/libstochastic_ref.so), three draws per case after srand(seed); beta look-ups from this "
+                       "repository's loaded tables (tests/support/beta_bridge.c)",
+               "tables_seed": tables_seed, "cases": cases}, open(path, "w"))
+    print(path, os.path.getsize(path), "bytes,", len(cases), "cases")
 
 
 if __name__ == "__main__":

@@ -98,3 +98,107 @@ def test_a_netcdf_path_is_refused_with_advice(tmp_path, clouds):
     code = ("import ctypes as C; lib = C.CDLL(%r); lib.initialize_clouds_lib(%r, b'x', b'y')" % (clouds._name, str(bad).encode()))
     r = subprocess.run(["python3", "-c", code], capture_output=True, text=True)
     assert r.returncode != 0 and "netcdf_to_dump.py" in r.stderr
+
+
+# ---- the sampling half of the row, pinned on the reference's own C (task 7) -------------------------------- #
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libstochastic_ref.so")
+STOCHASTIC_FIXTURE = os.path.join(ROOT, "tests", "golden", "stochastic_clouds_ref.json")
+
+
+class _IncompleteBeta(C.Structure):      # clouds/incomplete_beta.h (never read: the bridge asks our loaded tables)
+    _fields_ = [("num_shape", C.c_int), ("num_x", C.c_int), ("p", C.c_void_p), ("q", C.c_void_p), ("x", C.c_void_p),
+                ("y", C.c_void_p), ("y_inverse", C.c_void_p)]
+
+
+class _TotalWaterPDF(C.Structure):       # clouds/stochastic_clouds.h:8-13
+    _fields_ = [("beta", C.POINTER(_IncompleteBeta)), ("p", C.c_int), ("q", C.c_int)]
+
+
+def stochastic_cases():
+    """Columns for the sampling comparison: random cloud fractions incl. overcast and clear layers, liquid-only and
+    ice-only clouds, thick and thin layers (overlap near 1 and near 0)."""
+    cases = []
+    for seed in (3, 4, 5, 17, 2024):
+        rng = np.random.default_rng(seed)
+        L = int(rng.integers(6, 40))
+        cf = np.where(rng.random(L) < 0.6, rng.random(L), 0.0)
+        cf[0], cf[1] = 1.0, 0.0
+        lwc = np.where(cf > 0, 0.4 * rng.random(L), 0.0)
+        iwc = np.where(cf > 0, 0.06 * rng.random(L), 0.0)
+        lwc[2] = 0.0 if cf[2] > 0 and iwc[2] > 0 else lwc[2]
+        iwc[3] = 0.0 if cf[3] > 0 and lwc[3] > 0 else iwc[3]
+        alt = np.cumsum(10.0 ** rng.uniform(-2.0, 1.0, L))[::-1].copy()
+        cases.append(dict(seed=seed, cf=cf, lwc=lwc, iwc=iwc, alt=alt, scale=float(rng.uniform(0.5, 4.0))))
+    return cases
+
+
+def reference_sampler():
+    """oracle/_ref/libstochastic_ref.so: the reference's stochastic_clouds.c + our libclouds.a in one object."""
+    ref = C.CDLL(REF_SO)
+    dp = C.POINTER(C.c_double)
+    ref.overlap_parameter.argtypes = [C.c_int, dp, C.c_double, dp]
+    ref.overlap_parameter.restype = None
+    ref.sample_condensate.argtypes = [_TotalWaterPDF, C.c_int, dp, dp, dp, dp, dp, dp]
+    ref.sample_condensate.restype = None
+    ref.grt_clouds_sample_subcolumn.argtypes = [C.c_int, dp, dp, dp, dp, dp, dp]
+    ref.calculate_overlap.argtypes = [C.c_int, dp, C.c_double, dp]
+    return ref
+
+
+def run_sampler(lib, rand, case, reference, draws=3):
+    """`draws` subcolumns in a row after srand(seed): overlap parameter, then ql, qi of every draw."""
+    L = case["cf"].size
+    overlap = np.zeros(L - 1)
+    if reference:
+        lib.overlap_parameter(L, ptr(case["alt"]), case["scale"], ptr(overlap))
+        beta = _IncompleteBeta()
+        pdf = _TotalWaterPDF(C.pointer(beta), 5, 5)                 # clouds_lib.c: construct_water_pdf(&pdf, 5, 5, &beta)
+    else:
+        assert lib.calculate_overlap(L, ptr(case["alt"]), case["scale"], ptr(overlap)) == 0
+    out = [overlap]
+    rand.seed(case["seed"])
+    for _ in range(draws):
+        ql, qi = np.full(L, -1.0), np.full(L, -1.0)
+        if reference:
+            lib.sample_condensate(pdf, L, ptr(case["cf"]), ptr(case["lwc"]), ptr(case["iwc"]), ptr(overlap), ptr(ql), ptr(qi))
+        else:
+            assert lib.grt_clouds_sample_subcolumn(L, ptr(case["cf"]), ptr(case["lwc"]), ptr(case["iwc"]), ptr(overlap), ptr(ql), ptr(qi)) == 0
+        out += [ql, qi]
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(REF_SO), reason="oracle/_ref/libstochastic_ref.so not built (no reference tree on this box)")
+def test_sampling_equals_the_reference_c_bit_for_bit(tmp_path):
+    """clouds/stochastic_clouds.c compiled where it lies: same srand seed, same rand() call order, same subcolumns -- overlap
+    parameter and condensate of three successive draws, every layer, to the last bit."""
+    paths, _ = synthetic_tables(str(tmp_path), seed=5)
+    ref = reference_sampler()
+    assert ref.initialize_clouds_lib(paths["beta"].encode(), paths["ice"].encode(), paths["liquid"].encode()) == 0
+    rand = LibcRand()
+    for case in stochastic_cases():
+        want = run_sampler(ref, rand, case, reference=True)
+        got = run_sampler(ref, rand, case, reference=False)
+        assert any(np.any(w > 0.0) for w in want[1:])
+        for w, g in zip(want, got):
+            assert np.array_equal(w, g), (case["seed"], np.abs(w - g).max())
+    assert ref.finalize_clouds_lib() == 0
+
+
+def test_sampling_equals_the_committed_reference_vectors(tmp_path, clouds):
+    """The same comparison where the reference tree is absent (the GPU box): tests/golden/stochastic_clouds_ref.json holds
+    what oracle/_ref/libstochastic_ref.so returned here (tests/golden/make_golden.py writes it); libc's rand() is the
+    image's, the same on both boxes."""
+    import json
+    fixture = json.load(open(STOCHASTIC_FIXTURE))
+    paths, _ = synthetic_tables(str(tmp_path), seed=fixture["tables_seed"])
+    clouds.grt_clouds_sample_subcolumn.argtypes = [C.c_int] + [C.POINTER(C.c_double)] * 6
+    assert clouds.initialize_clouds_lib(paths["beta"].encode(), paths["ice"].encode(), paths["liquid"].encode()) == 0
+    rand = LibcRand()
+    cases = stochastic_cases()
+    assert len(cases) == len(fixture["cases"])
+    for case, rec in zip(cases, fixture["cases"]):
+        assert rec["seed"] == case["seed"] and np.array_equal(np.array(rec["cf"]), case["cf"])
+        got = run_sampler(clouds, rand, case, reference=False)
+        for w, g in zip(rec["out"], got):
+            assert np.array_equal(np.array([float.fromhex(h) for h in w]), g), case["seed"]
+    assert clouds.finalize_clouds_lib() == 0
