@@ -214,6 +214,58 @@ def reference_abi_rate(wl, ncol=3):
     return out
 
 
+def parity_physical_list(device, fast, lw_grid, sw_grid):
+    """A flux check that discriminates (task 2): SURVEY §8(d)'s line list makes a nearly black atmosphere whose
+    fluxes barely depend on tau, so one more column is compared -- the same grids, atmosphere and line counts with the
+    physically scaled strengths (synthetic.PHYSICAL_BANDS: outgoing longwave ~270 W m-2, 0.68 of the incoming shortwave
+    reaches the surface) -- production form on the GPU against the reference's own C, twelve integrated fluxes [W m-2]."""
+    from oracle import reference_column as RC
+    from oracle.reference_column import tau_metrics
+    from grtcode_amd import api, synthetic as syn, workload as W
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from scenario import MOLTAB, mol_mass
+    kind, chk, orc = RC.checker(omp=True)
+    if kind != "reference":
+        return None                     # (the scalar restatement would need minutes for a full-size column)
+    RC.set_omp_threads(min(os.cpu_count() or 1, 16))
+    wl = W.G1Workload(device, 1, physical=True, fast=fast, lw_grid=lw_grid, sw_grid=sw_grid, spectral=True)
+    col = syn.profile(0, W.NUM_LEVELS)
+    lib = api.load_library()
+    ref = {}
+    for band, grid, lines, sw in (("lw", lw_grid, wl.lw_lines, False), ("sw", sw_grid, wl.sw_lines, True)):
+        ref[band] = RC.band_column(kind, chk, orc, lib.Q, col, grid, lines, syn.tables(sw=sw), W.MOL_ORDER, MOLTAB,
+                                   mol_mass, W.CIA_PAIRS, sw)
+    want = np.concatenate([ref["lw"]["integ"], ref["sw"]["integ"]])
+    # (the reference's one defect is not reproduced: a range check tripping inside sw_flux makes sw_fluxes_kernel store the
+    # PREVIOUS wavenumber's fluxes, shortwave.c:318-320,:443 -- such points take the value under test in its integrals;
+    # tests/test_gpu_parity_production.py does the same)
+    (gcols, keep), _ = wl.columns(0, 1)
+    wl.pipe.run(gcols)
+    got = wl.pipe.fluxes(1)[0]
+    L, V = W.NUM_LEVELS - 1, W.NUM_LEVELS
+    r = ref["sw"]
+    stale = np.zeros(r["nw"], dtype=bool)
+    stale[1:] = np.all(r["up"][:, 1:] == r["up"][:, :-1], axis=0) & np.all(r["dn"][:, 1:] == r["dn"][:, :-1], axis=0)
+    if stale.any():
+        v = wl.pipe.views(1)
+        up = api.device_to_host(device, v["flux_up"], (V, r["nw"]))
+        dn = api.device_to_host(device, v["flux_down"], (V, r["nw"]))
+        rows = [np.where(stale, mine, theirs) for mine, theirs in ((up[0], r["up"][0]), (up[-1], r["up"][-1]), (dn[0], r["dn"][0]), (dn[-1], r["dn"][-1]))]
+        want = want.copy()
+        want[[6, 7, 9, 10]] = [orc.integrate_row(np.ascontiguousarray(x), sw_grid[2]) for x in rows]
+    out = {"what": "column 0, physically scaled line list (same grids, atmosphere and line counts), production form vs the reference's own C",
+           "reference_fluxes_w_m2": {"rlut": float(want[0]), "rlds": float(want[4]), "rsdt": float(want[9]), "rsds": float(want[10])},
+           "rsds_over_rsdt": float(want[10]/want[9]),
+           "max_abs_flux_diff_w_m2": float(np.abs(got - want).max()), "tolerance_w_m2": 1e-3,
+           "reference_stale_sw_points": int(stale.sum())}
+    for bi, band in enumerate(("lw", "sw")):
+        tau = api.device_to_host(device, wl.pipe.views(bi)["tau_gas"], (L, ref[band]["nw"]))
+        out["tau_" + band] = tau_metrics(tau, ref[band]["tau_gas"])
+    out["ok"] = bool(out["max_abs_flux_diff_w_m2"] <= out["tolerance_w_m2"])
+    wl.destroy()
+    return out
+
+
 def parity_of_column0(wl, fluxes, bands, kind):
     """The GPU's column 0 of the last timed step against the CPU checker's column 0 (same inputs): the twelve
     integrated fluxes [W m-2] and the spectral gas optical depths of both bands."""
@@ -683,6 +735,10 @@ def main():
                                                            args.sw_lines or W.SW_LINES)
             full = all(v["thin"] == 1 for v in line["cpu_baseline"]["detail"].values())
             line["parity"] = parity_of_column0(wl, fluxes, ref_bands, line["cpu_baseline"]["kind"]) if full else None
+            if line["parity"] is not None and (lw_grid[2], sw_grid[2]) == (1.0, 1.0) and args.lw_lines is None and args.sw_lines is None:
+                line["parity"]["physical_list"] = parity_physical_list(device, args.fast, lw_grid, sw_grid)
+                if line["parity"]["physical_list"] is not None:
+                    line["parity"]["ok"] = bool(line["parity"]["ok"] and line["parity"]["physical_list"]["ok"])
             if line["parity"] is not None and not line["parity"]["ok"]:
                 sys.stderr.write("bench.py: PARITY FAILURE, no result line: " + json.dumps(line["parity"]) + "\n")
                 for w in wls:

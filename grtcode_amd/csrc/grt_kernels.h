@@ -37,7 +37,22 @@ typedef struct GrtLineStore
     double nmax;            /* max |nexp| over the store and, per molecule slot, the largest yair / yself */
     float yair_max[GRT_MAX_SLOTS];   /* [cm-1 atm-1]: together a bound on the Lorentz half-width of any */
     float yself_max[GRT_MAX_SLOTS];  /* line in a layer (kernels.c:105-106), see k_gas_optics_mp.hip */
+    /* Packed fp32 records of the same lines, in the same order, for the lean first pass of the two-pass moment kernel
+       (k_gas_optics_mp.hip: lean_block) -- built for ONE grid (lean_w0, lean_wres); NULL: none.
+         lean_a [n][4]: d0 = offset of the UNSHIFTED centre from its nearest grid point, in grid steps, [-0.5, 0.5);
+                        c0 = that grid point's index floor((v0 - w0)/wres + 0.5) (int32 bit pattern);
+                        v0 as f32;  s0 * 2^GRT_LEAN_S0_SHIFT as f32
+         lean_b [n][4]: yair, yself, en, delta
+         lean_c [n]   : bits 0-7   index of the temperature exponent, nexp*100 (255: not a whole number of hundredths below 128),
+                        bits 8-13  molecule slot,  bits 14-23  slot*GRT_MAX_ISO + iso - 1,
+                        bit 31     the line always takes the general path (strength outside the scaled fp32 range, ...) */
+    float const *lean_a;
+    float const *lean_b;
+    uint32_t const *lean_c;
+    double lean_w0, lean_wres;
 } GrtLineStore;
+#define GRT_LEAN_S0_SHIFT 96
+#define GRT_LEAN_GENERAL 0x80000000u
 
 /* Per-column layer state prepared on the host in the reference's arithmetic
    (curtis_godson.c:25-106, kernels.c:52-66,117-127) and uploaded once per column.
@@ -106,6 +121,9 @@ typedef struct GrtGasOpticsArgs
                                  instead of the ring (GRT_DIRECT_NEAR=0 in the environment switches it off) */
     int tile_phase, tile_nphase;   /* set by the launcher: this launch takes cell tiles t with t % tile_nphase == tile_phase
                                  (tile_nphase <= 1: all of them) */
+    int lean;                 /* set by the launcher (two-pass form, single-level gather, lines.lean_a built for this grid): the
+                                 first pass takes the lean fp32 form of the line loop wherever a workgroup's near fields are
+                                 seven points wide (GRT_LEAN=0 in the environment switches it off: comparison runs) */
 } GrtGasOpticsArgs;
 
 int grt_launch_gas_optics(void *stream, GrtGasOpticsArgs const *a);

@@ -53,11 +53,14 @@ constexpr int kRcap = 12;       // widest near field taken for the sake of regio
 constexpr int kPowTable = 128;  // tabulated temperature exponents n = k/100 (kernels.c:105)
 constexpr int kCellLoop = 3;    // passes of the in-register moment reduction before falling back to per-lane adds
 
+// (old = 0 with bound_ctrl: every control used here -- rotations, mirrors, quad permutations -- has a source lane for every
+// lane, so the value is the same as with old = v, and in this form the compiler folds the move into the instruction that
+// uses it: one v_add_f32_dpp instead of v_mov_b32_dpp + v_add_f32)
 template <int CTRL>
 __device__ __forceinline__ float dpp_f(float v)
 {
     int const b = __float_as_int(v);
-    return __int_as_float(__builtin_amdgcn_update_dpp(b, b, CTRL, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, b, CTRL, 0xf, 0xf, true));
 }
 
 // row_ror:1 (DPP control 0x121): rotation by one lane inside each row of 16 lanes
@@ -72,7 +75,7 @@ __device__ __forceinline__ double row_pass(double v)
 template <int CTRL>
 __device__ __forceinline__ int dpp_i(int v)
 {
-    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
 }
 
 // Wave-wide integer max as a scalar: rotations inside the rows of 16 lanes (every lane of a row
@@ -154,6 +157,54 @@ __device__ __forceinline__ float row_sum_transposed_pair(float const (&m)[8], bo
     float const send = b0 ? y[0] : y[1];
     return keep + dpp_f<0xB1>(send);                    // quad_perm:[1,0,3,2]: lane ^ 1, other b0
 }
+
+// The same for two groups whose contributions every lane holds in two arrays (the lean line loop: a lane's lines of the
+// row's first cell in g0, of the next cell in g1).  On return lane l of the row holds, for group b3, the row's sum of
+// value l & 7.
+__device__ __forceinline__ float row_sum_two_groups(float const (&g0)[8], float const (&g1)[8], bool b3, bool b2, bool b1, bool b0)
+{
+    float w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+    {
+        float const keep = b3 ? g1[i] : g0[i];
+        float const send = b3 ? g0[i] : g1[i];
+        w[i] = keep + dpp_f<0x140>(send);               // row_mirror: the partner is in the other half
+    }
+    float x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+    {
+        float const keep = b2 ? w[i + 4] : w[i];
+        float const send = b2 ? w[i] : w[i + 4];
+        x[i] = keep + dpp_f<0x141>(send);               // row_half_mirror
+    }
+    float y[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+    {
+        float const keep = b1 ? x[i + 2] : x[i];
+        float const send = b1 ? x[i] : x[i + 2];
+        y[i] = keep + dpp_f<0x1B>(send);                // quad_perm:[3,2,1,0]
+    }
+    float const keep = b0 ? y[1] : y[0];
+    float const send = b0 ? y[0] : y[1];
+    return keep + dpp_f<0xB1>(send);                    // quad_perm:[1,0,3,2]
+}
+
+// The lean line loop's near-centre points wait here until a wave has 64 of them (line, strength S(T) N_s, accumulator index)
+// ... and the blocks with lines the lean loop hands over to the general one are listed here (block start, lanes per p)
+constexpr int kRawCap = 128;
+constexpr int kLeanListCap = 12;
+constexpr int kLeanMaxP = 4;
+struct LeanRaw
+{
+    unsigned long long xl_mask[kWaves][kLeanListCap][kLeanMaxP];
+    unsigned j[kWaves][kRawCap];
+    float amp[kWaves][kRawCap];
+    unsigned xl_base[kWaves][kLeanListCap];
+    unsigned short idx[kWaves][kRawCap];
+};
 
 // Near-centre points (Humlicek regions 1-4 inside XLIM1) wait in per-wave LDS queues, one queue per
 // class of formula (voigt_class), so that a batch of 64 points runs ONE formula with all lanes busy:
@@ -338,6 +389,9 @@ __device__ __forceinline__ void shift_pair(float const (&lo)[K], float const (&h
 template <int CLASS, int ONLY, typename Queue>
 __device__ __forceinline__ void drain_class(double *acc, Queue const *q, int wave, int first, int count, int lane)
 {
+#ifdef GRT_ABL_NOEVAL
+    if (count >= 0) return;         // (timing experiments only: scripts/lean_ablation.sh)
+#endif
     for (int i = first + lane; i < first + count; i += 64)
     {
         float const xi = q->xi[CLASS][wave][i], y = q->y[CLASS][wave][i];
@@ -364,7 +418,7 @@ __device__ __forceinline__ void drain_class(double *acc, Queue const *q, int wav
 // PROBE: the instrumented instance (GrtGasOpticsArgs.probe): per-workgroup clocks and event counts, for the cost
 // analysis of scripts/line_cost_by_wavenumber.py; the production instances carry none of it.
 constexpr int kProbeWords = 24;
-template <bool TWO_PASS, bool TREE, int K, bool LEAN = false, bool PROBE = false>
+template <bool TWO_PASS, bool TREE, int K, bool LEAN = false, bool PROBE = false, int LEANP = 0>
 __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long long fsteps_ll, unsigned ngroups,
                                                unsigned perm_stride, int ncell, int nacc, int halo)
 {
@@ -386,7 +440,9 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
 
     int const tid = threadIdx.x;
     int const lane = tid & 63;
-    int const wave = tid >> 6;
+    // (the same in every lane of a wave, and said so: line indices, queue positions and the addresses built on them then
+    // live in scalar registers)
+    int const wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     WorkItem const wi = decode_work(a, ngroups, perm_stride);
     int const col = wi.col, layer = wi.layer, tile_idx = wi.tile_idx, slice = wi.slice;
     if (TWO_PASS && a.tile_nphase > 1 && tile_idx % a.tile_nphase != a.tile_phase)
@@ -585,14 +641,51 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         }
     };
 
+    // A near-centre point per lane (cls: its class of formula, -1: none) goes to its class's queue; full batches of 64
+    // are evaluated off the top, and a queue that cannot take this push is emptied first.
+    auto queue_push = [&](int const cls, float const amp_q, float const xr, float const y_q, unsigned short const idx_q)
+    {
+#pragma unroll
+        for (int q = 0; q < Queue::classes; ++q)
+        {
+            unsigned long long const mk = __ballot(cls == q);
+            if (mk == 0ull)
+            {
+                continue;
+            }
+            int const npush = __popcll(mk);
+            if constexpr (PROBE) pc_near += (unsigned)npush;
+            if (qcount[q] + npush > Queue::capacity)
+            {
+                drain(q, 0, qcount[q]);
+                qcount[q] = 0;
+            }
+            if (cls == q)
+            {
+                int const pos = qcount[q] + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32),
+                                __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                nq->amp[q][wave][pos] = amp_q;
+                nq->xi[q][wave][pos] = xr;
+                nq->y[q][wave][pos] = y_q;
+                nq->idx[q][wave][pos] = idx_q;
+            }
+            qcount[q] += npush;
+            if (qcount[q] >= 64)
+            {
+                qcount[q] -= 64;
+                drain(q, qcount[q], 64);        // a full batch off the top
+            }
+        }
+    };
+
     if constexpr (PROBE) pt_last = __builtin_readcyclecounter();
-    for (uint64_t base = line_walk_first(a, jbeg, jend, wave); base < jend; base += line_walk_stride(a))
+    // One block of the general line loop: lane = line j (have: there is such a line).  Lanes without a line prepare the
+    // last line again and are masked at the end: straight line code for the whole wave instead of nested divergent regions.
+    auto general_block = [&](uint64_t const j, bool const have)
     {
         phase_mark(5);
         // Lanes past the end of the range prepare the last line again and are masked at the end: straight
         // line code for the whole wave instead of nested divergent regions.
-        uint64_t const j = base + lane;
-        bool const have = j < jend;
         RawLine const ln = load_line(a.lines, have ? j : jend - 1);
         // kernels.c:34-131 for this (layer, line) in the fused form's arithmetic: shifted centre, centre
         // index and Doppler width in fp64 exactly as the reference-order kernels (prepare_line); S(T) in
@@ -614,7 +707,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         valid = TWO_PASS ? valid & (c >= F0) & (c < F1) : valid & (s < F1) & (e_i >= F0);
         if (__ballot(valid) == 0ull)
         {
-            continue;
+            return;
         }
         if constexpr (PROBE) ++pc_blocks;
         // the line's window, clipped to what the accumulator spans (two-pass form: the tile and `halo` points
@@ -854,41 +947,12 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                     double const dwno = (double)s*a.wres + a.w0;                       // kernels.c:438
                     float const xr = voigt_x(dwno, f - s, a.wres, wnoadj, repwid);     // the reference's x
                     int const cls = near ? voigt_class<true, kSplit>(xr, y) : -1;
-#pragma unroll
-                    for (int q = 0; q < Queue::classes; ++q)
-                    {
-                        unsigned long long const mk = __ballot(cls == q);
-                        if (mk == 0ull)
-                        {
-                            continue;
-                        }
-                        int const npush = __popcll(mk);
-                        if constexpr (PROBE) pc_near += (unsigned)npush;
-                        if (qcount[q] + npush > Queue::capacity)
-                        {
-                            drain(q, 0, qcount[q]);
-                            qcount[q] = 0;
-                        }
-                        if (cls == q)
-                        {
-                            int const pos = qcount[q] + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32),
-                                            __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-                            nq->amp[q][wave][pos] = (float)(amp*(double)(kRsqrpi*repwid));
-                            nq->xi[q][wave][pos] = xr;
-                            nq->y[q][wave][pos] = y;
-                            // inside the near field the point is the queue's alone (the ring skips it: at a grid
-                            // point on a narrow line's centre the Lorentzian is hundreds of times the true value,
-                            // nothing to put through fp32 partial sums); beyond it the moments supply the
-                            // Lorentzian there (to ~1e-8), to be taken back when the entry is evaluated (top bit)
-                            nq->idx[q][wave][pos] = (unsigned short)((f - A0) | ((f >= near_lo) & (f <= near_hi) ? 0 : 0x8000));
-                        }
-                        qcount[q] += npush;
-                        if (qcount[q] >= 64)
-                        {
-                            qcount[q] -= 64;
-                            drain(q, qcount[q], 64);        // a full batch off the top
-                        }
-                    }
+                    // inside the near field the point is the queue's alone (the ring skips it: at a grid
+                    // point on a narrow line's centre the Lorentzian is hundreds of times the true value,
+                    // nothing to put through fp32 partial sums); beyond it the moments supply the
+                    // Lorentzian there (to ~1e-8), to be taken back when the entry is evaluated (top bit)
+                    queue_push(cls, (float)(amp*(double)(kRsqrpi*repwid)), xr, y,
+                               (unsigned short)((f - A0) | ((f >= near_lo) & (f <= near_hi) ? 0 : 0x8000)));
                 }
             }
         }
@@ -937,7 +1001,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                 // goes to the fp64 accumulators, as a ring token does.
                 if (__ballot(lo_n <= hi_n) == 0ull)
                 {
-                    continue;
+                    return;
                 }
                 float const amp_f32 = (float)amp;
                 bool lean = false;
@@ -1028,7 +1092,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                         }
                     }
                 }
-                continue;
+                return;
             }
         }
         // Each row of 16 lanes is a ring of its own, so each row covers the span of ITS lines (sorted lines:
@@ -1044,7 +1108,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                              max(__builtin_amdgcn_readlane(len, 32), __builtin_amdgcn_readlane(len, 48)));
         if (span == 0)
         {
-            continue;
+            return;
         }
         float const amp_f32 = (float)amp;
         // LEAN: where (1 - |delta|) wr >= XLIM0 for every line of the wave, region 1 and the near-centre points end within
@@ -1175,6 +1239,670 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
             }
         }
         phase_mark(4);
+    };
+    // ---------------------------------------------------------------------------------------------------------
+    // The LEAN form of the line loop (LEANP > 0: that many lines per lane; first pass of the two-pass form with the
+    // single-level gather).  Round 4's measurements (scripts/valu_mix*.hip, profiles/r4_*): the general loop above is not
+    // waiting on latencies, it fills the vector pipe -- with instructions that run at half rate on this chip (everything
+    // fp64, every conversion, compare, select, DPP move, min/max/floor; 4.5 cycles per wave against 2.4 for an fp32
+    // fma/mul/add) or at a quarter (rcp, exp, sqrt: 9.5), plus a scalar instruction stream that costs issue slots of its own.
+    // So this form does the per-line work in fp32 from packed records (GrtLineStore.lean_*), keeps compares and selects
+    // out of the per-point code, reduces TWO lines per lane with one pass of DPP exchanges, and leaves to the general
+    // code only what needs its fp64:
+    //   * centre index (kernels.c:431-432, bit-exact): nearest grid point and offset of the unshifted centre come with
+    //     the record; the pressure shift (kernels.c:44) is added to the offset in fp32, and a line whose sum comes within
+    //     1e-5 of the halfway mark goes through general_block, which forms the reference's fp64 expression;
+    //   * strength S(T) N (kernels.c:83-85, :459): exponent of e^(c2 E/T) split off exactly (two-float product), strength and
+    //     1/Q N as mantissa/exponent pairs -- relative error ~2e-7, the class of the fp32 line shape it multiplies;
+    //   * the Lorentzian of every point that sees one, A/((r - delta)^2 + eta^2), needs no Doppler width at all;
+    //   * near-centre points (|x| < XLIM1: Humlicek regions 2-4) need the reference's fp64 x and its y bit for bit (see
+    //     the file header): they wait in a raw per-wave queue (line, strength, grid point) and are prepared exactly, 64
+    //     at a time with all lanes busy, then sorted into the class queues as before;
+    //   * anything unusual (no Lorentz width, exponent not tabulated, strength outside the scaled range) is flagged and goes
+    //     through general_block whole.
+    // A workgroup takes this form if its near fields are seven points wide (R = 3: every (tile, layer) of the 1 cm-1 grids
+    // but absurd pressures') and its tile lies inside the grid (no window is clipped); otherwise every block of lines goes
+    // through general_block as before.
+    // ---------------------------------------------------------------------------------------------------------
+    constexpr int kLinesPerLane = LEANP > 0 ? LEANP : 1;
+    uint64_t const walk_first = a.deterministic ? (wave == 0 ? jbeg : jend) : jbeg + (uint64_t)wave*64*kLinesPerLane;
+    unsigned const walk_stride = (a.deterministic ? 64u : (unsigned)kBlock)*kLinesPerLane;
+    [[maybe_unused]] bool lean_ok = false;
+    [[maybe_unused]] float4 *msf = nullptr;
+    [[maybe_unused]] float2 *qnf = nullptr;
+    [[maybe_unused]] float *ptabf = nullptr;
+    [[maybe_unused]] LeanRaw *raw = nullptr;
+    [[maybe_unused]] int rawcount = 0;              // wave-uniform: entries waiting in the raw queue
+    [[maybe_unused]] int xcount = 0;                // wave-uniform: blocks with lines handed over to general_block
+    // (uniform per workgroup, but kept in VECTOR registers: an fp32 multiply or fma with a scalar operand runs at half rate)
+    [[maybe_unused]] float kh = 0.f, kl = 0.f, c2t = 0.f, pw = 0.f, pavg_f = 0.f, a_norm = 0.f, wres_v = 0.f, inv_wres_v = 0.f;
+    [[maybe_unused]] bool stim_tile = false, farir_tile = false, corrected_s = false;
+    auto uniform_flag = [](bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; };
+    if constexpr (LEANP > 0)
+    {
+        size_t const lean_off = ((size_t)(reinterpret_cast<unsigned char *>(invr + 1) - smem) + 15) & ~(size_t)15;
+        msf = reinterpret_cast<float4 *>(smem + lean_off);                        // [num_slots]: ps, p - ps, sqrt(ln 2) x doppler factor
+        qnf = reinterpret_cast<float2 *>(msf + a.lay.num_slots);                  // [num_slots][GRT_MAX_ISO]: N_s/Q as mantissa, exponent
+        ptabf = reinterpret_cast<float *>(qnf + (size_t)a.lay.num_slots*GRT_MAX_ISO);   // [kPowTable]
+        raw = reinterpret_cast<LeanRaw *>(ptabf + kPowTable);
+        lean_ok = uniform_flag(a.lean != 0 && use_moments && R == 3 && F0 >= 8 && F1 + 8 <= nw_i && fsteps >= 8 && halo >= 8
+                               && a.lines.lean_a != nullptr);
+        if (lean_ok)
+        {
+            for (int i = tid; i < a.lay.num_slots; i += kBlock)
+            {
+                // (third entry: alpha of kernels.c:127 over the line centre, divided by RFM_voigt.c:94's sqrt(ln 2) -- 1/REPWID per cm-1)
+                msf[i] = make_float4((float)ms_l[4*i], (float)ms_l[4*i + 1], (float)(((double)0.83255461115f/(double)kSqrln2)*ms_l[4*i + 3]), 0.f);
+            }
+            for (int i = tid; i < a.lay.num_slots*GRT_MAX_ISO; i += kBlock)
+            {
+                double const v = q_l[i]*ms_l[(i/GRT_MAX_ISO)*4 + 2];                 // N_s/Q(T): kernels.c:85, :459
+                int e = 0;
+                double const m = frexp(v, &e);                                      // v = m 2^e, 1/2 <= m < 1
+                qnf[i] = (v > 0. && v < 1e300) ? make_float2((float)(2.*m), (float)(e - 1 - GRT_LEAN_S0_SHIFT)) : make_float2(0.f, 0.f);
+            }
+            for (int i = tid; i < kPowTable; i += kBlock)
+            {
+                ptabf[i] = (float)ptab[i];
+            }
+            __syncthreads();
+            double const kTd = ((double)(-1.4387686f)*1.4426950408889634)*lay[2];  // c2 log2(e)/T (kernels.c:75)
+            kh = (float)kTd;
+            kl = (float)(kTd - (double)kh);
+            c2t = (float)((double)(-1.4387686f)*lay[2]);
+            pw = (float)(lay[0]*inv_wres);
+            pavg_f = (float)lay[0];
+            a_norm = (float)(1./(3.14159265358979323846*a.wres));
+            wres_v = wres_f;
+            inv_wres_v = inv_wres_f;
+            asm volatile("" : "+v"(kh), "+v"(kl), "+v"(c2t), "+v"(pw), "+v"(pavg_f), "+v"(a_norm), "+v"(wres_v), "+v"(inv_wres_v));
+            // stimulated emission 1 - exp(c2 v0/T) (kernels.c:84): 1 to fp32 and beyond below exp(-20); the tile's lowest
+            // wavenumber decides for the whole workgroup (sorted store, shifts of a fraction of a grid step)
+            double const x2_tile = ((double)(-1.4387686f)*lay[2])*(a.w0 + ((double)F0 - 2.)*a.wres - 1.);
+            stim_tile = uniform_flag(x2_tile > -21.);
+            farir_tile = uniform_flag(x2_tile > -1.1);
+            corrected_s = uniform_flag(corrected);
+        }
+    }
+
+    // The raw queue's entries, prepared exactly (general_block's fp64 expressions) and sorted into the class queues.
+    [[maybe_unused]] auto drain_raw = [&](int const first, int const count)
+    {
+        if constexpr (LEANP > 0)
+        {
+            bool const on = lane < count;
+            int const i = first + (on ? lane : 0);
+            uint64_t const j = raw->j[wave][i];
+            float const ampl = raw->amp[wave][i];
+            int const idx = raw->idx[wave][i];                                         // f - A0
+            RawLine const ln = load_line(a.lines, j);
+            double const *ms = ms_l + ln.slot*4;
+            double const wnoadj = ln.v0 + (double)ln.delta*lay[0];                     // kernels.c:44
+            double const dv = wnoadj - a.w0;
+            double u = (2*(dv*inv_wres) + 1)/2;                                        // kernels.c:431-432 (see general_block)
+            if (fabs(u - rint(u)) <= 4e-15*fmax(1., fabs(u)))
+            {
+                u = (2*(dv/a.wres) + 1)/2;
+            }
+            int const c = (int)floor(u);
+            int const s = c - fsteps < 0 ? 0 : c - fsteps;                             // kernels.c:435
+            float const nk = rintf(ln.nexp*100.f);                                     // (lean lines have tabulated exponents)
+            double const tpow = ptab[(nk >= 0.f) & (nk < (float)kPowTable) ? (int)nk : 0];
+            double const gamma = tpow*((double)ln.yair*ms[1] + (double)ln.yself*ms[0]);     // kernels.c:105-106
+            double const alpha = ((double)0.83255461115f*wnoadj)*ms[3];                // kernels.c:127
+            double const r0 = (double)__builtin_amdgcn_rcpf((float)alpha);
+            float const repwid = (float)((double)kSqrln2*(r0*fma(-alpha, r0, 2.0)));   // RFM_voigt.c:94
+            float const y = (float)((double)repwid*gamma);                             // RFM_voigt.c:95
+            double const dwno = (double)s*a.wres + a.w0;                               // kernels.c:438
+            float const xr = voigt_x(dwno, idx + A0 - s, a.wres, wnoadj, repwid);      // the reference's x
+            int const cls = on ? voigt_class<true, kSplit>(xr, y) : -1;
+            queue_push(cls, (float)((double)ampl*(double)(kRsqrpi*repwid)), xr, y, (unsigned short)idx);
+        }
+    };
+
+    // The packed records of line LEANP lane + p of the block at b (past the end of the workgroup's range: its last line) --
+    // requested one line ahead of their use.
+    [[maybe_unused]] float4 next_ra = make_float4(0.f, 0.f, 0.f, 0.f), next_rb = make_float4(0.f, 0.f, 0.f, 0.f);
+    [[maybe_unused]] unsigned next_rc = 0u;
+    [[maybe_unused]] auto lean_fetch = [&](uint64_t b, int const p)
+    {
+        if constexpr (LEANP > 0)
+        {
+            int rem_b = 1;
+            if (b < jend)
+            {
+                rem_b = jend - b < (uint64_t)(64*LEANP) ? (int)(jend - b) : 64*LEANP;
+            }
+            else
+            {
+                b = jend - 1;
+            }
+            int const li = LEANP*lane + p;
+            unsigned const off = (unsigned)(li < rem_b ? li : rem_b - 1);
+            // (byte offsets in 32 bits: scalar base + vector offset addressing instead of 64-bit vector address arithmetic)
+            float4 const *pa = reinterpret_cast<float4 const *>(a.lines.lean_a) + b;
+            float4 const *pb = reinterpret_cast<float4 const *>(a.lines.lean_b) + b;
+            unsigned const *pc = a.lines.lean_c + b;
+            next_ra = *reinterpret_cast<float4 const *>(reinterpret_cast<char const *>(pa) + (off << 4));
+            next_rb = *reinterpret_cast<float4 const *>(reinterpret_cast<char const *>(pb) + (off << 4));
+            next_rc = *reinterpret_cast<unsigned const *>(reinterpret_cast<char const *>(pc) + (off << 2));
+        }
+    };
+
+    // One lean block: lane l takes lines base + LEANP l + p, p = 0 .. LEANP - 1.  Lines that have to go through
+    // general_block instead are recorded, block by block, in the wave's list (raw->xl_*).
+    [[maybe_unused]] auto lean_block = [&](uint64_t const base)
+    {
+        if constexpr (LEANP > 0)
+        {
+            int const rem = jend - base < (uint64_t)(64*LEANP) ? (int)(jend - base) : 64*LEANP;     // lines of this block
+            float m0[kMom], m1[kMom], nvs[8];
+#pragma unroll
+            for (int k = 0; k < kMom; ++k)
+            {
+                m0[k] = 0.f; m1[k] = 0.f; nvs[k] = 0.f;
+            }
+            int cr = 0;                         // the row's reference cell: its lines sit in cells cr, cr + 1 (sorted store)
+            bool one_cell = true;               // (wave-uniform) so far every line of every row sat in its row's first cell
+            unsigned long long any_valid = 0ull;
+            unsigned long long handed[LEANP] = {};
+#ifdef GRT_LEAN_UNROLL
+#pragma unroll
+#else
+#pragma nounroll
+#endif
+            for (int p = 0; p < LEANP; ++p)
+            {
+                int const li = LEANP*lane + p;
+                bool const have = li < rem;
+                unsigned const off = (unsigned)(have ? li : rem - 1);
+                // this line's records were asked for one line ago (the loop waits for nothing it has just requested); now the next
+                // line's: the next p of this block, or the first of the wave's next block
+                float4 const ra = next_ra, rb = next_rb;
+                unsigned const rc = next_rc;
+                if (p + 1 < LEANP)
+                {
+                    lean_fetch(base, p + 1);
+                }
+                else
+                {
+                    lean_fetch(base + walk_stride, 0);
+                }
+                // ---- centre index and offset (kernels.c:44, :431-432) ----
+                float const u = fmaf(rb.w, pw, ra.x);
+                float const t = u + 0.5f;
+                float const kf = floorf(t);
+                float const dl = u - kf;                            // offset of the shifted centre from grid point c, [-1/2, 1/2)
+                int const c = __float_as_int(ra.y) + (int)kf;
+                bool const guard = fabsf((t - kf) - 0.5f) > 0.49999f;
+                bool const in_tile = (unsigned)(c - F0) < (unsigned)(F1 - F0);
+                float const wn = fmaf(rb.w, pavg_f, ra.z);          // shifted centre [cm-1]
+                // ---- S(T) N_s (kernels.c:83-85, :459) ----
+                float const en = rb.z;
+                float const nz = rintf(en*kh);
+                float const rz = fmaf(en, kl, fmaf(en, kh, -nz));   // en c2 log2(e)/T - nz, to ~1e-8
+                float2 const qe = qnf[(rc >> 14) & 1023u];
+                float amp = (ra.w*qe.x)*__builtin_amdgcn_exp2f(rz);
+                amp = ldexpf(amp, (int)(qe.y + nz));
+                if (stim_tile)
+                {
+                    // (kernels.c:84 with the UNSHIFTED centre: launch.c:119 hands calc_line_strengths the line list's v0)
+                    float const v0f = ra.z;
+                    float const n2 = rintf(v0f*kh);
+                    float const r2 = fmaf(v0f, kl, fmaf(v0f, kh, -n2));
+                    float stim = 1.f - ldexpf(__builtin_amdgcn_exp2f(r2), (int)n2);
+                    if (farir_tile)
+                    {
+                        // nu < ~0.7 T: 1 - e^x cancels; -expm1(x) by its series on [-1, 0] (eleven terms: 2e-9)
+                        float const x2 = v0f*c2t;
+                        float ps = 2.50521084e-08f;                                 // 1/11!
+                        ps = fmaf(ps, x2, 2.75573192e-07f);
+                        ps = fmaf(ps, x2, 2.75573192e-06f);
+                        ps = fmaf(ps, x2, 2.48015873e-05f);
+                        ps = fmaf(ps, x2, 1.98412698e-04f);
+                        ps = fmaf(ps, x2, 1.38888889e-03f);
+                        ps = fmaf(ps, x2, 8.33333333e-03f);
+                        ps = fmaf(ps, x2, 4.16666667e-02f);
+                        ps = fmaf(ps, x2, 1.66666667e-01f);
+                        ps = fmaf(ps, x2, 0.5f);
+                        ps = fmaf(ps, x2, 1.0f);
+                        stim = x2 > -1.f ? -x2*ps : stim;
+                    }
+                    amp *= stim;
+                }
+                // ---- widths (kernels.c:105-106, :127; RFM_voigt.c:94-95) ----
+                float4 const mf = msf[(rc >> 8) & 63u];
+                float const gam = ptabf[rc & 127u]*fmaf(rb.x, mf.y, rb.y*mf.x);
+                float const ad = wn*mf.z;                                           // alpha/sqrt(ln 2) (kernels.c:127, RFM_voigt.c:94)
+                float const r0 = __builtin_amdgcn_rcpf(ad);
+                float const rep = fmaf(fmaf(-ad, r0, 1.f), r0, r0);                 // REPWID (one Newton step: the far wings scale with it)
+                float y = rep*gam;
+                // (flagged by the loader: strength zeroed; RFM_voigt.c:122-126: no Lorentz width -- all of that is general_block's)
+                bool const exc = !(ra.w > 0.f) | guard | !(y > 0.000001f);
+                bool const valid = have & in_tile & !exc;
+                {
+                    unsigned long long const hm = __ballot(have & exc);
+#pragma unroll
+                    for (int q = 0; q < LEANP; ++q)
+                    {
+                        handed[q] = p == q ? hm : handed[q];
+                    }
+                }
+                any_valid |= __ballot(valid);
+                // a lane without a line of its own here works on a harmless one (no infinities: 0 x inf would poison the sums)
+                amp = valid ? amp : 0.f;
+                y = valid ? y : 1.f;
+                float const eta = valid ? gam*inv_wres_v : 1.f;
+                float const eta2 = eta*eta;
+                float const wr = wres_v*rep;
+                // ---- which cell of its row: cr or cr + 1; anything else (sparse lines) is added lane by lane ----
+                {
+                    int const c_first = dpp_i<0x150>(c);                            // row_newbcast:0 -- the row's first lane
+                    int const c_clamped = c_first < F0 ? F0 : (c_first > F1 - 1 ? F1 - 1 : c_first);
+                    cr = p == 0 ? c_clamped : cr;
+                }
+                int const o = c - cr;
+                float const w0f = (valid & (o == 0)) ? 1.f : 0.f;
+                float const w1f = (valid & (o == 1)) ? 1.f : 0.f;
+                bool const odd = valid & ((unsigned)o > 1u);
+                // (the longwave band's usual case, 308 lines per cell: no second cell, no weights)
+                bool const single = __ballot(valid & (o != 0)) == 0ull;
+                one_cell = one_cell & single;
+                // ---- moments of the Lorentzian about the cell centre (see general_block) ----
+                float const A = (amp*eta)*a_norm;                                   // K(r) = A/((r - dl)^2 + eta^2)
+                float m[kMom];
+#ifdef GRT_ABL_NOMOM
+                for (int k = 0; k < kMom; ++k) m[k] = 0.f;
+#else
+                {
+                    float uu = A, pk = 0.f;
+#pragma unroll
+                    for (int k = 0; k < kMom; ++k)
+                    {
+                        float const un = fmaf(dl, uu, -eta2*pk);
+                        pk = fmaf(dl, pk, uu);
+                        uu = un;
+                        m[k] = pk;
+                    }
+                }
+#endif
+                // Voigt constants (RFM_voigt.c:97-126, :177-179); a pure Lorentz line (y >= 70.55) has no region 1
+                float const yq = y*y;
+                float const x0q = y >= 70.55f ? 0.f : fmaf(y, fmaf(y, -3.6f, 40.0f), 15100.0f);   // XLIM0^2
+                float const xq_near = y >= 8.425f ? 0.f : 164.0f - y*fmaf(y, 1.8f, 4.3f);        // XLIM1^2
+                float const a0 = yq + 0.5f;
+                float const d0r = a0*a0;
+                float const d2r = (yq + yq) - 1.0f;
+                float const cl = (rep*y)*0.318309886f;
+                float const adl = fabsf(dl);
+                float const ndcr = -dl*wr;                          // x of the line's own grid point
+                bool pre2 = false;
+                if (corrected_s)
+                {
+                    // region 1 beyond the near field: folded into the moments, or (pre-pass 2 of general_block) point by point
+                    float const e4 = (4.f - adl)*wr;
+                    bool const reg1_far = valid & (e4*e4 < x0q);
+                    bool const fold = reg1_far & (adl*wr <= 0.5f*kFoldWrMax);
+                    pre2 = reg1_far & !fold;
+                    // (below ~15 000 cm-1 region 1 ends inside the near field: no line of the wave has anything to fold)
+                    if (__ballot(fold) != 0ull)
+                    {
+                    float const rwr = ad*inv_wres_v;                                // 1/wr
+                    float const rw2 = rwr*rwr;
+                    float const t4 = fold ? A*rw2 : 0.f;
+                    float const t6 = t4*rw2;
+                    float d4 = 1.5f*t4;
+                    float d6 = fmaf(-5.f, yq, 1.25f)*t6;
+                    float d8 = fmaf(yq, fmaf(10.5f, yq, -8.75f), 0.875f)*(t6*rw2);
+#pragma unroll
+                    for (int i = 2; i < kMom; ++i)
+                    {
+                        m[i] = fmaf((float)binomial(i + 1, 3), d4, m[i]);
+                        d4 *= dl;
+                        if (i >= 4)
+                        {
+                            m[i] = fmaf((float)binomial(i + 1, 5), d6, m[i]);
+                            d6 *= dl;
+                        }
+                        if (i >= 6)
+                        {
+                            m[i] = fmaf((float)binomial(i + 1, 7), d8, m[i]);
+                            d8 *= dl;
+                        }
+                    }
+                    }
+                }
+                if (single)
+                {
+#pragma unroll
+                    for (int k = 0; k < kMom; ++k)
+                    {
+                        m0[k] += m[k];          // (a lane without a valid line has A = 0: nothing)
+                    }
+                }
+                else
+                {
+#pragma unroll
+                    for (int k = 0; k < kMom; ++k)
+                    {
+                        m0[k] = fmaf(w0f, m[k], m0[k]);
+                        m1[k] = fmaf(w1f, m[k], m1[k]);
+                    }
+                }
+                // ---- near field: the line's seven points r = -3 .. 3 (v[r + 3]; x = r wr + ndcr, the general form's canonical
+                // x), by what the wave's lines have there: only Lorentzians but for a line's own point | region 1 throughout
+                // | the point's region picks the formula.  Near-centre points (|x| < XLIM1) are left out and noted in ncm. ----
+                float const e1 = (1.f - adl)*wr;                    // |x| of the second-nearest grid point
+                float const e35 = 3.5f*wr;
+                bool const lreg = __ballot(valid & !(e1*e1 >= 1.002f*x0q)) == 0ull;     // only a line's own point can be anything but Lorentzian
+                bool const nc_one = __ballot(valid & !(e1*e1 >= xq_near)) == 0ull;      // ... can be a near-centre point
+                float v[7];
+                unsigned ncm = 0u;
+#ifdef GRT_ABL_NOSLOTS
+                for (int k = 0; k < 7; ++k) v[k] = 0.f;
+                if (false)
+#else
+                if (lreg)
+#endif
+                {
+                    // every point but the line's own: the Lorentzian, A/(rel^2 + eta^2) (RFM_voigt.c:103,170,278)
+#pragma unroll
+                    for (int k = 0; k < 7; ++k)
+                    {
+                        if (k != 3)
+                        {
+                            float const rel = (float)(k - 3) - dl;
+                            v[k] = A*__builtin_amdgcn_rcpf(fmaf(rel, rel, eta2));
+                        }
+                    }
+                    // the line's own grid point: region 1, the Lorentzian, or a near-centre point (the queues')
+                    float const xq0 = ndcr*ndcr;
+                    bool const nc = xq0 < xq_near;
+                    bool const reg1 = xq0 < x0q;
+                    float const den = reg1 ? fmaf(xq0, d2r + xq0, d0r) : xq0 + yq;
+                    float const num = reg1 ? cl*(a0 + xq0) : cl;
+                    v[3] = nc ? 0.f : (amp*num)*__builtin_amdgcn_rcpf(den);
+                    ncm = (nc & valid) ? 8u : 0u;
+                }
+#ifndef GRT_ABL_NOSLOTS
+                else
+#else
+                else if (false)
+#endif
+                {
+                    float const acl = amp*cl;
+                    if (__ballot(valid & !(e35*e35 < x0q)) == 0ull)
+                    {
+                        // region 1 throughout: K = cl (A0 + XQ)/(D0 + XQ (D2 + XQ)) (RFM_voigt.c:172-183)
+#pragma unroll
+                        for (int k = 0; k < 7; ++k)
+                        {
+                            float const x = fmaf((float)(k - 3), wr, ndcr);
+                            float const xq = x*x;
+                            v[k] = (acl*(a0 + xq))*__builtin_amdgcn_rcpf(fmaf(xq, d2r + xq, d0r));
+                        }
+                    }
+                    else
+                    {
+                        // ... and the Lorentzian in the same form, cl (A0 + XQ)/((XQ + YQ)(XQ + A0)): the point's region picks (D0, D2)
+                        float const d0l = yq*a0, d2l = yq + a0;
+#pragma unroll
+                        for (int k = 0; k < 7; ++k)
+                        {
+                            float const x = fmaf((float)(k - 3), wr, ndcr);
+                            float const xq = x*x;
+                            bool const reg1 = xq < x0q;
+                            float const D2 = reg1 ? d2r : d2l;
+                            float const D0 = reg1 ? d0r : d0l;
+                            v[k] = (acl*(a0 + xq))*__builtin_amdgcn_rcpf(fmaf(xq, D2 + xq, D0));
+                        }
+                    }
+                    if (nc_one)
+                    {
+                        bool const nc = ndcr*ndcr < xq_near;
+                        v[3] = nc ? 0.f : v[3];
+                        ncm = (nc & valid) ? 8u : 0u;
+                    }
+                    else
+                    {
+#pragma unroll
+                        for (int k = 0; k < 7; ++k)
+                        {
+                            float const x = fmaf((float)(k - 3), wr, ndcr);
+                            bool const nc = x*x < xq_near;
+                            v[k] = nc ? 0.f : v[k];
+                            ncm |= (nc & valid) ? (1u << k) : 0u;
+                        }
+                    }
+                }
+                // into the row's eight slots (grid points cr - 3 .. cr + 4): a line of cell cr + o has its points in slots o .. 6 + o
+                if (single)
+                {
+#pragma unroll
+                    for (int sl = 0; sl < 7; ++sl)
+                    {
+                        nvs[sl] += v[sl];
+                    }
+                }
+                else
+                {
+#pragma unroll
+                    for (int sl = 0; sl < 8; ++sl)
+                    {
+                        if (sl <= 6) nvs[sl] = fmaf(w0f, v[sl], nvs[sl]);
+                        if (sl >= 1) nvs[sl] = fmaf(w1f, v[sl - 1], nvs[sl]);
+                    }
+                }
+                // ---- rare: a line in neither of its row's cells adds lane by lane; region-1 points beyond the near field of
+                // lines that are not folded (pre-pass 2 of general_block): such a line has |dl| wr > 12.5, so region 1
+                // (|x| < XLIM0 <= 123.4) ends within five grid steps ----
+                if (__ballot(odd | pre2) != 0ull)
+                {
+                    if (odd)
+                    {
+#pragma unroll
+                        for (int k = 0; k < kMom; ++k)
+                        {
+                            mom_add(k, c, m[k]);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 7; ++k)
+                        {
+                            if (v[k] != 0.f)
+                            {
+                                GRT_ACC_ADD(&acc[c - 3 + k - A0], (double)v[k]);
+                            }
+                        }
+                    }
+                    if (__ballot(pre2) != 0ull)
+                    {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                        {
+                            int const r = q == 0 ? -5 : (q == 1 ? -4 : (q == 2 ? 4 : 5));
+                            float const x = fmaf((float)r, wr, ndcr);
+                            float const xq = x*x;
+                            float const den = fmaf(xq, d2r + xq, d0r)*(xq + yq);
+                            float const corr = (amp*cl)*fmaf(1.5f, xq, -0.5f*a0)*__builtin_amdgcn_rcpf(den);
+                            if (pre2 & (xq < x0q))
+                            {
+                                GRT_ACC_ADD(&acc[c + r - A0], (double)corr);
+                            }
+                        }
+                    }
+                }
+#ifdef GRT_ABL_NORAW
+                ncm = 0u;
+#endif
+                // ---- near-centre points -> raw queue (line, strength, grid point); full batches are prepared exactly ----
+                while (__ballot(ncm != 0u) != 0ull)
+                {
+                    bool const push = ncm != 0u;
+                    int const k = push ? __builtin_ctz(ncm) : 0;
+                    ncm &= ncm - 1u;
+                    unsigned long long const mk = __ballot(push);
+                    if (push)
+                    {
+                        int const pos = rawcount + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                        raw->j[wave][pos] = (unsigned)(base + off);
+                        raw->amp[wave][pos] = amp;
+                        raw->idx[wave][pos] = (unsigned short)(c - 3 + k - A0);
+                    }
+                    rawcount += __popcll(mk);
+                    if (rawcount >= 64)
+                    {
+                        rawcount -= 64;
+                        drain_raw(rawcount, 64);
+                    }
+                }
+            }
+            {
+                unsigned long long any_handed = 0ull;
+#pragma unroll
+                for (int q = 0; q < LEANP; ++q)
+                {
+                    any_handed |= handed[q];
+                }
+                if (any_handed != 0ull)
+                {
+                    if (lane == 0)
+                    {
+                        raw->xl_base[wave][xcount] = (unsigned)(base - jbeg);
+#pragma unroll
+                        for (int q = 0; q < LEANP; ++q)
+                        {
+                            raw->xl_mask[wave][xcount][q] = handed[q];
+                        }
+                    }
+                    ++xcount;
+                }
+            }
+            if (any_valid == 0ull)
+            {
+                return;
+            }
+            // ---- the row sums: sixteen moment sums (eight per cell) end in sixteen lanes, eight near-field sums in eight ----
+#ifdef GRT_ABL_NOREDUCE
+            if (any_valid != 0ull) return;
+#endif
+            {
+                float t;
+                int cell;
+                if (one_cell)
+                {
+                    t = row_sum_transposed(m0, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0);       // value (lane >> 1) & 7, twice
+                    t = (lane & 1) == 0 ? t : 0.f;
+                    cell = cr;
+                }
+                else
+                {
+                    t = row_sum_two_groups(m0, m1, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0, (lane & 1) != 0);
+                    cell = cr + ((lane >> 3) & 1);
+                }
+                int const kmom = one_cell ? (lane >> 1) & 7 : lane & 7;
+#ifdef GRT_ABL_NOLDSADD
+                if ((t == 123.456f) & (cell < F1))
+#else
+                if ((t != 0.f) & (cell < F1))
+#endif
+                {
+                    mom_add(kmom, cell, t);
+                }
+                float const s8 = row_sum_transposed(nvs, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0);
+#ifdef GRT_ABL_NOLDSADD
+                if (((lane & 1) == 0) & (s8 == 123.456f))
+#else
+                if (((lane & 1) == 0) & (s8 != 0.f))
+#endif
+                {
+                    GRT_ACC_ADD(&acc[cr - 3 + ((lane >> 1) & 7) - A0], (double)s8);
+                }
+            }
+        }
+    };
+
+    // The workgroup's lines: lean blocks while that form applies and its list of handed-over lines has room; then the
+    // general form for the listed lines and for every block the lean loop did not take.
+    uint64_t base = walk_first;
+    if constexpr (LEANP > 0)
+    {
+        if (lean_ok)
+        {
+            if (base < jend)
+            {
+                lean_fetch(base, 0);
+            }
+            for (; base < jend; base += walk_stride)
+            {
+                lean_block(base);
+                if (xcount == kLeanListCap)
+                {
+                    base += walk_stride;
+                    break;
+                }
+            }
+            if (rawcount > 0)
+            {
+                drain_raw(0, rawcount);
+                rawcount = 0;
+            }
+        }
+    }
+    for (int x = 0;;)
+    {
+        bool listed = false;
+        uint64_t bj = 0;
+        if constexpr (LEANP > 0)
+        {
+            if (x < xcount)
+            {
+                listed = true;
+                bj = jbeg + raw->xl_base[wave][x];
+            }
+        }
+        if (!listed)
+        {
+            if (base >= jend)
+            {
+                break;
+            }
+            bj = base;
+            base += walk_stride;
+        }
+        for (int p = 0; p < kLinesPerLane; ++p)
+        {
+            uint64_t j;
+            bool hv;
+            if (listed)
+            {
+                // (lines the lean form handed over: flagged ones, and centres too close to halfway between two grid points)
+                unsigned long long mk = 0ull;
+                if constexpr (LEANP > 0)
+                {
+                    mk = raw->xl_mask[wave][x][p];
+                }
+                if (mk == 0ull)
+                {
+                    continue;
+                }
+                j = bj + (uint64_t)(kLinesPerLane*lane + p);
+                hv = ((mk >> lane) & 1ull) != 0ull;
+            }
+            else
+            {
+                if (bj + (uint64_t)p*64 >= jend)
+                {
+                    continue;
+                }
+                j = bj + (uint64_t)p*64 + lane;
+                hv = j < jend;
+            }
+            general_block(j, hv);
+        }
+        if (listed)
+        {
+            ++x;
+        }
     }
 #pragma unroll
     for (int q = 0; q < Queue::classes; ++q)
@@ -1362,6 +2090,21 @@ void gas_optics_mp_kernel_w5(GrtGasOpticsArgs a, long long fsteps_ll, unsigned n
                              int nacc, int halo)
 {
     mp_kernel_body<TWO_PASS, TREE, K, LEAN>(a, fsteps_ll, ngroups, perm_stride, ncell, nacc, halo);
+}
+
+// First pass of the two-pass form with the LEAN line loop (see mp_kernel_body): LEANP lines per lane.
+#ifndef GRT_LEAN_WAVES
+#define GRT_LEAN_WAVES 4
+#endif
+#ifndef GRT_LEAN_P
+#define GRT_LEAN_P 2
+#endif
+template <bool LEAN, int LEANP>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GRT_LEAN_WAVES, GRT_LEAN_WAVES)))
+void gas_optics_lean_kernel(GrtGasOpticsArgs a, long long fsteps_ll, unsigned ngroups, unsigned perm_stride, int ncell,
+                            int nacc, int halo)
+{
+    mp_kernel_body<true, false, kMom, LEAN, false, LEANP>(a, fsteps_ll, ngroups, perm_stride, ncell, nacc, halo);
 }
 
 // The instrumented instance of the tree form on sparse lines (twelve moments), see mp_kernel_body<..., PROBE>.
@@ -2096,6 +2839,11 @@ void launch_tree(hipStream_t s, GrtGasOpticsArgs const &b, long long fsteps, int
 
 // subtree_tile > 0: the tree form's first pass with moments straight to global memory, which ends by building the tile's
 // coarser cells in two LDS buffers (tile/2 + tile/4 cells of twelve moments) where the accumulator was
+size_t lean_lds_bytes(int num_slots)
+{
+    return 16 + sizeof(float4)*num_slots + sizeof(float2)*(size_t)num_slots*GRT_MAX_ISO + sizeof(float)*kPowTable + sizeof(LeanRaw);
+}
+
 size_t mp_lds_bytes(int nacc, int ncell, int fsteps, int num_slots, bool tree = false, int subtree_tile = 0)
 {
     size_t const main_loop = sizeof(double)*nacc + (tree ? sizeof(MpQueueTree) : sizeof(MpQueueFlat)) + 2*sizeof(long long) + sizeof(double)*(num_slots*(4 + GRT_MAX_ISO) + kPowTable)
@@ -2108,6 +2856,14 @@ size_t far_lds_bytes(int tile, int ncell, int fsteps, int num_slots, int cell_sh
 {
     return sizeof(double)*tile + sizeof(double)*num_slots*(4 + GRT_MAX_ISO) + sizeof(float)*((size_t)kMom*ncell + fsteps + 1)
            + sizeof(int)*((size_t)(ncell >> cell_shift) + 3);
+}
+
+// GRT_LEAN=0 in the environment (read at every launch, so that a test can compare the two forms in one process): the
+// two-pass form's first pass keeps the general line loop everywhere
+int lean_wanted()
+{
+    char const *env = getenv("GRT_LEAN");
+    return (env != NULL && env[0] == '0') ? 0 : 1;
 }
 
 // GRT_DIRECT_NEAR=0 in the environment: seven-point near fields through the ring as well (comparison runs)
@@ -2238,7 +2994,15 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
         }
         int slot = a->profile_tag ? grt_profile_begin(stream, a->profile_tag) : -1;
         int const ncell = (tree && a->tile > kDirectTile) ? 0 : a->tile;
-        size_t const lds = mp_lds_bytes(nacc, ncell, 0, a->lay.num_slots, tree, tree && ncell == 0 ? a->tile : 0);
+        size_t lds = mp_lds_bytes(nacc, ncell, 0, a->lay.num_slots, tree, tree && ncell == 0 ? a->tile : 0);
+        // the lean line loop: single-level gather, packed records built for this very grid, room for its tables in LDS
+        b.lean = !tree && a->probe == NULL && lean_wanted() && a->lines.lean_a != NULL && a->lines.lean_b != NULL
+                 && a->lines.lean_c != NULL && a->lines.lean_w0 == a->w0 && a->lines.lean_wres == a->wres
+                 && a->lines.n < 0xffffffffull && halo >= 8 && lds + lean_lds_bytes(a->lay.num_slots) <= kLdsPerWorkgroup;
+        if (b.lean)
+        {
+            lds += lean_lds_bytes(a->lay.num_slots);
+        }
         // Deterministic mode: the accumulators of cell tiles t and t' overlap when |t - t'| tile < tile + 2 halo, and the
         // order in which their workgroups add to tau is the scheduler's.  So the first pass runs in nphase launches, launch p
         // taking the tiles t = p (mod nphase): no two tiles of a launch touch the same point, the launches follow one
@@ -2283,6 +3047,16 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
                         hipLaunchKernelGGL((gas_optics_mp_probe_kernel<false>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
                                            fsteps, (unsigned)ngroups, golden_stride(ngroups), ncell, nacc, halo);
                     }
+                }
+                else if (b.lean && a->w0 + (double)a->nw*a->wres <= 4000.)
+                {
+                    hipLaunchKernelGGL((gas_optics_lean_kernel<true, GRT_LEAN_P>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
+                                       fsteps, (unsigned)ngroups, golden_stride(ngroups), ncell, nacc, halo);
+                }
+                else if (b.lean)
+                {
+                    hipLaunchKernelGGL((gas_optics_lean_kernel<false, GRT_LEAN_P>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
+                                       fsteps, (unsigned)ngroups, golden_stride(ngroups), ncell, nacc, halo);
                 }
                 else if (a->w0 + (double)a->nw*a->wres <= 4000.)
                 {

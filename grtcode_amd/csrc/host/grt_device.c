@@ -15,13 +15,27 @@
    that follow use; objects that are used together must be used on the same lane, or with a device synchronisation between. */
 static hipStream_t g_streams[GRT_MAX_DEVICES][GRT_NUM_LANES];
 static int g_lane[GRT_MAX_DEVICES];
+/* Once a lane other than 0 has been selected on a device, an object's work may sit on a stream other than the one selected
+   NOW: every wait of the library (grt_dev_sync: pipeline sync / destroy, destroy_optics before it parks its block, the
+   synchronous reference-shaped calls) then waits for the whole device, so that none of them can return, or hand memory on,
+   while a kernel on another lane still uses it.  Callers that never touch lanes keep the one-stream wait. */
+static int g_lanes_used[GRT_MAX_DEVICES];
 
 EXTERN int grt_device_use_lane(Device_t device, int lane)
 {
     GRT_TRY(grt_dev_require(device));
     GRT_REQUIRE_RANGE(lane, 0, GRT_NUM_LANES - 1);
     g_lane[device] = lane;
+    if (lane != 0)
+    {
+        g_lanes_used[device] = 1;
+    }
     return GRTCODE_SUCCESS;
+}
+
+int grt_dev_lane(Device_t device)
+{
+    return (device < 0 || device >= GRT_MAX_DEVICES) ? 0 : g_lane[device];
 }
 
 EXTERN int grt_device_synchronize(Device_t device)
@@ -109,11 +123,16 @@ int grt_dev_require(Device_t device)
 
 void *grt_dev_stream(Device_t device)
 {
-    if (device < 0 || device >= GRT_MAX_DEVICES)
+    return grt_dev_stream_of_lane(device, grt_dev_lane(device));
+}
+
+void *grt_dev_stream_of_lane(Device_t device, int lane)
+{
+    if (device < 0 || device >= GRT_MAX_DEVICES || lane < 0 || lane >= GRT_NUM_LANES)
     {
         return NULL;
     }
-    hipStream_t *s = &g_streams[device][g_lane[device]];
+    hipStream_t *s = &g_streams[device][lane];
     if (*s == NULL)
     {
         if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(s, hipStreamNonBlocking) != hipSuccess)
@@ -178,6 +197,11 @@ int grt_dev_copy(Device_t device, void *dst, void const *src, size_t bytes, void
 int grt_dev_sync(Device_t device, void *stream)
 {
     GRT_TRY(grt_dev_require(device));
+    if (g_lanes_used[device])
+    {
+        GRT_TRY(grt_dev_check((int)hipDeviceSynchronize(), "hipDeviceSynchronize"));
+        return GRTCODE_SUCCESS;
+    }
     GRT_TRY(grt_dev_check((int)hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize"));
     return GRTCODE_SUCCESS;
 }

@@ -682,9 +682,33 @@ EXTERN int create_gas_optics(GasOptics_t * const gas_optics, int const num_level
            reference order. */
         im->fast = 3;
         char const *env = getenv("GRT_GAS_OPTICS_FAST");
-        if (env != NULL && env[0] >= '0' && env[0] <= '3' && env[1] == '\0')
+        if (env != NULL && env[0] != '\0')
         {
-            im->fast = env[0] - '0';
+            /* leading / trailing blanks and zeros are tolerated ("0 ", "03"); anything else is said out loud and ignored */
+            char *end = NULL;
+            long const v = strtol(env, &end, 10);
+            while (end != NULL && (*end == ' ' || *end == '\t'))
+            {
+                ++end;
+            }
+            if (end != NULL && end != env && *end == '\0' && v >= 0 && v <= 3)
+            {
+                im->fast = (int)v;
+            }
+            else
+            {
+                GRT_WARN("GRT_GAS_OPTICS_FAST=\"%s\" is not one of 0, 1, 2, 3: ignored, the line kernel keeps its default form (%d).",
+                         env, im->fast);
+            }
+        }
+        static int told = -1;
+        if (told != im->fast)
+        {
+            /* (once per form: an unchanged caller should be able to see which arithmetic it got -- INTEGRATION.md §8) */
+            told = im->fast;
+            GRT_INFO("Line kernel form %d (%s); GRT_GAS_OPTICS_FAST=0 or grt_gas_optics_tune selects the reference's operation order.",
+                     im->fast, im->fast == 0 ? "reference operation order, tau within 1e-11"
+                               : "fused arithmetic, tau within 2e-6 of each layer's maximum, sums in the scheduler's order");
         }
     }
     size_t const V = (size_t)num_levels;
@@ -1096,19 +1120,21 @@ static size_t align256(size_t x)
 }
 
 /* Upload the lines named by `keys` (already in the wanted order) as one structure of arrays. */
+/* with_lean: also the packed fp32 records of the lean first pass (GrtLineStore.lean_*), for the object's own grid. */
 static int upload_lines(GasOptics_t *go, SortKey const *keys, uint64_t total, GrtLineStore *st, void **block,
-                        size_t *bytes_out)
+                        size_t *bytes_out, int with_lean)
 {
     GrtGasOpticsImpl *im = impl_of(go);
-    size_t off[10];
+    size_t off[13];
     size_t bytes = 0;
-    size_t const sizes[9] = {8, 8, 4, 4, 4, 4, 4, 1, 1};
-    for (int a = 0; a < 9; ++a)
+    size_t const sizes[12] = {8, 8, 4, 4, 4, 4, 4, 1, 1, 16, 16, 4};
+    int const narr = with_lean ? 12 : 9;
+    for (int a = 0; a < narr; ++a)
     {
         off[a] = bytes;
         bytes = align256(bytes + sizes[a]*total);
     }
-    off[9] = bytes;
+    off[narr] = bytes;
     unsigned char *host = malloc(bytes);
     if (host == NULL)
     {
@@ -1154,6 +1180,58 @@ static int upload_lines(GasOptics_t *go, SortKey const *keys, uint64_t total, Gr
             rescale_one(go->mols[slot[k]].id, q296[slot[k]], iso[k], v0[k], en[k], &s0[k]);
         }
     }
+    if (with_lean)
+    {
+        /* The lean first pass (k_gas_optics_mp.hip: lean_block) works in fp32 from quantities that depend on the line and
+           the grid only: the grid point nearest the unshifted centre and the centre's offset from it -- the pressure shift
+           (kernels.c:44) is added to the offset per layer, and whenever that sum comes within 1e-5 of the halfway mark the
+           line takes the general path, which forms kernels.c:431-432 in fp64 -- the strength scaled into fp32's range, and
+           the temperature exponent as an index into the per-layer table of (296/T)^(k/100) (kernels.c:105). */
+        float *la = (float *)(host + off[9]), *lb = (float *)(host + off[10]);
+        uint32_t *lc = (uint32_t *)(host + off[11]);
+        double const w0 = go->bins.w0, wres = go->bins.wres;
+        for (uint64_t k = 0; k < total; ++k)
+        {
+            double const uu = (v0[k] - w0)/wres;
+            double const c0 = floor(uu + 0.5);
+            uint32_t flags = 0;
+            int32_t ci = 0;
+            if (!(fabs(c0) < 1e9))
+            {
+                flags |= GRT_LEAN_GENERAL;
+            }
+            else
+            {
+                ci = (int32_t)c0;
+            }
+            double const ss = ldexp(s0[k], GRT_LEAN_S0_SHIFT);
+            if (!(ss >= 0x1p-100 && ss <= 0x1p100))
+            {
+                flags |= GRT_LEAN_GENERAL;      /* (zero, negative or NaN strengths included) */
+            }
+            float const n100 = nexp[k]*100.f, nk = rintf(n100);
+            uint32_t ik = 255;
+            if (fabsf(n100 - nk) <= 2e-5f && nk >= 0.f && nk < 128.f)       /* (the kernel's own test, kPowTable entries) */
+            {
+                ik = (uint32_t)nk;
+            }
+            else
+            {
+                flags |= GRT_LEAN_GENERAL;
+            }
+            if (iso[k] < 1 || iso[k] > GRT_MAX_ISO)
+            {
+                flags |= GRT_LEAN_GENERAL;
+            }
+            la[4*k] = (float)(uu - c0);
+            memcpy(&la[4*k + 1], &ci, sizeof(ci));
+            la[4*k + 2] = (float)v0[k];
+            la[4*k + 3] = (flags & GRT_LEAN_GENERAL) ? 0.f : (float)ss;
+            lb[4*k] = yair[k]; lb[4*k + 1] = yself[k]; lb[4*k + 2] = en[k]; lb[4*k + 3] = delta[k];
+            uint32_t const ti = (uint32_t)slot[k]*GRT_MAX_ISO + (uint32_t)(iso[k] >= 1 ? iso[k] - 1 : 0);
+            lc[k] = ik | ((uint32_t)slot[k] << 8) | ((ti & 1023u) << 14) | flags;
+        }
+    }
     int rc = grt_dev_alloc(go->device, block, bytes);
     void *s = grt_dev_stream(go->device);
     if (rc == GRTCODE_SUCCESS) rc = grt_dev_upload(go->device, *block, host, bytes, s);
@@ -1170,6 +1248,17 @@ static int upload_lines(GasOptics_t *go, SortKey const *keys, uint64_t total, Gr
     st->delta = (float const *)(d + off[6]);
     st->iso = d + off[7];
     st->slot = d + off[8];
+    st->lean_a = st->lean_b = NULL;
+    st->lean_c = NULL;
+    st->lean_w0 = st->lean_wres = 0.;
+    if (with_lean)
+    {
+        st->lean_a = (float const *)(d + off[9]);
+        st->lean_b = (float const *)(d + off[10]);
+        st->lean_c = (uint32_t const *)(d + off[11]);
+        st->lean_w0 = go->bins.w0;
+        st->lean_wres = go->bins.wres;
+    }
     if (bytes_out != NULL) *bytes_out = bytes;
     return GRTCODE_SUCCESS;
 }
@@ -1207,7 +1296,7 @@ static int build_store(GasOptics_t *go)
     }
     qsort(keys, total, sizeof(SortKey), sort_key_cmp);
     size_t bytes = 0;
-    int rc = upload_lines(go, keys, total, &im->store, &im->store_block, &bytes);
+    int rc = upload_lines(go, keys, total, &im->store, &im->store_block, &bytes, go->optical_depth_method == line_sample);
     if (rc == GRTCODE_SUCCESS && go->optical_depth_method != line_sample)
     {
         /* the sweep methods work molecule by molecule (launch.c:78-159): one store each, sorted by centre */
@@ -1226,7 +1315,7 @@ static int build_store(GasOptics_t *go)
             }
             if (n > 0)
             {
-                rc = upload_lines(go, mk, n, &im->mstore[sl], &im->mstore_block[sl], NULL);
+                rc = upload_lines(go, mk, n, &im->mstore[sl], &im->mstore_block[sl], NULL, 0);
             }
         }
         free(mk);
@@ -1437,8 +1526,12 @@ static void auto_tune(GasOptics_t const *go, int ncol, int moments, int *tile, i
            a tile keeps a few thousand lines: a workgroup's fixed costs (column state, the table of temperature powers,
            clearing and flushing its accumulators) are paid per tile.  One column of the G1 shortwave band (30 lines per
            cell): 256-cell tiles 1.91 ms, 128-cell tiles 1.98-2.14 ms. */
-        while (moments == 2 && want > 64 && ((nw + want - 1)/want)*(uint64_t)go->num_layers*(uint64_t)ncol < 16384
-               && per_cell*(double)(want/2) >= 6000.)
+        /* Round 4: the same with MANY columns too while a tile holds more than ~24 000 lines -- all the (layer, column)
+           workgroups of a tile read one slice of the line store, which should stay in an XCD's 4 MB L2 next to everything
+           else: G1 longwave, 64 columns per launch, 256-cell tiles (79 000 lines, 2.8 MB of packed records) 40.2 ms,
+           128-cell 36.5, 64-cell 34.9 (scripts/tile_sweep.sh). */
+        while (moments == 2 && want > 64 && per_cell*(double)(want/2) >= 6000.
+               && (((nw + want - 1)/want)*(uint64_t)go->num_layers*(uint64_t)ncol < 16384 || per_cell*(double)want > 24000.))
         {
             want >>= 1;
         }

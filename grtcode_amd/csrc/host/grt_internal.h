@@ -56,7 +56,9 @@ int grt_dev_event_record(Device_t device, void **ev, void *stream);
 int grt_dev_event_wait(Device_t device, void *ev);
 int grt_dev_event_destroy(Device_t device, void **ev);
 int grt_dev_check(int hip_error, char const *what);     /* maps any HIP error to GRTCODE_GPU_ERR */
-void *grt_dev_stream(Device_t device);                  /* library stream of a device (created lazily) */
+void *grt_dev_stream(Device_t device);                  /* library stream of a device (created lazily): the selected lane's */
+int grt_dev_lane(Device_t device);                      /* the lane selected now (grt_device_use_lane) */
+void *grt_dev_stream_of_lane(Device_t device, int lane);
 int grt_profile_begin(void *stream, int tag);           /* -1 when profiling is off */
 void grt_profile_end(void *stream, int slot);
 int grt_host_alloc_pinned(void **p, size_t bytes);

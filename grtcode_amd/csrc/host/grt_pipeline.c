@@ -38,6 +38,7 @@ typedef struct GrtBand
 struct GrtPipeline
 {
     Device_t device;
+    int lane;              /* the lane selected when the pipeline was created: grt_pipeline_stream names THAT stream */
     int max_cols, num_levels, user_level;
     int keep_spectra;      /* 0: fused solvers, integrated fluxes only (production); 1: tau/omega/g and fluxes materialised */
     GrtBand band[2];       /* 0: longwave, 1: shortwave */
@@ -183,6 +184,7 @@ EXTERN int grt_pipeline_create_ex(GrtPipeline_t **pipeline, GasOptics_t *lw_gas,
         GRT_FAIL(GRTCODE_NULL_ERR, "out of host memory for the pipeline object.%s", "");
     }
     p->device = any->device;
+    p->lane = grt_dev_lane(any->device);
     p->max_cols = max_columns;
     p->num_levels = any->num_levels;
     p->user_level = user_level;
@@ -233,7 +235,7 @@ EXTERN int grt_pipeline_destroy(GrtPipeline_t **pipeline)
 
 EXTERN void *grt_pipeline_stream(GrtPipeline_t *pipeline)
 {
-    return pipeline ? grt_dev_stream(pipeline->device) : NULL;
+    return pipeline ? grt_dev_stream_of_lane(pipeline->device, pipeline->lane) : NULL;
 }
 
 EXTERN int grt_pipeline_sync(GrtPipeline_t *pipeline)

@@ -81,8 +81,9 @@ class G1Workload:
         self.sw_lines = band_lines(sw_lines, sw_grid, 20261004, physical)
         self.go_lw, self.grid_lw = build_band(device, lw_grid, self.lw_lines, self.lw_files, num_levels)
         self.go_sw, self.grid_sw = build_band(device, sw_grid, self.sw_lines, self.sw_files, num_levels)
-        self.go_lw.tune(fast=fast, tile=tile, nslice=lw_nslice)
-        self.go_sw.tune(fast=fast, tile=tile)
+        # (GRT_BENCH_LW_TILE / GRT_BENCH_SW_TILE / GRT_BENCH_SW_NSLICE: exploration only -- per-band tilings of the line kernel)
+        self.go_lw.tune(fast=fast, tile=int(os.environ.get("GRT_BENCH_LW_TILE", tile)), nslice=lw_nslice)
+        self.go_sw.tune(fast=fast, tile=int(os.environ.get("GRT_BENCH_SW_TILE", tile)), nslice=int(os.environ.get("GRT_BENCH_SW_NSLICE", 0)))
         self.emis = np.full(self.grid_lw.n, 0.98)
         self.albedo = np.full(self.grid_sw.n, 0.2)
         self.solar = api.create_solar_flux(self.grid_sw, self.sw_files["solar"])

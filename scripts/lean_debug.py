@@ -15,6 +15,23 @@ elif case == "dense":
     band = Band(tmp, 900.0, 1100.0, 1.0, 20000); col = syn.profile(2, 13)
 elif case == "sw":
     band = Band(tmp, 30000.0, 30600.0, 1.0, 20000, sw=True, with_cfc=False); col = syn.profile(3, 13)
+elif case == "farir":
+    band = Band(tmp, 40.0, 400.0, 1.0, 9000); col = syn.profile(0, 25)
+elif case.startswith("seed"):      # the cases of tests/test_gpu_moment_kernel.py::test_randomised_grids_profiles_and_launch_shapes
+    rng = np.random.default_rng(4242 + int(case[4:]))
+    dw = float(rng.choice([0.1, 0.2, 0.25, 0.5, 1.0, 1.25, 1.5]))
+    npts = int(rng.integers(150, 900))
+    w0 = float(np.round(rng.choice([1.0, 300.0, 2000.0, 9000.0, 30000.0]) + rng.uniform(0, 50), 2))
+    span = npts*dw
+    if w0 + span > 50000.0:
+        w0 = 50000.0 - span
+    nlines = int(rng.integers(50, 6000))
+    V = int(rng.integers(4, 15))
+    band = Band(tmp, w0, w0 + span, dw, nlines, seed=int(rng.integers(1, 10**6)), sw=w0 > 3000.0, with_cfc=w0 < 3000.0)
+    col = syn.profile(int(rng.integers(0, 50)), V)
+    col["p"] = col["p"]*float(rng.choice([0.3, 1.0, 1.0, 2.5]))
+    col["t"] = np.clip(col["t"] + float(rng.uniform(-40, 30)), 150.0, 340.0)
+    print(f"{case}: dw {dw} w0 {w0} n {band.nw} lines {nlines} V {V} p_surf {col['p'][-1]:.1f}")
 else:
     band = Band(tmp, 300.0, 700.0, 1.0, 6000); col = syn.profile(5, 13)
 V = col["p"].size

@@ -281,15 +281,15 @@ def test_config4_1800_replicated_columns_in_8_rank_shards_with_gather(tmp_path, 
 
 
 def test_config5_era5_like_two_thousand_columns_full_grids_all_cfcs(tmp_path, oracle, lib, device):
-    """BASELINE config 5 at a size one GPU does in seconds: 2 048 columns (O(10^3) of the O(10^4)), longwave 1-3250 cm-1
+    """BASELINE config 5 at a size one GPU does in seconds: 2 048 columns (O(10^3) of the O(10^4)) of 60 layers, longwave 1-3250 cm-1
     at 0.1 cm-1 (n = 32 491: the tree form of the line kernel), shortwave 1-50 000 cm-1 at 10 cm-1 (7-point windows: the
-    direct-walk form), all 21 CFC/HCFC species of cfcs.h:32-56, 3 CIA pairs, production pipeline in chunks of 128;
+    direct-walk form), all 21 CFC/HCFC species of cfcs.h:32-56, 3 CIA pairs, production pipeline in chunks of 64;
     sampled columns against the CPU checker."""
     import os
     from oracle import reference_column as RC
     kind, chk, orc = RC.checker(omp=True)
     RC.set_omp_threads(min(os.cpu_count() or 1, 16))
-    V, ncfc, ncol, chunk = 31, 21, 2048, 128
+    V, ncfc, ncol, chunk = 61, 21, 2048, 64          # (61 levels = the stated 60 layers; round 3 ran 31)
     lwb = Band(str(tmp_path / "lw"), 1.0, 3250.0, 0.1, 6000, physical=True)
     swb = Band(str(tmp_path / "sw"), 1.0, 50000.0, 10.0, 6000, sw=True, physical=True)
 

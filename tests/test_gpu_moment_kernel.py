@@ -36,15 +36,28 @@ def run(band, device, col, fast, tile=0, nslice=0, from_file=False):
     return tau
 
 
+# the two-pass form's LEAN line loop (fp32 preparation from packed records, round 4) against its general line loop (fp64
+# preparation): per-line factors a few fp32 roundings apart -- strength, Lorentz width, 1/Doppler width
+LEAN_TOL = 1.5e-6
+
+
 def check(band, device, oracle, lib, col, **kw):
     want = band.oracle_tau(oracle, oracle, lib, col)
     mp = run(band, device, col, 1, **kw)
     ring = run(band, device, col, 2, **kw)
-    two = run(band, device, col, 3, **kw)               # two-pass form: cell moments through global memory
+    lean = run(band, device, col, 3, **kw)              # two-pass form: cell moments through global memory; lean line loop
+    os.environ["GRT_LEAN"] = "0"
+    try:
+        two = run(band, device, col, 3, **kw)           # ... with the general line loop: the one-pass form's arithmetic
+    finally:
+        del os.environ["GRT_LEAN"]
     e_mp, e_ring, e_between = tau_close(mp, want), tau_close(ring, want), tau_close(mp, ring)
     e_two, e_forms = tau_close(two, want), tau_close(two, mp)
+    e_lean, e_lean_two = tau_close(lean, want), tau_close(lean, two)
     print(f"moment kernel vs oracle {e_mp:.2e}; ring kernel vs oracle {e_ring:.2e}; moment vs ring {e_between:.2e}; "
-          f"two-pass vs oracle {e_two:.2e}, vs one-pass {e_forms:.2e}")
+          f"two-pass vs oracle {e_two:.2e}, vs one-pass {e_forms:.2e}; lean two-pass vs oracle {e_lean:.2e}, vs general {e_lean_two:.2e}")
+    assert e_lean < FAST_TOL
+    assert e_lean_two < LEAN_TOL
     if os.environ.get("GRT_STRESS_STRICT"):             # soak runs: the reference-order form on the same case
         e_strict = tau_close(run(band, device, col, 0, **kw), want)
         print(f"reference-order form vs oracle {e_strict:.2e}")

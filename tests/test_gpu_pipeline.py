@@ -216,6 +216,13 @@ def test_two_pipelines_on_two_lanes_equal_one(bands, lib, device):
             made[0][0].sync()
             assert np.array_equal(out[b].to_host((ncol, api.GRT_FLUXES_PER_COLUMN)), two[b]), b
         assert np.all(two[0][:, 0] > 0) and not np.array_equal(two[0], two[1])
+        # a pipeline's own sync() must wait for ITS work whichever lane is selected now: run the lane-1 pipeline,
+        # select lane 0, sync the lane-1 pipeline, read -- no device-wide wait in between
+        api.use_lane(device, 1)
+        made[1][0].run(batches[1][0], out[0].ptr)
+        api.use_lane(device, 0)
+        made[1][0].sync()
+        assert np.array_equal(out[0].to_host((ncol, api.GRT_FLUXES_PER_COLUMN)), two[1])
     finally:
         api.check(lib.grt_set_deterministic(-1))
         api.use_lane(device, 0)
