@@ -661,10 +661,26 @@ def main():
                                       2: "fused form, every window point in the ring",
                                       3: "fused form, far wings by cell moments, two passes"}.get(args.fast, str(args.fast)),
                        "parallelism": f"columns sharded over {world} GPU(s), one process per GPU; one RCCL gather of the job's 12 fluxes/column to rank 0"},
-            "roofline": {"kernel": f"{line_kernel} (line-by-line tau), SW-band launch", "bound": "hbm",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            # The dominant kernel is bound by the vector pipe's ISSUE rate, not by HBM or MFMA (no dense contraction on this
+            # path): `roofline` prices it against what binds it -- VALU wave64 instructions per second over the chip's issue
+            # slots (1 024 SIMDs, one such instruction per two cycles at best; instruction count from the PMC pass of this
+            # same command, launch duration measured live in this run) -- and `roofline_hbm` keeps the HBM view with SURVEY
+            # §8(d)'s algorithmic bytes (task 2).
+            "roofline": {"kernel": f"{line_kernel} (line-by-line tau), SW-band launch", "bound": "valu_issue",
+                         "achieved": (sq["SQ_INSTS_VALU"] / (dom_ms * 1e-3) / 1e9) if sq.get("SQ_INSTS_VALU") and dom_ms > 0 else None,
+                         "peak": SIMDS * CLOCK_HZ * 0.5 / 1e9, "unit": "G wave64 VALU instructions/s",
+                         "frac": (sq["SQ_INSTS_VALU"] / (SIMDS * dom_ms * 1e-3 * CLOCK_HZ * 0.5)) if sq.get("SQ_INSTS_VALU") and dom_ms > 0 else None,
+                         "algorithmic_fp32_frac": (valu_flop / (dom_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS) if dom_ms > 0 else None,
                          "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": dom_ms, "launches": ms[2][1],
-                         "note": "this kernel is FP32/FP64-VALU bound by construction, see roofline_valu"},
+                         "instructions_source": traffic_src,
+                         "note": "measured on gfx950 (scripts/valu_mix*.hip, profiles/r4_valu_mix*.txt): at this kernel's occupancy a wave64 "
+                                 "fp32 fma/mul/add occupies the pipe ~2.5-4 cycles, every fp64 op, conversion, compare, select and DPP "
+                                 "move ~4.6, rcp/exp/sqrt ~10 -- so the two-cycle issue peak is not reachable with this instruction mix; "
+                                 "SQ_ACTIVE_INST_VALU of the PMC pass puts the pipe at >90 % busy"},
+            "roofline_hbm": {"kernel": f"{line_kernel} (line-by-line tau), SW-band launch", "bound": "hbm",
+                             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                             "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": dom_ms, "launches": ms[2][1],
+                             "note": "this kernel is VALU-issue bound by construction, see roofline"},
             "roofline_valu": {"kernel": f"{line_kernel}, SW-band launch", "bound": "valu_fp32",
                               "achieved": valu_flop / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0,
                               "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s (algorithmic: 12 flop x L*S*F line-shape points, SURVEY §8d; the moment kernel "
@@ -702,8 +718,9 @@ def main():
                              "compulsory_bytes_fused": fused_b * n * cols_launch, "achieved_gb_per_s_fused": fused_b * n * cols_launch / t / 1e9,
                              "traffic": solver_traffic.get(name + "_kernel")}
                 if name == "sw":
-                    # tau_gas once, albedo + solar, reflectances (2 V rows) and layer properties (5 L rows) written and read back
-                    park_b = (8.0 * L + 24 + 2 * 8.0 * (2 * V + 5 * L)) * n * cols_launch
+                    # tau_gas once, albedo + solar, layer properties (5 L rows) written and read back (round 4: the 2 V rows of
+                    # reflectances are no longer parked -- only three levels' fluxes leave the fused kernel)
+                    park_b = (8.0 * L + 24 + 2 * 8.0 * (5 * L)) * n * cols_launch
                     sol[name].update({"traffic_with_park": park_b, "achieved_gb_per_s_with_park": park_b / t / 1e9,
                                       "frac_hbm_with_park": park_b / t / 1e9 / HBM_PEAK_GBS})
         line["roofline_solvers"] = dict(sol, bound="hbm (shortwave: layer properties parked by the first sweep, read back by the second); "

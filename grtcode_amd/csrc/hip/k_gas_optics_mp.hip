@@ -1505,8 +1505,9 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                 float const w0f = (valid & (o == 0)) ? 1.f : 0.f;
                 float const w1f = (valid & (o == 1)) ? 1.f : 0.f;
                 bool const odd = valid & ((unsigned)o > 1u);
-                // (the longwave band's usual case, 308 lines per cell: no second cell, no weights)
-                bool const single = __ballot(valid & (o != 0)) == 0ull;
+                // (the longwave band's usual case, 308 lines per cell: no second cell, no weights; the shortwave instance, 30
+                // lines per cell, does not ask)
+                bool const single = LEAN && __ballot(valid & (o != 0)) == 0ull;
                 one_cell = one_cell & single;
                 // ---- moments of the Lorentzian about the cell centre (see general_block) ----
                 float const A = (amp*eta)*a_norm;                                   // K(r) = A/((r - dl)^2 + eta^2)

@@ -190,8 +190,17 @@ __global__ __launch_bounds__(kBlock) void sw_kernel(GrtSwArgs a)
     // sweep 1: shortwave.c:280-294
     double Rdir_dn = a.alb_dir[(uint64_t)col*a.alb_stride + ii];
     double Rdif_dn = a.alb_dif[(uint64_t)col*a.alb_stride + ii];
-    fu[(uint64_t)L*nw] = Rdir_dn;
-    fd[(uint64_t)L*nw] = Rdif_dn;
+    // Fused form: only three levels' fluxes leave the kernel (top, surface, the user's), so the downward-beam reflectances
+    // of the other levels are never needed again -- the surface's are the albedos, the top's and the user level's stay in
+    // registers, and nothing of this sweep but the layer properties is parked (round 4: 2 V fewer rows written and read
+    // back per column; the same doubles reach the same expressions, so the fluxes are the same to the last bit).
+    double const surf_rdir = Rdir_dn, surf_rdif = Rdif_dn;
+    double user_rdir = Rdir_dn, user_rdif = Rdif_dn;        // (the user level is the surface, or set below)
+    if (!FUSED)
+    {
+        fu[(uint64_t)L*nw] = Rdir_dn;
+        fd[(uint64_t)L*nw] = Rdif_dn;
+    }
     for (int j = L - 1; j >= 0; --j)
     {
         uint64_t const o = (uint64_t)j*nw;
@@ -207,8 +216,16 @@ __global__ __launch_bounds__(kBlock) void sw_kernel(GrtSwArgs a)
         double const ndif = p.Rdif + p.Tdif*p.Tdif*Rdif_dn*B;
         Rdir_dn = ndir;
         Rdif_dn = ndif;
-        fu[o] = Rdir_dn;
-        fd[o] = Rdif_dn;
+        if (FUSED)
+        {
+            user_rdir = j == user ? Rdir_dn : user_rdir;
+            user_rdif = j == user ? Rdif_dn : user_rdif;
+        }
+        else
+        {
+            fu[o] = Rdir_dn;
+            fd[o] = Rdif_dn;
+        }
     }
 
     // sweep 2: shortwave.c:299-329 fused, then the scalings of :401-405 and :447-451
@@ -217,7 +234,7 @@ __global__ __launch_bounds__(kBlock) void sw_kernel(GrtSwArgs a)
     double dir_beam = 1.;
     double dif_beam = 0.;
     {
-        double up = dir_beam*fu[0];       // R[0] = dir_beam*R_dir_downward[0]
+        double up = dir_beam*(FUSED ? Rdir_dn : fu[0]);       // R[0] = dir_beam*R_dir_downward[0]
         double dn = dir_beam;             // T[0]
         up *= scale;
         dn *= scale;
@@ -270,8 +287,12 @@ __global__ __launch_bounds__(kBlock) void sw_kernel(GrtSwArgs a)
         }
         dir_beam *= p.Tpure;
         uint64_t const ol = (uint64_t)lev*nw;
-        double const rdir = fu[ol];       // R_dir_downward[lev] parked by sweep 1
-        double const rdif = fd[ol];       // R_dif_downward[lev]
+        if (FUSED && lev != L && lev != user)
+        {
+            continue;                     // (no flux of this level is asked for)
+        }
+        double const rdir = FUSED ? (lev == L ? surf_rdir : user_rdir) : fu[ol];       // R_dir_downward[lev] of sweep 1
+        double const rdif = FUSED ? (lev == L ? surf_rdif : user_rdif) : fd[ol];       // R_dif_downward[lev]
         double const B = 1./(1. - rdif*Rup_prev);
         double up = (dir_beam*rdir + dif_beam*rdif)*B;
         double dn = dir_beam*(1. + rdir*Rup_prev*B) + dif_beam*B;

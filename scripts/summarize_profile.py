@@ -27,7 +27,7 @@ def newest(pattern):
 
 
 def short(name):
-    for k in ("gas_optics_mp_kernel", "gas_optics_far_kernel", "gas_optics_kernel", "sw_kernel", "lw_kernel", "clear_sky_kernel", "integrate_rows_kernel",
+    for k in ("gas_optics_lean_kernel", "gas_optics_mp_kernel", "gas_optics_far_kernel", "gas_optics_kernel", "sw_kernel", "lw_kernel", "clear_sky_kernel", "integrate_rows_kernel",
               "reduce_partials_kernel",
               "fillBufferAligned", "copyBuffer"):
         if k in name:
