@@ -121,6 +121,10 @@ typedef struct GrtGasOpticsArgs
                                  instead of the ring (GRT_DIRECT_NEAR=0 in the environment switches it off) */
     int tile_phase, tile_nphase;   /* set by the launcher: this launch takes cell tiles t with t % tile_nphase == tile_phase
                                  (tile_nphase <= 1: all of them) */
+    uint32_t const *tile_ranges;   /* two-pass form, or NULL: [tiles][2] first / one-past-last line of the store whose centre can
+                                 fall in cell tile t under any pressure shift up to the bound the host built the table for
+                                 (a superset: the kernel decides membership line by line) -- spares every workgroup the
+                                 search of the sorted store, ten dependent loads before its waves can start */
     int lean;                 /* set by the launcher (two-pass form, single-level gather, lines.lean_a built for this grid): the
                                  first pass takes the lean fp32 form of the line loop wherever a workgroup's near fields are
                                  seven points wide (GRT_LEAN=0 in the environment switches it off: comparison runs) */

@@ -536,7 +536,21 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
     {
         ptab[i] = exp_fp64((double)((float)i/100.f)*lay[3]);
     }
-    if (wave == 0)
+    if (TWO_PASS && a.tile_ranges != nullptr)
+    {
+        // the host has searched the sorted store for this tile (a superset for any pressure shift up to its bound)
+        if (tid == 0)
+        {
+            uint64_t const jlo = a.tile_ranges[2*tile_idx], jhi = a.tile_ranges[2*tile_idx + 1];
+            uint64_t const per = (jhi - jlo + a.nslice - 1)/a.nslice;
+            uint64_t const b = jlo + per*slice;
+            uint64_t e = b + per;
+            if (e > jhi) e = jhi;
+            range[0] = (long long)(b < jhi ? b : jhi);
+            range[1] = (long long)e;
+        }
+    }
+    else if (wave == 0)
     {
         candidate_range_wave(a, lay, F0l, F1l, TWO_PASS ? 0 : fsteps_ll, slice, range, lane);
     }
@@ -1332,23 +1346,21 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         {
             bool const on = lane < count;
             int const i = first + (on ? lane : 0);
-            uint64_t const j = raw->j[wave][i];
+            unsigned const j = raw->j[wave][i];
             float const ampl = raw->amp[wave][i];
-            int const idx = raw->idx[wave][i];                                         // f - A0
-            RawLine const ln = load_line(a.lines, j);
-            double const *ms = ms_l + ln.slot*4;
-            double const wnoadj = ln.v0 + (double)ln.delta*lay[0];                     // kernels.c:44
-            double const dv = wnoadj - a.w0;
-            double u = (2*(dv*inv_wres) + 1)/2;                                        // kernels.c:431-432 (see general_block)
-            if (fabs(u - rint(u)) <= 4e-15*fmax(1., fabs(u)))
-            {
-                u = (2*(dv/a.wres) + 1)/2;
-            }
-            int const c = (int)floor(u);
+            unsigned const packed = raw->idx[wave][i];
+            int const idx = (int)(packed & 4095u);                                      // f - A0
+            // the centre index is the lean loop's (it is exact there, or the line would not be here): the point is its
+            // grid point c + k - 3
+            int const c = idx + A0 - ((int)(packed >> 12) - 3);
+            double const v0 = a.lines.v0[j];
+            float4 const rb = reinterpret_cast<float4 const *>(a.lines.lean_b)[j];     // yair, yself, en, delta
+            unsigned const rc = a.lines.lean_c[j];
+            double const *ms = ms_l + ((rc >> 8) & 63u)*4;
+            double const wnoadj = v0 + (double)rb.w*lay[0];                            // kernels.c:44
             int const s = c - fsteps < 0 ? 0 : c - fsteps;                             // kernels.c:435
-            float const nk = rintf(ln.nexp*100.f);                                     // (lean lines have tabulated exponents)
-            double const tpow = ptab[(nk >= 0.f) & (nk < (float)kPowTable) ? (int)nk : 0];
-            double const gamma = tpow*((double)ln.yair*ms[1] + (double)ln.yself*ms[0]);     // kernels.c:105-106
+            double const tpow = ptab[rc & 127u];                                       // (lean lines have tabulated exponents)
+            double const gamma = tpow*((double)rb.x*ms[1] + (double)rb.y*ms[0]);       // kernels.c:105-106
             double const alpha = ((double)0.83255461115f*wnoadj)*ms[3];                // kernels.c:127
             double const r0 = (double)__builtin_amdgcn_rcpf((float)alpha);
             float const repwid = (float)((double)kSqrln2*(r0*fma(-alpha, r0, 2.0)));   // RFM_voigt.c:94
@@ -1658,11 +1670,24 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                             v[k] = (acl*(a0 + xq))*__builtin_amdgcn_rcpf(fmaf(xq, D2 + xq, D0));
                         }
                     }
+                    float const e2 = (2.f - adl)*wr;                // |x| of the nearest point two steps from the line's own
                     if (nc_one)
                     {
                         bool const nc = ndcr*ndcr < xq_near;
                         v[3] = nc ? 0.f : v[3];
                         ncm = (nc & valid) ? 8u : 0u;
+                    }
+                    else if (__ballot(valid & !(e2*e2 >= xq_near)) == 0ull)
+                    {
+                        // (grid steps of 8.6 Doppler widths and more: the own point and its two neighbours)
+#pragma unroll
+                        for (int k = 2; k <= 4; ++k)
+                        {
+                            float const x = fmaf((float)(k - 3), wr, ndcr);
+                            bool const nc = x*x < xq_near;
+                            v[k] = nc ? 0.f : v[k];
+                            ncm |= (nc & valid) ? (1u << k) : 0u;
+                        }
                     }
                     else
                     {
@@ -1747,7 +1772,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                         int const pos = rawcount + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
                         raw->j[wave][pos] = (unsigned)(base + off);
                         raw->amp[wave][pos] = amp;
-                        raw->idx[wave][pos] = (unsigned short)(c - 3 + k - A0);
+                        raw->idx[wave][pos] = (unsigned short)((c - 3 + k - A0) | (k << 12));
                     }
                     rawcount += __popcll(mk);
                     if (rawcount >= 64)
@@ -2999,7 +3024,8 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
         // the lean line loop: single-level gather, packed records built for this very grid, room for its tables in LDS
         b.lean = !tree && a->probe == NULL && lean_wanted() && a->lines.lean_a != NULL && a->lines.lean_b != NULL
                  && a->lines.lean_c != NULL && a->lines.lean_w0 == a->w0 && a->lines.lean_wres == a->wres
-                 && a->lines.n < 0xffffffffull && halo >= 8 && lds + lean_lds_bytes(a->lay.num_slots) <= kLdsPerWorkgroup;
+                 && a->lines.n < 0xffffffffull && halo >= 8 && nacc <= 4096
+                 && lds + lean_lds_bytes(a->lay.num_slots) <= kLdsPerWorkgroup;
         if (b.lean)
         {
             lds += lean_lds_bytes(a->lay.num_slots);

@@ -736,6 +736,11 @@ static int free_store(GasOptics_t *go)
     }
     GRT_TRY(grt_dev_free(go->device, im->sweep_scratch));
     im->sweep_scratch = NULL;
+    free(im->sorted_v0_h);
+    im->sorted_v0_h = NULL;
+    GRT_TRY(grt_dev_free(go->device, im->tile_ranges_d));
+    im->tile_ranges_d = NULL;
+    im->tr_tile = 0;
     return GRTCODE_SUCCESS;
 }
 
@@ -1232,6 +1237,17 @@ static int upload_lines(GasOptics_t *go, SortKey const *keys, uint64_t total, Gr
             lc[k] = ik | ((uint32_t)slot[k] << 8) | ((ti & 1023u) << 14) | flags;
         }
     }
+    if (with_lean)
+    {
+        /* (the merged store only: the sorted centres stay on the host as well, for grt_fill_gas_args' tile ranges) */
+        free(im->sorted_v0_h);
+        im->sorted_v0_h = malloc(sizeof(double)*(size_t)(total ? total : 1));
+        if (im->sorted_v0_h != NULL)
+        {
+            memcpy(im->sorted_v0_h, v0, sizeof(double)*(size_t)total);
+        }
+        im->tr_tile = 0;            /* (any table built for the old store is stale) */
+    }
     int rc = grt_dev_alloc(go->device, block, bytes);
     void *s = grt_dev_stream(go->device);
     if (rc == GRTCODE_SUCCESS) rc = grt_dev_upload(go->device, *block, host, bytes, s);
@@ -1599,6 +1615,75 @@ static int near_halo_bound(GasOptics_t const *go, int ncol, double w_top, double
     return worst < 1e9 ? (int)worst : 1000000000;
 }
 
+/* Two-pass form: which lines of the sorted store can have their centre in cell tile t -- searched here, once per (tile size,
+   pressure bound), instead of by every workgroup (k_gas_optics_mp.hip: candidate_range_wave, ten dependent loads of v0 before
+   a workgroup's waves can start).  A line's shifted centre is v0 + delta p (kernels.c:44), |delta| <= store.dmax, so with
+   p up to the bound the candidates of the tile [F0, F1) lie in [w0 + (F0 - 1.5) wres - dmax p, w0 + (F1 + 0.5) wres + dmax p]
+   -- the kernel's own margins; membership is decided line by line there, this is a superset.  The bound covers the batch
+   (its largest layer pressure, from the host copy of the column states) with room to spare, so the table is built once. */
+static int tile_ranges(GasOptics_t *go, int ncol, GrtGasOpticsArgs *a)
+{
+    GrtGasOpticsImpl *im = impl_of(go);
+    GrtColumnLayout const *lo = &im->layout;
+    double pmax = 0.;
+    for (int c = 0; c < ncol && im->colstate_h != NULL; ++c)
+    {
+        double const *lay = im->colstate_h + (size_t)c*lo->stride + lo->off_lay;
+        for (int i = 0; i < go->num_layers; ++i)
+        {
+            double const p = fabs(lay[(size_t)i*4]);
+            pmax = p > pmax ? p : pmax;
+        }
+    }
+    uint64_t const tiles = (a->nw + (uint64_t)a->tile - 1)/(uint64_t)a->tile;
+    if (im->tile_ranges_d == NULL || im->tr_tile != a->tile || im->tr_tiles != tiles || !(pmax <= im->tr_pbound))
+    {
+        double const pbound = pmax*1.25 > 2. ? pmax*1.25 : 2.;
+        uint32_t *host = malloc(sizeof(uint32_t)*2*(size_t)tiles);
+        if (host == NULL)
+        {
+            GRT_FAIL(GRTCODE_NULL_ERR, "out of host memory for %zu tile ranges.", (size_t)tiles);
+        }
+        double const *v = im->sorted_v0_h;
+        uint64_t const n = im->store.n;
+        double const shift = im->store.dmax*pbound;
+        for (uint64_t t = 0; t < tiles; ++t)
+        {
+            double const F0 = (double)(t*(uint64_t)a->tile);
+            double const F1 = (double)((t + 1)*(uint64_t)a->tile < a->nw ? (t + 1)*(uint64_t)a->tile : a->nw);
+            double const wlo = a->w0 + (F0 - 1.5)*a->wres - shift, whi = a->w0 + (F1 + 0.5)*a->wres + shift;
+            uint64_t l = 0, h = n;
+            while (l < h)
+            {
+                uint64_t const m = (l + h) >> 1;
+                if (v[m] < wlo) l = m + 1; else h = m;
+            }
+            host[2*t] = (uint32_t)l;
+            h = n;
+            while (l < h)
+            {
+                uint64_t const m = (l + h) >> 1;
+                if (v[m] <= whi) l = m + 1; else h = m;
+            }
+            host[2*t + 1] = (uint32_t)l;
+        }
+        GRT_TRY(grt_dev_sync(go->device, grt_dev_stream(go->device)));      /* (a launch may still read the old table) */
+        GRT_TRY(grt_dev_free(go->device, im->tile_ranges_d));
+        im->tile_ranges_d = NULL;
+        int rc = grt_dev_alloc(go->device, (void **)&im->tile_ranges_d, sizeof(uint32_t)*2*(size_t)tiles);
+        void *s = grt_dev_stream(go->device);
+        if (rc == GRTCODE_SUCCESS) rc = grt_dev_upload(go->device, im->tile_ranges_d, host, sizeof(uint32_t)*2*(size_t)tiles, s);
+        if (rc == GRTCODE_SUCCESS) rc = grt_dev_sync(go->device, s);
+        free(host);
+        GRT_TRY(rc);
+        im->tr_tile = a->tile;
+        im->tr_tiles = tiles;
+        im->tr_pbound = pbound;
+    }
+    a->tile_ranges = im->tile_ranges_d;
+    return GRTCODE_SUCCESS;
+}
+
 /* Deterministic mode (grt_ext.h): -1 = follow GRT_DETERMINISTIC in the environment (read at every launch, so that a
    test can switch it inside one process), 0 / 1 = forced off / on. */
 static int g_deterministic = -1;
@@ -1753,6 +1838,10 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
         {
             a->probe = im->probe;
         }
+    }
+    if (a->fast == 3 && im->sorted_v0_h != NULL && im->store.n > 0 && im->store.n < 0xffffffffull)
+    {
+        GRT_TRY(tile_ranges(go, ncol, a));
     }
     if (grt_deterministic())
     {

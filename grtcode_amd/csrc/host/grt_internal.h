@@ -80,6 +80,11 @@ typedef struct GrtGasOpticsImpl
     unsigned long store_tips_generation;   /* partition-sum provider the store's strengths were scaled with */
     GrtLineStore store;            /* device SoA, sorted by centre */
     void *store_block;             /* single device allocation backing `store` */
+    double *sorted_v0_h;           /* host copy of store.v0 (sorted centres): the per-tile candidate ranges are searched here */
+    uint32_t *tile_ranges_d;       /* device [tiles][2], see GrtGasOpticsArgs.tile_ranges; rebuilt when tile / pressure bound change */
+    int tr_tile;
+    uint64_t tr_tiles;
+    double tr_pbound;
     /* sweep methods only: one store per molecule (each sorted by centre), prep/sort scratch, bin arrays */
     GrtLineStore mstore[NUM_MOLS];
     void *mstore_block[NUM_MOLS];
