@@ -1291,6 +1291,12 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
     // (uniform per workgroup, but kept in VECTOR registers: an fp32 multiply or fma with a scalar operand runs at half rate)
     [[maybe_unused]] float kh = 0.f, kl = 0.f, c2t = 0.f, pw = 0.f, pavg_f = 0.f, a_norm = 0.f, wres_v = 0.f, inv_wres_v = 0.f;
     [[maybe_unused]] bool stim_tile = false, farir_tile = false, corrected_s = false;
+    // what the near field of this (tile, layer) is made of, from bounds on its lines' Doppler widths -- decided once per
+    // workgroup (each per-wave vote cost a compare, two scalar instructions and the expressions it tested):
+    //   lreg_t      only a line's own grid point can be anything but Lorentzian (half a grid step >= XLIM0 Doppler units)
+    //   v1_t        all seven points of every line lie in Humlicek region 1
+    //   nc_one_t    only a line's own grid point can be a near-centre point (|x| < XLIM1); nc_three_t: or its two neighbours
+    [[maybe_unused]] bool lreg_t = false, v1_t = false, nc_one_t = false, nc_three_t = false;
     auto uniform_flag = [](bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; };
     if constexpr (LEANP > 0)
     {
@@ -1336,6 +1342,26 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
             stim_tile = uniform_flag(x2_tile > -21.);
             farir_tile = uniform_flag(x2_tile > -1.1);
             corrected_s = uniform_flag(corrected);
+            {
+                double dop_hi = 0., dop_lo = 1e300;
+                for (int sl = 0; sl < a.lay.num_slots; ++sl)
+                {
+                    double const d = ((double)0.83255461115f/(double)kSqrln2)*ms_l[sl*4 + 3];
+                    dop_hi = fmax(dop_hi, d);
+                    dop_lo = d > 0. ? fmin(dop_lo, d) : dop_lo;
+                }
+                // grid step in Doppler units, wr = wres REPWID = wres/(centre x doppler factor), over the tile's lines (one cell
+                // and the largest shift of margin either side)
+                double const nu_lo = fmax(a.w0 + ((double)F0 - 1.5)*a.wres - a.lines.dmax*fabs(lay[0]), 1e-3);
+                double const nu_hi = a.w0 + ((double)F1 + 0.5)*a.wres + a.lines.dmax*fabs(lay[0]);
+                double const wr_min = dop_hi > 0. ? a.wres/(nu_hi*dop_hi) : 0.;
+                double const wr_max = dop_lo < 1e300 ? a.wres/(nu_lo*dop_lo) : 1e300;
+                // XLIM0^2 = 15100 + y (40 - 3.6 y) <= 15211.2 (y = 5.56), >= 15100 for y <= 4; XLIM1^2 <= 164 (RFM_voigt.c:109-118)
+                lreg_t = uniform_flag(0.25*wr_min*wr_min >= 1.003*15211.2);
+                v1_t = uniform_flag(corrected && 12.25*wr_max*wr_max < 0.999*15100.);
+                nc_one_t = uniform_flag(0.25*wr_min*wr_min >= 164.1);
+                nc_three_t = uniform_flag(2.25*wr_min*wr_min >= 164.1);
+            }
         }
     }
 
@@ -1416,7 +1442,6 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
             }
             int cr = 0;                         // the row's reference cell: its lines sit in cells cr, cr + 1 (sorted store)
             bool one_cell = true;               // (wave-uniform) so far every line of every row sat in its row's first cell
-            unsigned long long any_valid = 0ull;
             unsigned long long handed[LEANP] = {};
 #ifdef GRT_LEAN_UNROLL
 #pragma unroll
@@ -1500,7 +1525,6 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                         handed[q] = p == q ? hm : handed[q];
                     }
                 }
-                any_valid |= __ballot(valid);
                 // a lane without a line of its own here works on a harmless one (no infinities: 0 x inf would poison the sums)
                 amp = valid ? amp : 0.f;
                 y = valid ? y : 1.f;
@@ -1605,10 +1629,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                 // ---- near field: the line's seven points r = -3 .. 3 (v[r + 3]; x = r wr + ndcr, the general form's canonical
                 // x), by what the wave's lines have there: only Lorentzians but for a line's own point | region 1 throughout
                 // | the point's region picks the formula.  Near-centre points (|x| < XLIM1) are left out and noted in ncm. ----
-                float const e1 = (1.f - adl)*wr;                    // |x| of the second-nearest grid point
-                float const e35 = 3.5f*wr;
-                bool const lreg = __ballot(valid & !(e1*e1 >= 1.002f*x0q)) == 0ull;     // only a line's own point can be anything but Lorentzian
-                bool const nc_one = __ballot(valid & !(e1*e1 >= xq_near)) == 0ull;      // ... can be a near-centre point
+                bool const lreg = lreg_t, nc_one = nc_one_t;
                 float v[7];
                 unsigned ncm = 0u;
 #ifdef GRT_ABL_NOSLOTS
@@ -1644,7 +1665,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
 #endif
                 {
                     float const acl = amp*cl;
-                    if (__ballot(valid & !(e35*e35 < x0q)) == 0ull)
+                    if (v1_t)
                     {
                         // region 1 throughout: K = cl (A0 + XQ)/(D0 + XQ (D2 + XQ)) (RFM_voigt.c:172-183)
 #pragma unroll
@@ -1670,14 +1691,13 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                             v[k] = (acl*(a0 + xq))*__builtin_amdgcn_rcpf(fmaf(xq, D2 + xq, D0));
                         }
                     }
-                    float const e2 = (2.f - adl)*wr;                // |x| of the nearest point two steps from the line's own
                     if (nc_one)
                     {
                         bool const nc = ndcr*ndcr < xq_near;
                         v[3] = nc ? 0.f : v[3];
                         ncm = (nc & valid) ? 8u : 0u;
                     }
-                    else if (__ballot(valid & !(e2*e2 >= xq_near)) == 0ull)
+                    else if (nc_three_t)
                     {
                         // (grid steps of 8.6 Doppler widths and more: the own point and its two neighbours)
 #pragma unroll
@@ -1722,7 +1742,8 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                 // ---- rare: a line in neither of its row's cells adds lane by lane; region-1 points beyond the near field of
                 // lines that are not folded (pre-pass 2 of general_block): such a line has |dl| wr > 12.5, so region 1
                 // (|x| < XLIM0 <= 123.4) ends within five grid steps ----
-                if (__ballot(odd | pre2) != 0ull)
+                // (a wave whose lines all sit in their row's first cell has no such lane)
+                if ((!single || corrected_s) && __ballot(odd | pre2) != 0ull)
                 {
                     if (odd)
                     {
@@ -1803,13 +1824,9 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                     ++xcount;
                 }
             }
-            if (any_valid == 0ull)
-            {
-                return;
-            }
             // ---- the row sums: sixteen moment sums (eight per cell) end in sixteen lanes, eight near-field sums in eight ----
 #ifdef GRT_ABL_NOREDUCE
-            if (any_valid != 0ull) return;
+            if (rem > 0) return;
 #endif
             {
                 float t;

@@ -196,3 +196,31 @@ def test_shortwave_extreme_optical_depths(oracle, device, tauval):
     assert np.max(np.abs(up - wu)) / scale < 1e-12 and np.max(np.abs(dn - wd)) / scale < 1e-12
     sw.destroy()
     o.destroy()
+
+
+def test_flux_rows_opt_in_copies_only_the_rows_asked_for(oracle, device, monkeypatch):
+    """GRT_FLUX_ROWS=toa,sfc,<k>: a caller that integrates three levels gets those rows of
+    flux_up / flux_down and keeps the others as it had them -- instead of 2 V n doubles over PCIe per call."""
+    L, w0, wn, dw = 12, 1.0, 3250.0, 1.0
+    rng = np.random.default_rng(3)
+    grid = api.create_spectral_grid(w0, wn, dw)
+    n = grid.n
+    col = syn.profile(4, L + 1)
+    tau, omega, g = random_optics(rng, L, n)
+    emis = rng.uniform(0.9, 1.0, n)
+    o = api.OpticsObject(L, grid, device)
+    o.update(tau, omega, g)
+    lw = api.LongwaveObject(L + 1, grid, device)
+    full_up, full_dn = lw.fluxes(o, col["t_surf"], col["t_layer"], col["t"], emis)
+    monkeypatch.setenv("GRT_FLUX_ROWS", "toa, sfc,5")
+    up, dn = np.full((L + 1, n), -7.0), np.full((L + 1, n), -7.0)
+    lw.fluxes(o, col["t_surf"], col["t_layer"], col["t"], emis, out=(up, dn))
+    rows = [0, L, 5]
+    others = [k for k in range(L + 1) if k not in rows]
+    assert np.array_equal(up[rows], full_up[rows]) and np.array_equal(dn[rows], full_dn[rows])
+    assert np.all(up[others] == -7.0) and np.all(dn[others] == -7.0)
+    monkeypatch.setenv("GRT_FLUX_ROWS", "toa,99")                 # outside 0..L: reported, everything copied
+    up2, dn2 = lw.fluxes(o, col["t_surf"], col["t_layer"], col["t"], emis)
+    assert np.array_equal(up2, full_up) and np.array_equal(dn2, full_dn)
+    lw.destroy()
+    o.destroy()
