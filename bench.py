@@ -205,7 +205,7 @@ def reference_abi_rate(wl, ncol=3):
     out["note"] = ("one column per call, synchronous, 2*V*n doubles of spectral flux copied to the host per solver call "
                    "(49 MB per shortwave column); fast3 = what an unchanged driver gets (the default of a new object), fast0 = the same "
                    "driver with GRT_GAS_OPTICS_FAST=0 in its environment (the reference's operation order); the real binary: "
-                   "profiles/r3_reference_driver_timing.json")
+                   "profiles/r4_reference_driver_timing.json")
     for o in (lw, sw):
         o.destroy()
     for name in objs:
@@ -642,7 +642,8 @@ def main():
                     sq = tj["gas_optics_sw"].get("sq", {})
             except Exception:
                 traffic = None
-        line_kernel = "gas_optics_mp_kernel" if args.fast in (1, 3) else "gas_optics_kernel"
+        lean_on = args.fast == 3 and os.environ.get("GRT_LEAN", "1") != "0" and (lw_grid[2], sw_grid[2]) == (1.0, 1.0)
+        line_kernel = ("gas_optics_lean_kernel" if lean_on else "gas_optics_mp_kernel") if args.fast in (1, 3) else "gas_optics_kernel"
         line = {
             "metric": "columns/sec (60-layer, 1 cm\u207b\u00b9 LBL, LW+SW)" if (lw_grid[2], sw_grid[2]) == (1.0, 1.0) else
                       f"columns/sec (60-layer LBL, LW @{lw_grid[2]:g} + SW @{sw_grid[2]:g} cm\u207b\u00b9)",

@@ -60,8 +60,23 @@ def _run(cmd):
     return r.stdout
 
 
+def _flags_changed():
+    """The flags the objects in lib/obj were built with are kept next to them: a build under other flags (GRT_HIPFLAGS_EXTRA
+    set or dropped, a new default) rebuilds everything instead of silently reusing objects of the other configuration."""
+    import hashlib
+    stamp = os.path.join(OBJ, "flags.sha256")
+    want = hashlib.sha256("\0".join(CFLAGS + ["|"] + HIPFLAGS).encode()).hexdigest()
+    have = open(stamp).read().strip() if os.path.exists(stamp) else None
+    if have != want:
+        with open(stamp, "w") as f:
+            f.write(want + "\n")
+        return have is not None or any(n.endswith(".o") for n in os.listdir(OBJ))
+    return False
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
+    force = force or _flags_changed()
     headers = [os.path.join(ROOT, "include", h) for h in ("grtcode_hip_api.h", "grt_ext.h")]
     headers += [os.path.join(CSRC, "grt_kernels.h"), os.path.join(CSRC, "hip", "gas_optics_dev.h"), os.path.join(CSRC, "host", "grt_internal.h"),
                 os.path.join(CSRC, "host", "grt_molecule_table.h")]

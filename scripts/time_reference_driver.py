@@ -60,7 +60,7 @@ def column_text(c, V):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--columns", type=int, nargs=2, default=[40, 240])
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r3_reference_driver_timing.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r4_reference_driver_timing.json"))
     args = ap.parse_args()
     V = W.NUM_LEVELS
     root = tempfile.mkdtemp(prefix="grt_drv_")
@@ -73,7 +73,9 @@ def main():
     print(f"wrote {par}: {os.path.getsize(par) / 1e6:.0f} MB in {time.perf_counter() - t0:.0f} s", file=sys.stderr, flush=True)
     files, _ = W.write_tables(root, sw=True)
     runs = {}
-    for fast in ("3", "0"):
+    # "3rows": the default arithmetic with the driver's opt-in GRT_FLUX_ROWS=toa,sfc (only the rows `-integrated` integrates
+    # cross PCIe: INTEGRATION.md section 7)
+    for fast in ("3", "3rows", "0"):
         for n in args.columns:
             cols = os.path.join(root, f"columns_{n}.txt")
             with open(cols, "w") as f:
@@ -83,7 +85,9 @@ def main():
                    "-O2-N2", files["cia_o2n2"], "-O2-O2", files["cia_o2o2"], "-a", "0.2", "-e", "0.98",
                    "-w-lw", "1", "-W-lw", "3250", "-r-lw", "1", "-w-sw", "1", "-W-sw", "50000", "-r-sw", "1",
                    "-integrated", "-o", os.path.join(root, f"out_{fast}_{n}.txt")]
-            env = dict(os.environ, GRT_GAS_OPTICS_FAST=fast, GRT_TIPS_QUIET="1", GRT_HITRAN_CACHE_DIR=root)
+            env = dict(os.environ, GRT_GAS_OPTICS_FAST=fast[0], GRT_TIPS_QUIET="1", GRT_HITRAN_CACHE_DIR=root)
+            if fast == "3rows":
+                env["GRT_FLUX_ROWS"] = "toa,sfc"
             wall = 1e30
             for attempt in range(3):            # (the first run of all also writes the line-list index; best of three)
                 t0 = time.perf_counter()
@@ -98,7 +102,7 @@ def main():
                      "examples/driver_app.c, libgrtcode_hip.so)", "options": "-integrated, LW 1-3250 + SW 1-50000 cm-1 @1 cm-1, 61 levels",
            "lines": {"lw_band": int(sum((ln["v0"] <= 3250.0).sum() for ln in lists.values())),
                      "sw_band": int(sum(ln["v0"].size for ln in lists.values()))}, "runs": runs}
-    for fast in ("3", "0"):
+    for fast in ("3", "3rows", "0"):
         dt = (runs[f"fast{fast}_{n2}_columns_wall_s"] - runs[f"fast{fast}_{n1}_columns_wall_s"]) / (n2 - n1)
         out[f"fast{fast}"] = {"seconds_per_column": dt, "columns_per_s": 1.0 / dt,
                               "startup_s": runs[f"fast{fast}_{n1}_columns_wall_s"] - n1 * dt}

@@ -74,3 +74,46 @@ def test_rccl_path_at_world_size_one_costs_about_one_percent():
     assert forced["value"] >= 0.98 * plain["value"]
     slower = forced["kernel_ms_per_step"]["gas_optics_sw"] / plain["kernel_ms_per_step"]["gas_optics_sw"]
     assert 1.0 <= slower < 1.03                     # the loss sits in the kernels' own durations
+
+
+# ---- round 4 (profiles/r4_*) ------------------------------------------------------------------------------------------- #
+def test_round4_line_prices_the_kernel_against_what_binds_it_and_checks_a_discriminating_column():
+    """VERDICT r3, task 2: `roofline` is the vector-issue view (the HBM view stays as `roofline_hbm`), and the parity leg
+    carries the physically scaled list's column 0 -- an atmosphere whose fluxes depend on tau."""
+    line = load("r4_bench_line.json")
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert line["metric"].split(" at ")[0] in base["metric"] and line["unit"] == "columns/s" and line["scaling"] == "weak"
+    assert line["n_gpus"] == 1 and line["steps"] * line["ms_per_step"] >= 2800.0 and line["dtype"] == "f64"
+    assert line["ms_per_step"] <= 145.0 and line["value"] >= 440.0                       # VERDICT r3, task 1
+    assert len(line["ms_per_step_by_rank"]) == 1
+    r = line["roofline"]
+    assert r["bound"] == "valu_issue" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.3 < r["frac"] < 1.0
+    assert "not measured in this run" in r["instructions_source"] and r["traffic"] > 0
+    h = line["roofline_hbm"]
+    assert h["bound"] == "hbm" and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-12
+    v = line["roofline_valu"]
+    assert v["instructions_per_64_lines"] <= 780                                          # VERDICT r3, task 1's alternative
+    p = line["parity"]
+    assert p["kind"] == "reference" and p["ok"] is True and p["max_abs_flux_diff_w_m2"] <= 1e-3 and p["max_tau_err_of_layer_max"] <= 2e-6
+    q = p["physical_list"]
+    assert q["ok"] is True and q["max_abs_flux_diff_w_m2"] <= 1e-3 and 0.62 < q["rsds_over_rsdt"] < 0.75
+    assert 250.0 < q["reference_fluxes_w_m2"]["rlut"] < 300.0
+    assert q["tau_lw"]["of_layer_max"] <= 2e-6 and q["tau_sw"]["of_layer_max"] <= 2e-6
+    c = line["cpu_baseline"]
+    assert c["kind"] == "reference" and c["cores"] >= 1 and c["value"] > 0 and c["one_thread"]["cores"] == 1
+    cols = line["config"]["columns_per_step"]
+    assert abs(line["value"] - cols / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-9
+
+
+def test_round4_lines_of_the_other_configurations():
+    g3 = load("r4_g3_pipeline_bench_line.json")                  # the ~3M-point grid through the whole pipeline (VERDICT r3, task 3-i)
+    assert "0.001" in g3["config"]["workload"] and g3["value"] > 15.0
+    era = load("r4_era5_like_bench_line.json")                   # config 5's grids at 64 columns per step (task 8)
+    assert "@0.1 cm-1" in era["config"]["workload"] and "@10 cm-1" in era["config"]["workload"] and era["config"]["columns_per_step"] == 64
+    assert era["value"] > 400.0
+    forced, plain = load("r4_rccl_world1_bench_line.json"), load("r4_bench_line.json")
+    assert forced["rccl_ranks"] == 1 and forced["collective"]["gathers_in_timed_region"] == 1 and forced["value"] >= 0.98 * plain["value"]
+    strong = load("r4_strong_100_columns_bench_line.json")
+    assert strong["scaling"] == "strong" and strong["config"]["columns_per_step"] == 100
+    drv = load("r4_reference_driver_timing.json")                # the unchanged driver binary; with its opt-in for three rows
+    assert drv["fast3"]["columns_per_s"] > 150.0 and drv["fast3rows"]["columns_per_s"] > drv["fast3"]["columns_per_s"]
