@@ -512,6 +512,8 @@ def main():
     job = torch.zeros(slots, max(per, 1), nfl, dtype=torch.float64, device=dev_t)
     gathered = [torch.zeros_like(job) for _ in range(world)] if (use_dist and rank == 0) else None
     stream = None if placeholder else torch.cuda.ExternalStream(wl.pipe.stream(), device=dev_t)
+    if not placeholder:
+        torch.cuda.synchronize()        # (the zero fills ran on torch's stream; the library's streams are non-blocking: order them once)
     row_bytes = 8 * nfl
     gathers = {"count": 0}
     gathered_host = [torch.zeros(slots, max(per, 1), nfl, dtype=torch.float64) for _ in range(world)] if (use_dist and rank == 0 and rehearsal) else None
@@ -544,6 +546,10 @@ def main():
                 api.device_synchronize(device)   # (one wait per gather, i.e. per job: every lane has delivered)
             with torch.cuda.stream(stream):      # RCCL gather ordered after the kernels on the library stream, no host sync
                 dist.gather(job, gathered if rank == 0 else None, dst=0)
+            if lanes > 1:
+                # the gather reads `job` on lane 0's stream; the next step's launches on the other lanes write its slots and
+                # are not ordered after it: wait here (several lanes AND several gathers per job is an exploration mode)
+                stream.synchronize()
 
     def barrier():
         if not placeholder:
