@@ -391,15 +391,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cols", type=int, default=int(os.environ.get("GRT_BENCH_COLS", 64)), help="columns per GPU per step (weak scaling)")
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("GRT_BENCH_CHUNK", 64)), help="columns per launch of the pipeline "
-                    "(measured on G1: 8 -> 363.5, 32 -> 367.7, 64 -> 368.7 columns/s: fewer launch tails)")
+                    "(round 4, G1, one stream: 32 -> 457.5, 64 -> 455.1 columns/s; the roofline's counters were taken at 64)")
     ap.add_argument("--fast", type=int, default=int(os.environ.get("GRT_BENCH_FAST", 3)),
                     help="3: fused form, far wings by cell moments, two passes (production); 1: the same in one pass; "
                          "2: fused form, ring kernel; 0: reference operation order")
     ap.add_argument("--columns", type=int, default=0, help="strong scaling: a step is this fixed number of columns, sharded "
                     "over the ranks (0: weak scaling, --cols columns per GPU per step)")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("GRT_BENCH_LANES", 1)), help="batches in flight: launches alternate between this many "
-                    "pipelines, each on a stream of its own (default 1: one pipeline, one stream; measured on G1: 2 lanes +0.7 %, "
-                    "3 lanes +1.4 % -- the end of a launch's work is not idle enough to hide much behind)")
+                    "pipelines, each on a HIP stream of its own, so that the end of one launch -- its last workgroups, the far-field "
+                    "gather, the solvers -- overlaps the next launch's line kernel (round 4, G1: one stream 455-457 columns/s, two "
+                    "streams x 32 columns 463-467, three x 22: 467.8 -- profiles/r4_two_streams_bench_line.json).  Default 1: with more, "
+                    "the kernels' durations overlap (kernel_ms_per_step sums to more than ms_per_step) and the roofline's "
+                    "per-launch duration no longer is the kernel's own")
     ap.add_argument("--gather-every", type=int, default=0, help="steps between gathers of the output fluxes to rank 0 "
                     "(0: ONE gather, after the last step -- the job's output, as the north star words it)")
     ap.add_argument("--tile", type=int, default=0, help="exploration only: wavenumbers (cells) per workgroup of the line kernel")
@@ -486,7 +489,7 @@ def main():
         sw_grid = (W.SW_GRID[0], W.SW_GRID[1], args.sw_dw or W.SW_GRID[2])
         # --lanes K > 1: K pipelines, each with gas-optics objects and buffers of its own on a stream of its own; launches
         # alternate between them, so that the end of one launch's work (far-field gather, solvers) can overlap the next
-        # launch's line kernel.  Same work per step; nothing is shared between the lanes.  Exploration: the default is 1.
+        # launch's line kernel.  Same work per step; nothing is shared between the lanes.  Default 1 (two lanes: +2 %, but overlapping kernel durations).
         lanes = max(1, min(args.lanes, 4, -(-max(count, 1) // chunk)))
         os.environ.setdefault("GRT_LINES_CACHE", os.path.join(os.environ.get("TMPDIR", "/tmp"), f"grt_lines_cache_{os.getuid()}"))
         wls = []
