@@ -38,17 +38,23 @@ typedef struct GrtLineStore
     float yair_max[GRT_MAX_SLOTS];   /* [cm-1 atm-1]: together a bound on the Lorentz half-width of any */
     float yself_max[GRT_MAX_SLOTS];  /* line in a layer (kernels.c:105-106), see k_gas_optics_mp.hip */
     /* Packed fp32 records of the same lines, in the same order, for the lean first pass of the two-pass moment kernel
-       (k_gas_optics_mp.hip: lean_block) -- built for ONE grid (lean_w0, lean_wres); NULL: none.
-         lean_a [n][4]: d0 = offset of the UNSHIFTED centre from its nearest grid point, in grid steps, [-0.5, 0.5);
-                        c0 = that grid point's index floor((v0 - w0)/wres + 0.5) (int32 bit pattern);
-                        v0 as f32;  s0 * 2^GRT_LEAN_S0_SHIFT as f32
-         lean_b [n][4]: yair, yself, en, delta
-         lean_c [n]   : bits 0-7   index of the temperature exponent, nexp*100 (255: not a whole number of hundredths below 128),
-                        bits 8-13  molecule slot,  bits 14-23  slot*GRT_MAX_ISO + iso - 1,
+       (k_gas_optics_mp.hip: lean_block) -- built for ONE grid (lean_w0, lean_wres); NULL: none.  The lean loop takes TWO
+       lines per lane and does their arithmetic with gfx950's packed fp32 instructions (v_pk_fma_f32 ...: one instruction,
+       two lines), so the records come PAIR-INTERLEAVED: pair q = lines 2q, 2q + 1 (an odd store's last pair repeats the
+       last line with its strength zeroed), every field of the two lines side by side -- a 16-byte load puts each field
+       in an aligned register pair, the operand form of the packed instructions.
+         lean_a [2][npair][4]: plane 0: d0 of line 2q, of line 2q + 1, c0 of line 2q, of line 2q + 1 -- d0 = offset of the
+                        UNSHIFTED centre from its nearest grid point, in grid steps, [-0.5, 0.5); c0 = that grid point's
+                        index floor((v0 - w0)/wres + 0.5) (int32 bit pattern);
+                        plane 1: v0 as f32 (twice), s0 * 2^GRT_LEAN_S0_SHIFT as f32 (twice)
+         lean_b [2][npair][4]: plane 0: yair (twice), yself (twice); plane 1: en (twice), delta (twice)
+         lean_c [npair][2]: per line: bits 0-7   index of the temperature exponent, nexp*100 (255: not a whole number of
+                        hundredths below 128), bits 8-13  molecule slot,  bits 14-23  slot*GRT_MAX_ISO + iso - 1,
                         bit 31     the line always takes the general path (strength outside the scaled fp32 range, ...) */
     float const *lean_a;
     float const *lean_b;
     uint32_t const *lean_c;
+    uint64_t lean_npair;
     double lean_w0, lean_wres;
 } GrtLineStore;
 #define GRT_LEAN_S0_SHIFT 96

@@ -78,6 +78,18 @@ __device__ __forceinline__ int dpp_i(int v)
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
 }
 
+// Two fp32 values in an aligned register pair: the operand form of gfx950's packed fp32 instructions (v_pk_fma_f32,
+// v_pk_mul_f32, v_pk_add_f32: one instruction, both halves; measured 4.6 cycles per wave against 2 x 3.3-4.2 for the plain
+// ones, profiles/r4_valu_mix2.txt).  The lean line loop keeps its two lines per lane in the halves.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f splat2(float x) { return (v2f){x, x}; }
+__device__ __forceinline__ v2f rcp2(v2f a) { return (v2f){__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}; }
+__device__ __forceinline__ v2f exp2_2(v2f a) { return (v2f){__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)}; }
+__device__ __forceinline__ v2f rint2(v2f a) { return (v2f){rintf(a.x), rintf(a.y)}; }
+__device__ __forceinline__ unsigned long long ballot_b(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+__device__ __forceinline__ v2f sel2(bool c0, bool c1, v2f a, v2f b) { return (v2f){c0 ? a.x : b.x, c1 ? a.y : b.y}; }
+
 // Wave-wide integer max as a scalar: rotations inside the rows of 16 lanes (every lane of a row
 // ends up with the row's extreme, whatever the direction of row_ror), then the four rows on the
 // scalar unit.
@@ -200,10 +212,12 @@ constexpr int kLeanMaxP = 4;
 struct LeanRaw
 {
     unsigned long long xl_mask[kWaves][kLeanListCap][kLeanMaxP];
-    unsigned j[kWaves][kRawCap];
-    float amp[kWaves][kRawCap];
+    unsigned j[kWaves][kRawCap];             // the line
+    float amp[kWaves][kRawCap];              // S(T) N_s
+    float y[kWaves][kRawCap];
+    float delta[kWaves][kRawCap];            // its pressure shift coefficient
+    unsigned idx[kWaves][kRawCap];           // accumulator index f - A0 | the point's k << 12 | the line's molecule slot << 16
     unsigned xl_base[kWaves][kLeanListCap];
-    unsigned short idx[kWaves][kRawCap];
 };
 
 // Near-centre points (Humlicek regions 1-4 inside XLIM1) wait in per-wave LDS queues, one queue per
@@ -1278,32 +1292,35 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
     // but absurd pressures') and its tile lies inside the grid (no window is clipped); otherwise every block of lines goes
     // through general_block as before.
     // ---------------------------------------------------------------------------------------------------------
+    static_assert(LEANP == 0 || LEANP == 2, "the lean loop keeps the two lines of a lane in the halves of packed registers");
     constexpr int kLinesPerLane = LEANP > 0 ? LEANP : 1;
-    uint64_t const walk_first = a.deterministic ? (wave == 0 ? jbeg : jend) : jbeg + (uint64_t)wave*64*kLinesPerLane;
-    unsigned const walk_stride = (a.deterministic ? 64u : (unsigned)kBlock)*kLinesPerLane;
     [[maybe_unused]] bool lean_ok = false;
-    [[maybe_unused]] float4 *msf = nullptr;
-    [[maybe_unused]] float2 *qnf = nullptr;
+    // (per-slot and per-isotopologue tables, one array per quantity: a line's look-up then lands in its half of a register pair)
+    [[maybe_unused]] float *msf = nullptr;
+    [[maybe_unused]] float *qnf = nullptr;
     [[maybe_unused]] float *ptabf = nullptr;
     [[maybe_unused]] LeanRaw *raw = nullptr;
     [[maybe_unused]] int rawcount = 0;              // wave-uniform: entries waiting in the raw queue
     [[maybe_unused]] int xcount = 0;                // wave-uniform: blocks with lines handed over to general_block
     // (uniform per workgroup, but kept in VECTOR registers: an fp32 multiply or fma with a scalar operand runs at half rate)
     [[maybe_unused]] float kh = 0.f, kl = 0.f, c2t = 0.f, pw = 0.f, pavg_f = 0.f, a_norm = 0.f, wres_v = 0.f, inv_wres_v = 0.f;
-    [[maybe_unused]] bool stim_tile = false, farir_tile = false, corrected_s = false;
     // what the near field of this (tile, layer) is made of, from bounds on its lines' Doppler widths -- decided once per
-    // workgroup (each per-wave vote cost a compare, two scalar instructions and the expressions it tested):
-    //   lreg_t      only a line's own grid point can be anything but Lorentzian (half a grid step >= XLIM0 Doppler units)
-    //   v1_t        all seven points of every line lie in Humlicek region 1
-    //   nc_one_t    only a line's own grid point can be a near-centre point (|x| < XLIM1); nc_three_t: or its two neighbours
-    [[maybe_unused]] bool lreg_t = false, v1_t = false, nc_one_t = false, nc_three_t = false;
+    // workgroup (each per-wave vote cost a compare, two scalar instructions and the expressions it tested), kept as bits of
+    // ONE scalar word (a flag as a lane mask of its own is two scalar registers, and the loop is short of those):
+    //   stim / farir the stimulated-emission factor is not 1 to fp32 / needs its series
+    //   corrected    region 1 beyond the near field is folded into the moments
+    //   lreg         only a line's own grid point can be anything but Lorentzian (half a grid step >= XLIM0 Doppler units)
+    //   v1           all seven points of every line lie in Humlicek region 1
+    //   nc_one       only a line's own grid point can be a near-centre point (|x| < XLIM1); nc_three: or its two neighbours
+    [[maybe_unused]] unsigned tflags = 0u;
+    enum : unsigned { kTfStim = 1u, kTfFarir = 2u, kTfCorrected = 4u, kTfLreg = 8u, kTfV1 = 16u, kTfNcOne = 32u, kTfNcThree = 64u };
     auto uniform_flag = [](bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; };
     if constexpr (LEANP > 0)
     {
         size_t const lean_off = ((size_t)(reinterpret_cast<unsigned char *>(invr + 1) - smem) + 15) & ~(size_t)15;
-        msf = reinterpret_cast<float4 *>(smem + lean_off);                        // [num_slots]: ps, p - ps, sqrt(ln 2) x doppler factor
-        qnf = reinterpret_cast<float2 *>(msf + a.lay.num_slots);                  // [num_slots][GRT_MAX_ISO]: N_s/Q as mantissa, exponent
-        ptabf = reinterpret_cast<float *>(qnf + (size_t)a.lay.num_slots*GRT_MAX_ISO);   // [kPowTable]
+        msf = reinterpret_cast<float *>(smem + lean_off);                         // [4][num_slots]: ps | p - ps | sqrt(ln 2) x doppler factor | -
+        qnf = msf + 4*a.lay.num_slots;                                            // [2][num_slots][GRT_MAX_ISO]: N_s/Q as mantissa | exponent
+        ptabf = qnf + 2*(size_t)a.lay.num_slots*GRT_MAX_ISO;                      // [kPowTable]
         raw = reinterpret_cast<LeanRaw *>(ptabf + kPowTable);
         lean_ok = uniform_flag(a.lean != 0 && use_moments && R == 3 && F0 >= 8 && F1 + 8 <= nw_i && fsteps >= 8 && halo >= 8
                                && a.lines.lean_a != nullptr);
@@ -1312,14 +1329,18 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
             for (int i = tid; i < a.lay.num_slots; i += kBlock)
             {
                 // (third entry: alpha of kernels.c:127 over the line centre, divided by RFM_voigt.c:94's sqrt(ln 2) -- 1/REPWID per cm-1)
-                msf[i] = make_float4((float)ms_l[4*i], (float)ms_l[4*i + 1], (float)(((double)0.83255461115f/(double)kSqrln2)*ms_l[4*i + 3]), 0.f);
+                msf[i] = (float)ms_l[4*i];
+                msf[a.lay.num_slots + i] = (float)ms_l[4*i + 1];
+                msf[2*a.lay.num_slots + i] = (float)(((double)0.83255461115f/(double)kSqrln2)*ms_l[4*i + 3]);
             }
             for (int i = tid; i < a.lay.num_slots*GRT_MAX_ISO; i += kBlock)
             {
                 double const v = q_l[i]*ms_l[(i/GRT_MAX_ISO)*4 + 2];                 // N_s/Q(T): kernels.c:85, :459
                 int e = 0;
                 double const m = frexp(v, &e);                                      // v = m 2^e, 1/2 <= m < 1
-                qnf[i] = (v > 0. && v < 1e300) ? make_float2((float)(2.*m), (float)(e - 1 - GRT_LEAN_S0_SHIFT)) : make_float2(0.f, 0.f);
+                bool const ok = v > 0. && v < 1e300;
+                qnf[i] = ok ? (float)(2.*m) : 0.f;
+                qnf[a.lay.num_slots*GRT_MAX_ISO + i] = ok ? (float)(e - 1 - GRT_LEAN_S0_SHIFT) : 0.f;
             }
             for (int i = tid; i < kPowTable; i += kBlock)
             {
@@ -1339,9 +1360,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
             // stimulated emission 1 - exp(c2 v0/T) (kernels.c:84): 1 to fp32 and beyond below exp(-20); the tile's lowest
             // wavenumber decides for the whole workgroup (sorted store, shifts of a fraction of a grid step)
             double const x2_tile = ((double)(-1.4387686f)*lay[2])*(a.w0 + ((double)F0 - 2.)*a.wres - 1.);
-            stim_tile = uniform_flag(x2_tile > -21.);
-            farir_tile = uniform_flag(x2_tile > -1.1);
-            corrected_s = uniform_flag(corrected);
+            unsigned tf = (x2_tile > -21. ? kTfStim : 0u) | (x2_tile > -1.1 ? kTfFarir : 0u) | (corrected ? kTfCorrected : 0u);
             {
                 double dop_hi = 0., dop_lo = 1e300;
                 for (int sl = 0; sl < a.lay.num_slots; ++sl)
@@ -1357,508 +1376,489 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                 double const wr_min = dop_hi > 0. ? a.wres/(nu_hi*dop_hi) : 0.;
                 double const wr_max = dop_lo < 1e300 ? a.wres/(nu_lo*dop_lo) : 1e300;
                 // XLIM0^2 = 15100 + y (40 - 3.6 y) <= 15211.2 (y = 5.56), >= 15100 for y <= 4; XLIM1^2 <= 164 (RFM_voigt.c:109-118)
-                lreg_t = uniform_flag(0.25*wr_min*wr_min >= 1.003*15211.2);
-                v1_t = uniform_flag(corrected && 12.25*wr_max*wr_max < 0.999*15100.);
-                nc_one_t = uniform_flag(0.25*wr_min*wr_min >= 164.1);
-                nc_three_t = uniform_flag(2.25*wr_min*wr_min >= 164.1);
+                tf |= (0.25*wr_min*wr_min >= 1.003*15211.2 ? kTfLreg : 0u) | ((corrected && 12.25*wr_max*wr_max < 0.999*15100.) ? kTfV1 : 0u)
+                      | (0.25*wr_min*wr_min >= 164.1 ? kTfNcOne : 0u) | (2.25*wr_min*wr_min >= 164.1 ? kTfNcThree : 0u);
             }
+            tflags = (unsigned)__builtin_amdgcn_readfirstlane((int)tf);
         }
     }
 
-    // The raw queue's entries, prepared exactly (general_block's fp64 expressions) and sorted into the class queues.
+    // (lean blocks start on even line indices -- a pair of the packed records; a line before jbeg in the first block is masked)
+    uint64_t const jal = lean_ok ? (jbeg & ~(uint64_t)1) : jbeg;
+    uint64_t const walk_first = a.deterministic ? (wave == 0 ? jal : jend) : jal + (uint64_t)wave*64*kLinesPerLane;
+    unsigned const walk_stride = (a.deterministic ? 64u : (unsigned)kBlock)*kLinesPerLane;
+
+    // The raw queue's entries -- core points (|x| < XLIM1: Humlicek regions 2-4) -- get the reference's x, 64 at a time with
+    // all lanes busy, and are sorted into the class queues.  K(x, y) there changes by 2 x^2 times a relative change of x, so
+    // x has to be the reference's fp32 number to the bit: its fp64 expressions from the line's fp64 centre (general_block's;
+    // one 8-byte load per point -- everything else the entry brings along or LDS holds), REPWID rounded to fp32 as the
+    // reference has it.  y only scales smoothly: the lean loop's fp32 value serves.
     [[maybe_unused]] auto drain_raw = [&](int const first, int const count)
     {
         if constexpr (LEANP > 0)
         {
             bool const on = lane < count;
             int const i = first + (on ? lane : 0);
-            unsigned const j = raw->j[wave][i];
-            float const ampl = raw->amp[wave][i];
             unsigned const packed = raw->idx[wave][i];
             int const idx = (int)(packed & 4095u);                                      // f - A0
             // the centre index is the lean loop's (it is exact there, or the line would not be here): the point is its
             // grid point c + k - 3
-            int const c = idx + A0 - ((int)(packed >> 12) - 3);
-            double const v0 = a.lines.v0[j];
-            float4 const rb = reinterpret_cast<float4 const *>(a.lines.lean_b)[j];     // yair, yself, en, delta
-            unsigned const rc = a.lines.lean_c[j];
-            double const *ms = ms_l + ((rc >> 8) & 63u)*4;
-            double const wnoadj = v0 + (double)rb.w*lay[0];                            // kernels.c:44
+            int const c = idx + A0 - ((int)((packed >> 12) & 15u) - 3);
+            double const wnoadj = a.lines.v0[raw->j[wave][i]] + (double)raw->delta[wave][i]*lay[0];     // kernels.c:44
             int const s = c - fsteps < 0 ? 0 : c - fsteps;                             // kernels.c:435
-            double const tpow = ptab[rc & 127u];                                       // (lean lines have tabulated exponents)
-            double const gamma = tpow*((double)rb.x*ms[1] + (double)rb.y*ms[0]);       // kernels.c:105-106
-            double const alpha = ((double)0.83255461115f*wnoadj)*ms[3];                // kernels.c:127
+            double const alpha = ((double)0.83255461115f*wnoadj)*ms_l[(packed >> 16)*4 + 3];           // kernels.c:127
             double const r0 = (double)__builtin_amdgcn_rcpf((float)alpha);
             float const repwid = (float)((double)kSqrln2*(r0*fma(-alpha, r0, 2.0)));   // RFM_voigt.c:94
-            float const y = (float)((double)repwid*gamma);                             // RFM_voigt.c:95
             double const dwno = (double)s*a.wres + a.w0;                               // kernels.c:438
             float const xr = voigt_x(dwno, idx + A0 - s, a.wres, wnoadj, repwid);      // the reference's x
+            float const y = raw->y[wave][i];
             int const cls = on ? voigt_class<true, kSplit>(xr, y) : -1;
-            queue_push(cls, (float)((double)ampl*(double)(kRsqrpi*repwid)), xr, y, (unsigned short)idx);
+            // (RFM_voigt.c:278; the product of two fp32 numbers rounded once, as the general form's fp64 product rounded to fp32)
+            queue_push(cls, raw->amp[wave][i]*(kRsqrpi*repwid), xr, y, (unsigned short)idx);
         }
     };
 
-    // The packed records of line LEANP lane + p of the block at b (past the end of the workgroup's range: its last line) --
-    // requested one line ahead of their use.
-    [[maybe_unused]] float4 next_ra = make_float4(0.f, 0.f, 0.f, 0.f), next_rb = make_float4(0.f, 0.f, 0.f, 0.f);
-    [[maybe_unused]] unsigned next_rc = 0u;
-    [[maybe_unused]] auto lean_fetch = [&](uint64_t b, int const p)
+    // The packed records of the pair of lines b + 2 lane, b + 2 lane + 1 (b even; past the end of the workgroup's range:
+    // its last pair) -- requested one block ahead of their use.
+    [[maybe_unused]] float4 next_a0 = make_float4(0.f, 0.f, 0.f, 0.f), next_a1 = next_a0, next_b0 = next_a0, next_b1 = next_a0;
+    [[maybe_unused]] uint2 next_c = make_uint2(0u, 0u);
+    [[maybe_unused]] auto lean_fetch = [&](uint64_t const b)
     {
         if constexpr (LEANP > 0)
         {
-            int rem_b = 1;
-            if (b < jend)
-            {
-                rem_b = jend - b < (uint64_t)(64*LEANP) ? (int)(jend - b) : 64*LEANP;
-            }
-            else
-            {
-                b = jend - 1;
-            }
-            int const li = LEANP*lane + p;
-            unsigned const off = (unsigned)(li < rem_b ? li : rem_b - 1);
+            uint64_t const qlast = (jend - 1) >> 1;
+            uint64_t const qb = b < jend ? (b >> 1) : qlast;
+            unsigned const room = (unsigned)(qlast - qb);
+            unsigned const off = (unsigned)lane < room ? (unsigned)lane : room;
             // (byte offsets in 32 bits: scalar base + vector offset addressing instead of 64-bit vector address arithmetic)
-            float4 const *pa = reinterpret_cast<float4 const *>(a.lines.lean_a) + b;
-            float4 const *pb = reinterpret_cast<float4 const *>(a.lines.lean_b) + b;
-            unsigned const *pc = a.lines.lean_c + b;
-            next_ra = *reinterpret_cast<float4 const *>(reinterpret_cast<char const *>(pa) + (off << 4));
-            next_rb = *reinterpret_cast<float4 const *>(reinterpret_cast<char const *>(pb) + (off << 4));
-            next_rc = *reinterpret_cast<unsigned const *>(reinterpret_cast<char const *>(pc) + (off << 2));
+            float4 const *pa = reinterpret_cast<float4 const *>(a.lines.lean_a) + qb;
+            float4 const *pb = reinterpret_cast<float4 const *>(a.lines.lean_b) + qb;
+            uint2 const *pc = reinterpret_cast<uint2 const *>(a.lines.lean_c) + qb;
+            next_a0 = *reinterpret_cast<float4 const *>(reinterpret_cast<char const *>(pa) + (off << 4));
+            next_a1 = *reinterpret_cast<float4 const *>(reinterpret_cast<char const *>(pa + a.lines.lean_npair) + (off << 4));
+            next_b0 = *reinterpret_cast<float4 const *>(reinterpret_cast<char const *>(pb) + (off << 4));
+            next_b1 = *reinterpret_cast<float4 const *>(reinterpret_cast<char const *>(pb + a.lines.lean_npair) + (off << 4));
+            next_c = *reinterpret_cast<uint2 const *>(reinterpret_cast<char const *>(pc) + (off << 3));
         }
     };
 
-    // One lean block: lane l takes lines base + LEANP l + p, p = 0 .. LEANP - 1.  Lines that have to go through
-    // general_block instead are recorded, block by block, in the wave's list (raw->xl_*).
+    // One lean block: lane l takes the pair of lines base + 2 l (half 0 of every packed value below) and base + 2 l + 1
+    // (half 1); base is even.  What depends on one line only and has a packed instruction -- fp32 multiply, add, fma -- is
+    // done for both lines at once; compares, selects, conversions, transcendentals and table look-ups come per half.  The
+    // operations and their order are those of a line on its own, so the halves hold what two passes over single lines
+    // would.  Lines that have to go through general_block instead are recorded, block by block, in the wave's list
+    // (raw->xl_*).
     [[maybe_unused]] auto lean_block = [&](uint64_t const base)
     {
         if constexpr (LEANP > 0)
         {
-            int const rem = jend - base < (uint64_t)(64*LEANP) ? (int)(jend - base) : 64*LEANP;     // lines of this block
-            float m0[kMom], m1[kMom], nvs[8];
-#pragma unroll
-            for (int k = 0; k < kMom; ++k)
+            // lines of this block: base + lo .. base + hi - 1 (lo = 1: the workgroup's range begins on an odd index)
+            int const lo = jbeg > base ? (int)(jbeg - base) : 0;
+            int const hi = jend - base < (uint64_t)128 ? (int)(jend - base) : 128;
+            float4 const ra0 = next_a0, ra1 = next_a1, rb0 = next_b0, rb1 = next_b1;
+            uint2 const rcc = next_c;
+            lean_fetch(base + walk_stride);
+            // (the tile's flags, tested where they are used: hoisted out of the loop, each test became a lane mask in two
+            // scalar registers, spilled to a vector register's lanes and read back with v_readlane at every use)
+            unsigned tfl = tflags;
+            asm volatile("" : "+s"(tfl));
+            bool const have[2] = {2*lane >= lo && 2*lane < hi, 2*lane + 1 < hi};
+            unsigned const rc[2] = {rcc.x, rcc.y};
+            v2f const d0 = {ra0.x, ra0.y};
+            int const ci[2] = {__float_as_int(ra0.z), __float_as_int(ra0.w)};
+            v2f const v0f = {ra1.x, ra1.y};
+            v2f const ss = {ra1.z, ra1.w};
+            v2f const yair = {rb0.x, rb0.y}, yself = {rb0.z, rb0.w}, en = {rb1.x, rb1.y}, dsh = {rb1.z, rb1.w};
+            v2f const kh2 = splat2(kh), kl2 = splat2(kl), inv_wres2 = splat2(inv_wres_v);
+            // ---- centre index and offset (kernels.c:44, :431-432) ----
+            v2f const u = pk_fma(dsh, splat2(pw), d0);
+            v2f const t = u + 0.5f;
+            v2f const kf = {floorf(t.x), floorf(t.y)};
+            v2f const dl = u - kf;                              // offset of the shifted centre from grid point c, [-1/2, 1/2)
+            v2f const gd = (t - kf) - 0.5f;
+            int const c[2] = {ci[0] + (int)kf.x, ci[1] + (int)kf.y};
+            bool const guard[2] = {fabsf(gd.x) > 0.49999f, fabsf(gd.y) > 0.49999f};
+            bool const in_tile[2] = {(unsigned)(c[0] - F0) < (unsigned)(F1 - F0), (unsigned)(c[1] - F0) < (unsigned)(F1 - F0)};
+            v2f const wn = pk_fma(dsh, splat2(pavg_f), v0f);    // shifted centre [cm-1]
+            // ---- S(T) N_s (kernels.c:83-85, :459) ----
+            v2f const nz = rint2(en*kh2);
+            v2f const rz = pk_fma(en, kl2, pk_fma(en, kh2, -nz));       // en c2 log2(e)/T - nz, to ~1e-8
+            unsigned const qi[2] = {(rc[0] >> 14) & 1023u, (rc[1] >> 14) & 1023u};
+            float const *qnx = qnf + a.lay.num_slots*GRT_MAX_ISO;
+            v2f amp = (ss*(v2f){qnf[qi[0]], qnf[qi[1]]})*exp2_2(rz);
             {
-                m0[k] = 0.f; m1[k] = 0.f; nvs[k] = 0.f;
+                v2f const ex = (v2f){qnx[qi[0]], qnx[qi[1]]} + nz;
+                amp = (v2f){ldexpf(amp.x, (int)ex.x), ldexpf(amp.y, (int)ex.y)};
             }
-            int cr = 0;                         // the row's reference cell: its lines sit in cells cr, cr + 1 (sorted store)
-            bool one_cell = true;               // (wave-uniform) so far every line of every row sat in its row's first cell
-            unsigned long long handed[LEANP] = {};
-#ifdef GRT_LEAN_UNROLL
-#pragma unroll
-#else
-#pragma nounroll
-#endif
-            for (int p = 0; p < LEANP; ++p)
+            if (tfl & kTfStim)
             {
-                int const li = LEANP*lane + p;
-                bool const have = li < rem;
-                unsigned const off = (unsigned)(have ? li : rem - 1);
-                // this line's records were asked for one line ago (the loop waits for nothing it has just requested); now the next
-                // line's: the next p of this block, or the first of the wave's next block
-                float4 const ra = next_ra, rb = next_rb;
-                unsigned const rc = next_rc;
-                if (p + 1 < LEANP)
+                // (kernels.c:84 with the UNSHIFTED centre: launch.c:119 hands calc_line_strengths the line list's v0)
+                v2f const n2 = rint2(v0f*kh2);
+                v2f const r2 = pk_fma(v0f, kl2, pk_fma(v0f, kh2, -n2));
+                v2f const e2 = exp2_2(r2);
+                v2f stim = 1.f - (v2f){ldexpf(e2.x, (int)n2.x), ldexpf(e2.y, (int)n2.y)};
+                if (tfl & kTfFarir)
                 {
-                    lean_fetch(base, p + 1);
+                    // nu < ~0.7 T: 1 - e^x cancels; -expm1(x) by its series on [-1, 0] (eleven terms: 2e-9)
+                    v2f const x2 = v0f*splat2(c2t);
+                    v2f ps = splat2(2.50521084e-08f);                           // 1/11!
+                    ps = pk_fma(ps, x2, splat2(2.75573192e-07f));
+                    ps = pk_fma(ps, x2, splat2(2.75573192e-06f));
+                    ps = pk_fma(ps, x2, splat2(2.48015873e-05f));
+                    ps = pk_fma(ps, x2, splat2(1.98412698e-04f));
+                    ps = pk_fma(ps, x2, splat2(1.38888889e-03f));
+                    ps = pk_fma(ps, x2, splat2(8.33333333e-03f));
+                    ps = pk_fma(ps, x2, splat2(4.16666667e-02f));
+                    ps = pk_fma(ps, x2, splat2(1.66666667e-01f));
+                    ps = pk_fma(ps, x2, splat2(0.5f));
+                    ps = pk_fma(ps, x2, splat2(1.0f));
+                    stim = sel2(x2.x > -1.f, x2.y > -1.f, (-x2)*ps, stim);
                 }
-                else
+                amp *= stim;
+            }
+            // ---- widths (kernels.c:105-106, :127; RFM_voigt.c:94-95) ----
+            unsigned const si[2] = {(rc[0] >> 8) & 63u, (rc[1] >> 8) & 63u};
+            float const *msy = msf + a.lay.num_slots, *msz = msf + 2*a.lay.num_slots;
+            v2f const ptv = {ptabf[rc[0] & 127u], ptabf[rc[1] & 127u]};
+            v2f const gam = ptv*pk_fma(yair, (v2f){msy[si[0]], msy[si[1]]}, yself*(v2f){msf[si[0]], msf[si[1]]});
+            v2f const ad = wn*(v2f){msz[si[0]], msz[si[1]]};                              // alpha/sqrt(ln 2) (kernels.c:127, RFM_voigt.c:94)
+            v2f const r0 = rcp2(ad);
+            v2f const rep = pk_fma(pk_fma(-ad, r0, splat2(1.f)), r0, r0);       // REPWID (one Newton step: the far wings scale with it)
+            v2f y = rep*gam;
+            // (flagged by the loader: strength zeroed; RFM_voigt.c:122-126: no Lorentz width -- all of that is general_block's)
+            bool const exc[2] = {bool(!(ss.x > 0.f) | guard[0] | !(y.x > 0.000001f)), bool(!(ss.y > 0.f) | guard[1] | !(y.y > 0.000001f))};
+            bool const valid[2] = {bool(have[0] & in_tile[0] & !exc[0]), bool(have[1] & in_tile[1] & !exc[1])};
+            {
+                unsigned long long const handed0 = ballot_b(have[0] & exc[0]), handed1 = ballot_b(have[1] & exc[1]);
+                if ((handed0 | handed1) != 0ull)
                 {
-                    lean_fetch(base + walk_stride, 0);
-                }
-                // ---- centre index and offset (kernels.c:44, :431-432) ----
-                float const u = fmaf(rb.w, pw, ra.x);
-                float const t = u + 0.5f;
-                float const kf = floorf(t);
-                float const dl = u - kf;                            // offset of the shifted centre from grid point c, [-1/2, 1/2)
-                int const c = __float_as_int(ra.y) + (int)kf;
-                bool const guard = fabsf((t - kf) - 0.5f) > 0.49999f;
-                bool const in_tile = (unsigned)(c - F0) < (unsigned)(F1 - F0);
-                float const wn = fmaf(rb.w, pavg_f, ra.z);          // shifted centre [cm-1]
-                // ---- S(T) N_s (kernels.c:83-85, :459) ----
-                float const en = rb.z;
-                float const nz = rintf(en*kh);
-                float const rz = fmaf(en, kl, fmaf(en, kh, -nz));   // en c2 log2(e)/T - nz, to ~1e-8
-                float2 const qe = qnf[(rc >> 14) & 1023u];
-                float amp = (ra.w*qe.x)*__builtin_amdgcn_exp2f(rz);
-                amp = ldexpf(amp, (int)(qe.y + nz));
-                if (stim_tile)
-                {
-                    // (kernels.c:84 with the UNSHIFTED centre: launch.c:119 hands calc_line_strengths the line list's v0)
-                    float const v0f = ra.z;
-                    float const n2 = rintf(v0f*kh);
-                    float const r2 = fmaf(v0f, kl, fmaf(v0f, kh, -n2));
-                    float stim = 1.f - ldexpf(__builtin_amdgcn_exp2f(r2), (int)n2);
-                    if (farir_tile)
+                    if (lane == 0)
                     {
-                        // nu < ~0.7 T: 1 - e^x cancels; -expm1(x) by its series on [-1, 0] (eleven terms: 2e-9)
-                        float const x2 = v0f*c2t;
-                        float ps = 2.50521084e-08f;                                 // 1/11!
-                        ps = fmaf(ps, x2, 2.75573192e-07f);
-                        ps = fmaf(ps, x2, 2.75573192e-06f);
-                        ps = fmaf(ps, x2, 2.48015873e-05f);
-                        ps = fmaf(ps, x2, 1.98412698e-04f);
-                        ps = fmaf(ps, x2, 1.38888889e-03f);
-                        ps = fmaf(ps, x2, 8.33333333e-03f);
-                        ps = fmaf(ps, x2, 4.16666667e-02f);
-                        ps = fmaf(ps, x2, 1.66666667e-01f);
-                        ps = fmaf(ps, x2, 0.5f);
-                        ps = fmaf(ps, x2, 1.0f);
-                        stim = x2 > -1.f ? -x2*ps : stim;
+                        raw->xl_base[wave][xcount] = (unsigned)(base - jal);
+                        raw->xl_mask[wave][xcount][0] = handed0;
+                        raw->xl_mask[wave][xcount][1] = handed1;
                     }
-                    amp *= stim;
+                    ++xcount;
                 }
-                // ---- widths (kernels.c:105-106, :127; RFM_voigt.c:94-95) ----
-                float4 const mf = msf[(rc >> 8) & 63u];
-                float const gam = ptabf[rc & 127u]*fmaf(rb.x, mf.y, rb.y*mf.x);
-                float const ad = wn*mf.z;                                           // alpha/sqrt(ln 2) (kernels.c:127, RFM_voigt.c:94)
-                float const r0 = __builtin_amdgcn_rcpf(ad);
-                float const rep = fmaf(fmaf(-ad, r0, 1.f), r0, r0);                 // REPWID (one Newton step: the far wings scale with it)
-                float y = rep*gam;
-                // (flagged by the loader: strength zeroed; RFM_voigt.c:122-126: no Lorentz width -- all of that is general_block's)
-                bool const exc = !(ra.w > 0.f) | guard | !(y > 0.000001f);
-                bool const valid = have & in_tile & !exc;
-                {
-                    unsigned long long const hm = __ballot(have & exc);
+            }
+            // a lane without a line of its own here works on a harmless one (no infinities: 0 x inf would poison the sums)
+            amp = sel2(valid[0], valid[1], amp, splat2(0.f));
+            y = sel2(valid[0], valid[1], y, splat2(1.f));
+            v2f const eta = sel2(valid[0], valid[1], gam*inv_wres2, splat2(1.f));
+            v2f const eta2 = eta*eta;
+            v2f const wr = splat2(wres_v)*rep;
+            // ---- which cell of its row: cr or cr + 1; anything else (sparse lines) is added lane by lane ----
+            // (cr: the row's reference cell -- its lines sit in cells cr, cr + 1: sorted store)
+            int cr;
+            {
+                int const c_first = dpp_i<0x150>(c[0]);                             // row_newbcast:0 -- the row's first lane
+                cr = c_first < F0 ? F0 : (c_first > F1 - 1 ? F1 - 1 : c_first);
+            }
+            // (a lane without a valid line has amp = 0 and adds nothing wherever it is put: it is put in cell cr, and from here
+            // on nothing asks about validity -- its XLIM0 and XLIM1 below are zero, so it has no region 1 and no core point)
+            int const o[2] = {valid[0] ? c[0] - cr : 0, valid[1] ? c[1] - cr : 0};
+            bool const odd[2] = {(unsigned)o[0] > 1u, (unsigned)o[1] > 1u};
+            // (the longwave band's usual case, 308 lines per cell: no second cell, no weights; the shortwave instance, 30
+            // lines per cell, does not ask)
+            bool const single = LEAN && ballot_b((o[0] | o[1]) != 0) == 0ull;
+            v2f const W0 = {o[0] == 0 ? 1.f : 0.f, o[1] == 0 ? 1.f : 0.f};
+            v2f const W1 = {o[0] == 1 ? 1.f : 0.f, o[1] == 1 ? 1.f : 0.f};
+            // ---- moments of the Lorentzian about the cell centre (see general_block) ----
+            v2f const A = (amp*eta)*splat2(a_norm);                             // K(r) = A/((r - dl)^2 + eta^2)
+            v2f m[kMom];
+            {
+                v2f uu = A, pk = splat2(0.f);
 #pragma unroll
-                    for (int q = 0; q < LEANP; ++q)
-                    {
-                        handed[q] = p == q ? hm : handed[q];
-                    }
-                }
-                // a lane without a line of its own here works on a harmless one (no infinities: 0 x inf would poison the sums)
-                amp = valid ? amp : 0.f;
-                y = valid ? y : 1.f;
-                float const eta = valid ? gam*inv_wres_v : 1.f;
-                float const eta2 = eta*eta;
-                float const wr = wres_v*rep;
-                // ---- which cell of its row: cr or cr + 1; anything else (sparse lines) is added lane by lane ----
+                for (int k = 0; k < kMom; ++k)
                 {
-                    int const c_first = dpp_i<0x150>(c);                            // row_newbcast:0 -- the row's first lane
-                    int const c_clamped = c_first < F0 ? F0 : (c_first > F1 - 1 ? F1 - 1 : c_first);
-                    cr = p == 0 ? c_clamped : cr;
+                    v2f const un = pk_fma(dl, uu, (-eta2)*pk);
+                    pk = pk_fma(dl, pk, uu);
+                    uu = un;
+                    m[k] = pk;
                 }
-                int const o = c - cr;
-                float const w0f = (valid & (o == 0)) ? 1.f : 0.f;
-                float const w1f = (valid & (o == 1)) ? 1.f : 0.f;
-                bool const odd = valid & ((unsigned)o > 1u);
-                // (the longwave band's usual case, 308 lines per cell: no second cell, no weights; the shortwave instance, 30
-                // lines per cell, does not ask)
-                bool const single = LEAN && __ballot(valid & (o != 0)) == 0ull;
-                one_cell = one_cell & single;
-                // ---- moments of the Lorentzian about the cell centre (see general_block) ----
-                float const A = (amp*eta)*a_norm;                                   // K(r) = A/((r - dl)^2 + eta^2)
-                float m[kMom];
-#ifdef GRT_ABL_NOMOM
-                for (int k = 0; k < kMom; ++k) m[k] = 0.f;
-#else
+            }
+            // Voigt constants (RFM_voigt.c:97-126, :177-179); a pure Lorentz line (y >= 70.55) has no region 1
+            v2f const yq = y*y;
+            v2f const x0q = sel2(!valid[0] | (y.x >= 70.55f), !valid[1] | (y.y >= 70.55f), splat2(0.f), pk_fma(y, pk_fma(y, splat2(-3.6f), splat2(40.0f)), splat2(15100.0f)));   // XLIM0^2
+            v2f const xq_near = sel2(!valid[0] | (y.x >= 8.425f), !valid[1] | (y.y >= 8.425f), splat2(0.f), 164.0f - y*pk_fma(y, splat2(1.8f), splat2(4.3f)));              // XLIM1^2
+            v2f const a0 = yq + 0.5f;
+            v2f const d0r = a0*a0;
+            v2f const d2r = (yq + yq) - 1.0f;
+            v2f const cl = (rep*y)*0.318309886f;
+            v2f const adl = {fabsf(dl.x), fabsf(dl.y)};
+            v2f const ndcr = (-dl)*wr;                          // x of the line's own grid point
+            bool pre2[2] = {false, false};
+            if (tfl & kTfCorrected)
+            {
+                // region 1 beyond the near field: folded into the moments, or (pre-pass 2 of general_block) point by point
+                v2f const e4 = (4.f - adl)*wr;
+                v2f const e4q = e4*e4, aw = adl*wr;
+                bool const reg1_far[2] = {e4q.x < x0q.x, e4q.y < x0q.y};
+                bool const fold[2] = {bool(reg1_far[0] & (aw.x <= 0.5f*kFoldWrMax)), bool(reg1_far[1] & (aw.y <= 0.5f*kFoldWrMax))};
+                pre2[0] = reg1_far[0] & !fold[0];
+                pre2[1] = reg1_far[1] & !fold[1];
+                // (below ~15 000 cm-1 region 1 ends inside the near field: no line of the wave has anything to fold)
+                if (ballot_b(fold[0] | fold[1]) != 0ull)
                 {
-                    float uu = A, pk = 0.f;
-#pragma unroll
-                    for (int k = 0; k < kMom; ++k)
-                    {
-                        float const un = fmaf(dl, uu, -eta2*pk);
-                        pk = fmaf(dl, pk, uu);
-                        uu = un;
-                        m[k] = pk;
-                    }
-                }
-#endif
-                // Voigt constants (RFM_voigt.c:97-126, :177-179); a pure Lorentz line (y >= 70.55) has no region 1
-                float const yq = y*y;
-                float const x0q = y >= 70.55f ? 0.f : fmaf(y, fmaf(y, -3.6f, 40.0f), 15100.0f);   // XLIM0^2
-                float const xq_near = y >= 8.425f ? 0.f : 164.0f - y*fmaf(y, 1.8f, 4.3f);        // XLIM1^2
-                float const a0 = yq + 0.5f;
-                float const d0r = a0*a0;
-                float const d2r = (yq + yq) - 1.0f;
-                float const cl = (rep*y)*0.318309886f;
-                float const adl = fabsf(dl);
-                float const ndcr = -dl*wr;                          // x of the line's own grid point
-                bool pre2 = false;
-                if (corrected_s)
-                {
-                    // region 1 beyond the near field: folded into the moments, or (pre-pass 2 of general_block) point by point
-                    float const e4 = (4.f - adl)*wr;
-                    bool const reg1_far = valid & (e4*e4 < x0q);
-                    bool const fold = reg1_far & (adl*wr <= 0.5f*kFoldWrMax);
-                    pre2 = reg1_far & !fold;
-                    // (below ~15 000 cm-1 region 1 ends inside the near field: no line of the wave has anything to fold)
-                    if (__ballot(fold) != 0ull)
-                    {
-                    float const rwr = ad*inv_wres_v;                                // 1/wr
-                    float const rw2 = rwr*rwr;
-                    float const t4 = fold ? A*rw2 : 0.f;
-                    float const t6 = t4*rw2;
-                    float d4 = 1.5f*t4;
-                    float d6 = fmaf(-5.f, yq, 1.25f)*t6;
-                    float d8 = fmaf(yq, fmaf(10.5f, yq, -8.75f), 0.875f)*(t6*rw2);
+                    v2f const rwr = ad*inv_wres2;                                   // 1/wr
+                    v2f const rw2 = rwr*rwr;
+                    v2f const t4 = sel2(fold[0], fold[1], A*rw2, splat2(0.f));
+                    v2f const t6 = t4*rw2;
+                    v2f d4 = 1.5f*t4;
+                    v2f d6 = pk_fma(splat2(-5.f), yq, splat2(1.25f))*t6;
+                    v2f d8 = pk_fma(yq, pk_fma(splat2(10.5f), yq, splat2(-8.75f)), splat2(0.875f))*(t6*rw2);
 #pragma unroll
                     for (int i = 2; i < kMom; ++i)
                     {
-                        m[i] = fmaf((float)binomial(i + 1, 3), d4, m[i]);
+                        m[i] = pk_fma(splat2((float)binomial(i + 1, 3)), d4, m[i]);
                         d4 *= dl;
                         if (i >= 4)
                         {
-                            m[i] = fmaf((float)binomial(i + 1, 5), d6, m[i]);
+                            m[i] = pk_fma(splat2((float)binomial(i + 1, 5)), d6, m[i]);
                             d6 *= dl;
                         }
                         if (i >= 6)
                         {
-                            m[i] = fmaf((float)binomial(i + 1, 7), d8, m[i]);
+                            m[i] = pk_fma(splat2((float)binomial(i + 1, 7)), d8, m[i]);
                             d8 *= dl;
                         }
                     }
-                    }
                 }
-                if (single)
-                {
+            }
+            // ---- the row's moment sums: eight per cell end in sixteen lanes (one cell: in eight) ----
+            if (single)
+            {
+                float g0[kMom];
 #pragma unroll
-                    for (int k = 0; k < kMom; ++k)
-                    {
-                        m0[k] += m[k];          // (a lane without a valid line has A = 0: nothing)
-                    }
-                }
-                else
+                for (int k = 0; k < kMom; ++k)
                 {
+                    g0[k] = m[k].x + m[k].y;        // (a lane without a valid line has A = 0: nothing)
+                }
+                float tsum = row_sum_transposed(g0, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0);       // value (lane >> 1) & 7, twice
+                tsum = (lane & 1) == 0 ? tsum : 0.f;
+                if ((tsum != 0.f) & (cr < F1))
+                {
+                    mom_add((lane >> 1) & 7, cr, tsum);
+                }
+            }
+            else
+            {
+                float g0[kMom], g1[kMom];
 #pragma unroll
-                    for (int k = 0; k < kMom; ++k)
+                for (int k = 0; k < kMom; ++k)
+                {
+                    v2f const t0 = W0*m[k], t1 = W1*m[k];
+                    g0[k] = t0.x + t0.y;
+                    g1[k] = t1.x + t1.y;
+                }
+                float const tsum = row_sum_two_groups(g0, g1, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0, (lane & 1) != 0);
+                int const cell = cr + ((lane >> 3) & 1);
+                if ((tsum != 0.f) & (cell < F1))
+                {
+                    mom_add(lane & 7, cell, tsum);
+                }
+            }
+            bool const any_odd = (!single || (tfl & kTfCorrected) != 0u) && ballot_b(odd[0] | odd[1] | pre2[0] | pre2[1]) != 0ull;
+            // (rare: a line in neither of its row's cells adds lane by lane)
+            if (any_odd)
+            {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                {
+                    if (odd[h])
                     {
-                        m0[k] = fmaf(w0f, m[k], m0[k]);
-                        m1[k] = fmaf(w1f, m[k], m1[k]);
+#pragma unroll
+                        for (int k = 0; k < kMom; ++k)
+                        {
+                            mom_add(k, c[h], m[k][h]);
+                        }
                     }
                 }
-                // ---- near field: the line's seven points r = -3 .. 3 (v[r + 3]; x = r wr + ndcr, the general form's canonical
-                // x), by what the wave's lines have there: only Lorentzians but for a line's own point | region 1 throughout
-                // | the point's region picks the formula.  Near-centre points (|x| < XLIM1) are left out and noted in ncm. ----
-                bool const lreg = lreg_t, nc_one = nc_one_t;
-                float v[7];
-                unsigned ncm = 0u;
-#ifdef GRT_ABL_NOSLOTS
-                for (int k = 0; k < 7; ++k) v[k] = 0.f;
-                if (false)
-#else
-                if (lreg)
-#endif
+            }
+            // ---- near field: the lines' seven points r = -3 .. 3 (v[r + 3]; x = r wr + ndcr, the general form's canonical
+            // x), by what the wave's lines have there: only Lorentzians but for a line's own point | region 1 throughout
+            // | the point's region picks the formula.  Near-centre points (|x| < XLIM1) are left out and noted in ncm. ----
+            v2f v[7];
+            unsigned ncm[2] = {0u, 0u};
+            if (tfl & kTfLreg)
+            {
+                // every point but the line's own: the Lorentzian, A/(rel^2 + eta^2) (RFM_voigt.c:103,170,278)
+#pragma unroll
+                for (int k = 0; k < 7; ++k)
                 {
-                    // every point but the line's own: the Lorentzian, A/(rel^2 + eta^2) (RFM_voigt.c:103,170,278)
+                    if (k != 3)
+                    {
+                        v2f const rel = (float)(k - 3) - dl;
+                        v[k] = A*rcp2(pk_fma(rel, rel, eta2));
+                    }
+                }
+                // the line's own grid point: region 1, the Lorentzian, or a near-centre point (the queues')
+                v2f const xq0 = ndcr*ndcr;
+                bool const nc[2] = {xq0.x < xq_near.x, xq0.y < xq_near.y};
+                bool const reg1[2] = {xq0.x < x0q.x, xq0.y < x0q.y};
+                v2f const den = sel2(reg1[0], reg1[1], pk_fma(xq0, d2r + xq0, d0r), xq0 + yq);
+                v2f const num = sel2(reg1[0], reg1[1], cl*(a0 + xq0), cl);
+                v[3] = sel2(nc[0], nc[1], splat2(0.f), (amp*num)*rcp2(den));
+                ncm[0] = nc[0] ? 8u : 0u;
+                ncm[1] = nc[1] ? 8u : 0u;
+            }
+            else
+            {
+                v2f const acl = amp*cl;
+                v2f xq[7];
+#pragma unroll
+                for (int k = 0; k < 7; ++k)
+                {
+                    v2f const x = pk_fma(splat2((float)(k - 3)), wr, ndcr);
+                    xq[k] = x*x;
+                }
+                if (tfl & kTfV1)
+                {
+                    // region 1 throughout: K = cl (A0 + XQ)/(D0 + XQ (D2 + XQ)) (RFM_voigt.c:172-183)
 #pragma unroll
                     for (int k = 0; k < 7; ++k)
                     {
-                        if (k != 3)
-                        {
-                            float const rel = (float)(k - 3) - dl;
-                            v[k] = A*__builtin_amdgcn_rcpf(fmaf(rel, rel, eta2));
-                        }
+                        v[k] = (acl*(a0 + xq[k]))*rcp2(pk_fma(xq[k], d2r + xq[k], d0r));
                     }
-                    // the line's own grid point: region 1, the Lorentzian, or a near-centre point (the queues')
-                    float const xq0 = ndcr*ndcr;
-                    bool const nc = xq0 < xq_near;
-                    bool const reg1 = xq0 < x0q;
-                    float const den = reg1 ? fmaf(xq0, d2r + xq0, d0r) : xq0 + yq;
-                    float const num = reg1 ? cl*(a0 + xq0) : cl;
-                    v[3] = nc ? 0.f : (amp*num)*__builtin_amdgcn_rcpf(den);
-                    ncm = (nc & valid) ? 8u : 0u;
                 }
-#ifndef GRT_ABL_NOSLOTS
                 else
-#else
-                else if (false)
-#endif
                 {
-                    float const acl = amp*cl;
-                    if (v1_t)
-                    {
-                        // region 1 throughout: K = cl (A0 + XQ)/(D0 + XQ (D2 + XQ)) (RFM_voigt.c:172-183)
+                    // ... and the Lorentzian in the same form, cl (A0 + XQ)/((XQ + YQ)(XQ + A0)): the point's region picks (D0, D2)
+                    v2f const d0l = yq*a0, d2l = yq + a0;
 #pragma unroll
-                        for (int k = 0; k < 7; ++k)
-                        {
-                            float const x = fmaf((float)(k - 3), wr, ndcr);
-                            float const xq = x*x;
-                            v[k] = (acl*(a0 + xq))*__builtin_amdgcn_rcpf(fmaf(xq, d2r + xq, d0r));
-                        }
-                    }
-                    else
+                    for (int k = 0; k < 7; ++k)
                     {
-                        // ... and the Lorentzian in the same form, cl (A0 + XQ)/((XQ + YQ)(XQ + A0)): the point's region picks (D0, D2)
-                        float const d0l = yq*a0, d2l = yq + a0;
-#pragma unroll
-                        for (int k = 0; k < 7; ++k)
-                        {
-                            float const x = fmaf((float)(k - 3), wr, ndcr);
-                            float const xq = x*x;
-                            bool const reg1 = xq < x0q;
-                            float const D2 = reg1 ? d2r : d2l;
-                            float const D0 = reg1 ? d0r : d0l;
-                            v[k] = (acl*(a0 + xq))*__builtin_amdgcn_rcpf(fmaf(xq, D2 + xq, D0));
-                        }
-                    }
-                    if (nc_one)
-                    {
-                        bool const nc = ndcr*ndcr < xq_near;
-                        v[3] = nc ? 0.f : v[3];
-                        ncm = (nc & valid) ? 8u : 0u;
-                    }
-                    else if (nc_three_t)
-                    {
-                        // (grid steps of 8.6 Doppler widths and more: the own point and its two neighbours)
-#pragma unroll
-                        for (int k = 2; k <= 4; ++k)
-                        {
-                            float const x = fmaf((float)(k - 3), wr, ndcr);
-                            bool const nc = x*x < xq_near;
-                            v[k] = nc ? 0.f : v[k];
-                            ncm |= (nc & valid) ? (1u << k) : 0u;
-                        }
-                    }
-                    else
-                    {
-#pragma unroll
-                        for (int k = 0; k < 7; ++k)
-                        {
-                            float const x = fmaf((float)(k - 3), wr, ndcr);
-                            bool const nc = x*x < xq_near;
-                            v[k] = nc ? 0.f : v[k];
-                            ncm |= (nc & valid) ? (1u << k) : 0u;
-                        }
+                        bool const r1x = xq[k].x < x0q.x, r1y = xq[k].y < x0q.y;
+                        v2f const D2 = sel2(r1x, r1y, d2r, d2l);
+                        v2f const D0 = sel2(r1x, r1y, d0r, d0l);
+                        v[k] = (acl*(a0 + xq[k]))*rcp2(pk_fma(xq[k], D2 + xq[k], D0));
                     }
                 }
-                // into the row's eight slots (grid points cr - 3 .. cr + 4): a line of cell cr + o has its points in slots o .. 6 + o
+                if (tfl & kTfNcOne)
+                {
+                    v2f const xq0 = ndcr*ndcr;
+                    bool const nc[2] = {xq0.x < xq_near.x, xq0.y < xq_near.y};
+                    v[3] = sel2(nc[0], nc[1], splat2(0.f), v[3]);
+                    ncm[0] = nc[0] ? 8u : 0u;
+                    ncm[1] = nc[1] ? 8u : 0u;
+                }
+                else if (tfl & kTfNcThree)
+                {
+                    // (grid steps of 8.6 Doppler widths and more: the own point and its two neighbours)
+#pragma unroll
+                    for (int k = 2; k <= 4; ++k)
+                    {
+                        bool const nc[2] = {xq[k].x < xq_near.x, xq[k].y < xq_near.y};
+                        v[k] = sel2(nc[0], nc[1], splat2(0.f), v[k]);
+                        ncm[0] |= nc[0] ? (1u << k) : 0u;
+                        ncm[1] |= nc[1] ? (1u << k) : 0u;
+                    }
+                }
+                else
+                {
+#pragma unroll
+                    for (int k = 0; k < 7; ++k)
+                    {
+                        bool const nc[2] = {xq[k].x < xq_near.x, xq[k].y < xq_near.y};
+                        v[k] = sel2(nc[0], nc[1], splat2(0.f), v[k]);
+                        ncm[0] |= nc[0] ? (1u << k) : 0u;
+                        ncm[1] |= nc[1] ? (1u << k) : 0u;
+                    }
+                }
+            }
+            // into the row's eight slots (grid points cr - 3 .. cr + 4): a line of cell cr + o has its points in slots o .. 6 + o
+            {
+                float nvs[8];
                 if (single)
                 {
 #pragma unroll
                     for (int sl = 0; sl < 7; ++sl)
                     {
-                        nvs[sl] += v[sl];
+                        nvs[sl] = v[sl].x + v[sl].y;
                     }
+                    nvs[7] = 0.f;
                 }
                 else
                 {
 #pragma unroll
                     for (int sl = 0; sl < 8; ++sl)
                     {
-                        if (sl <= 6) nvs[sl] = fmaf(w0f, v[sl], nvs[sl]);
-                        if (sl >= 1) nvs[sl] = fmaf(w1f, v[sl - 1], nvs[sl]);
+                        v2f tt = splat2(0.f);
+                        if (sl <= 6) tt = W0*v[sl];
+                        if (sl >= 1) tt = pk_fma(W1, v[sl - 1], tt);
+                        nvs[sl] = tt.x + tt.y;
                     }
                 }
-                // ---- rare: a line in neither of its row's cells adds lane by lane; region-1 points beyond the near field of
-                // lines that are not folded (pre-pass 2 of general_block): such a line has |dl| wr > 12.5, so region 1
-                // (|x| < XLIM0 <= 123.4) ends within five grid steps ----
-                // (a wave whose lines all sit in their row's first cell has no such lane)
-                if ((!single || corrected_s) && __ballot(odd | pre2) != 0ull)
+                float const s8 = row_sum_transposed(nvs, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0);
+                if (((lane & 1) == 0) & (s8 != 0.f))
                 {
-                    if (odd)
-                    {
+                    GRT_ACC_ADD(&acc[cr - 3 + ((lane >> 1) & 7) - A0], (double)s8);
+                }
+            }
+            // ---- rare: a line in neither of its row's cells adds lane by lane; region-1 points beyond the near field of
+            // lines that are not folded (pre-pass 2 of general_block): such a line has |dl| wr > 12.5, so region 1
+            // (|x| < XLIM0 <= 123.4) ends within five grid steps ----
+            // (a wave whose lines all sit in their row's first cell has no such lane)
+            if (any_odd)
+            {
 #pragma unroll
-                        for (int k = 0; k < kMom; ++k)
-                        {
-                            mom_add(k, c, m[k]);
-                        }
+                for (int h = 0; h < 2; ++h)
+                {
+                    if (odd[h])
+                    {
 #pragma unroll
                         for (int k = 0; k < 7; ++k)
                         {
-                            if (v[k] != 0.f)
+                            if (v[k][h] != 0.f)
                             {
-                                GRT_ACC_ADD(&acc[c - 3 + k - A0], (double)v[k]);
+                                GRT_ACC_ADD(&acc[c[h] - 3 + k - A0], (double)v[k][h]);
                             }
                         }
                     }
-                    if (__ballot(pre2) != 0ull)
+                    if (ballot_b(pre2[h]) != 0ull)
                     {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
                         {
                             int const r = q == 0 ? -5 : (q == 1 ? -4 : (q == 2 ? 4 : 5));
-                            float const x = fmaf((float)r, wr, ndcr);
+                            float const x = fmaf((float)r, wr[h], ndcr[h]);
                             float const xq = x*x;
-                            float const den = fmaf(xq, d2r + xq, d0r)*(xq + yq);
-                            float const corr = (amp*cl)*fmaf(1.5f, xq, -0.5f*a0)*__builtin_amdgcn_rcpf(den);
-                            if (pre2 & (xq < x0q))
+                            float const den = fmaf(xq, d2r[h] + xq, d0r[h])*(xq + yq[h]);
+                            float const corr = (amp[h]*cl[h])*fmaf(1.5f, xq, -0.5f*a0[h])*__builtin_amdgcn_rcpf(den);
+                            if (pre2[h] & (xq < x0q[h]))
                             {
-                                GRT_ACC_ADD(&acc[c + r - A0], (double)corr);
+                                GRT_ACC_ADD(&acc[c[h] + r - A0], (double)corr);
                             }
                         }
                     }
                 }
-#ifdef GRT_ABL_NORAW
-                ncm = 0u;
-#endif
-                // ---- near-centre points -> raw queue (line, strength, grid point); full batches are prepared exactly ----
-                while (__ballot(ncm != 0u) != 0ull)
-                {
-                    bool const push = ncm != 0u;
-                    int const k = push ? __builtin_ctz(ncm) : 0;
-                    ncm &= ncm - 1u;
-                    unsigned long long const mk = __ballot(push);
-                    if (push)
-                    {
-                        int const pos = rawcount + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-                        raw->j[wave][pos] = (unsigned)(base + off);
-                        raw->amp[wave][pos] = amp;
-                        raw->idx[wave][pos] = (unsigned short)((c - 3 + k - A0) | (k << 12));
-                    }
-                    rawcount += __popcll(mk);
-                    if (rawcount >= 64)
-                    {
-                        rawcount -= 64;
-                        drain_raw(rawcount, 64);
-                    }
-                }
             }
+            // ---- core points (|x| < XLIM1: Humlicek regions 2-4) -> raw queue (line, strength, y, shift coefficient, grid
+            // point and molecule slot); full batches are given the reference's x (drain_raw).
+            // Bits 0-6: points of the lane's first line, 7-13: of its second ----
+            unsigned nc2 = ncm[0] | (ncm[1] << 7);
+            while (ballot_b(nc2 != 0u) != 0ull)
             {
-                unsigned long long any_handed = 0ull;
-#pragma unroll
-                for (int q = 0; q < LEANP; ++q)
+                bool const push = nc2 != 0u;
+                int const kb = push ? __builtin_ctz(nc2) : 0;
+                nc2 &= nc2 - 1u;
+                bool const second = kb >= 7;
+                int const k = second ? kb - 7 : kb;
+                unsigned long long const mk = ballot_b(push);
+                if (push)
                 {
-                    any_handed |= handed[q];
+                    int const pos = rawcount + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                    raw->j[wave][pos] = (unsigned)base + 2u*(unsigned)lane + (second ? 1u : 0u);
+                    raw->amp[wave][pos] = second ? amp.y : amp.x;
+                    raw->y[wave][pos] = second ? y.y : y.x;
+                    raw->delta[wave][pos] = second ? dsh.y : dsh.x;
+                    raw->idx[wave][pos] = (unsigned)((second ? c[1] : c[0]) - 3 + k - A0) | ((unsigned)k << 12) | ((second ? si[1] : si[0]) << 16);
                 }
-                if (any_handed != 0ull)
+                rawcount += __popcll(mk);
+                if (rawcount >= 64)
                 {
-                    if (lane == 0)
-                    {
-                        raw->xl_base[wave][xcount] = (unsigned)(base - jbeg);
-#pragma unroll
-                        for (int q = 0; q < LEANP; ++q)
-                        {
-                            raw->xl_mask[wave][xcount][q] = handed[q];
-                        }
-                    }
-                    ++xcount;
-                }
-            }
-            // ---- the row sums: sixteen moment sums (eight per cell) end in sixteen lanes, eight near-field sums in eight ----
-#ifdef GRT_ABL_NOREDUCE
-            if (rem > 0) return;
-#endif
-            {
-                float t;
-                int cell;
-                if (one_cell)
-                {
-                    t = row_sum_transposed(m0, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0);       // value (lane >> 1) & 7, twice
-                    t = (lane & 1) == 0 ? t : 0.f;
-                    cell = cr;
-                }
-                else
-                {
-                    t = row_sum_two_groups(m0, m1, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0, (lane & 1) != 0);
-                    cell = cr + ((lane >> 3) & 1);
-                }
-                int const kmom = one_cell ? (lane >> 1) & 7 : lane & 7;
-#ifdef GRT_ABL_NOLDSADD
-                if ((t == 123.456f) & (cell < F1))
-#else
-                if ((t != 0.f) & (cell < F1))
-#endif
-                {
-                    mom_add(kmom, cell, t);
-                }
-                float const s8 = row_sum_transposed(nvs, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0);
-#ifdef GRT_ABL_NOLDSADD
-                if (((lane & 1) == 0) & (s8 == 123.456f))
-#else
-                if (((lane & 1) == 0) & (s8 != 0.f))
-#endif
-                {
-                    GRT_ACC_ADD(&acc[cr - 3 + ((lane >> 1) & 7) - A0], (double)s8);
+                    rawcount -= 64;
+                    drain_raw(rawcount, 64);
                 }
             }
         }
@@ -1873,7 +1873,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         {
             if (base < jend)
             {
-                lean_fetch(base, 0);
+                lean_fetch(base);
             }
             for (; base < jend; base += walk_stride)
             {
@@ -1900,7 +1900,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
             if (x < xcount)
             {
                 listed = true;
-                bj = jbeg + raw->xl_base[wave][x];
+                bj = jal + raw->xl_base[wave][x];
             }
         }
         if (!listed)
@@ -2197,14 +2197,14 @@ __global__ __launch_bounds__(kBlock) void gas_optics_far_kernel(GrtGasOpticsArgs
     }
     int const cell0 = F0 - fsteps;
     float const *gm = a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*a.gmom_stride;       // [cell][8]
-    // the cells' moments stay cell-major in LDS, as they lie in global memory: [cell][8] -- staged 16 bytes per lane, and read
-    // by the gather two ds_read_b128 per cell instead of eight ds_read_b32 (the gather was LDS-issue-bound: 0.90 -> 0.68 ms
-    // per shortwave launch)
+    // the cells' moments in LDS as two planes of 16-byte pieces: [2][cell][4] (moments 0-3 | 4-7) -- staged 16 bytes per
+    // lane, and read by the gather two ds_read_b128 per cell, neighbouring lanes neighbouring pieces (round 3 kept them
+    // [cell][8] as they lie in global memory: lanes then read every other piece)
     for (int i = tid; i < 2*ncell; i += kBlock)
     {
         long long const c = (long long)cell0 + (i >> 1);
         float4 const v = (c >= 0 && c < nw) ? reinterpret_cast<float4 const *>(gm + (uint64_t)c*kMom)[i & 1] : make_float4(0.f, 0.f, 0.f, 0.f);
-        reinterpret_cast<float4 *>(mom)[i] = v;
+        reinterpret_cast<float4 *>(mom)[(i & 1)*ncell + (i >> 1)] = v;
     }
     for (int i = tid; i < F1 - F0; i += kBlock)
     {
@@ -2252,8 +2252,8 @@ __global__ __launch_bounds__(kBlock) void gas_optics_far_kernel(GrtGasOpticsArgs
         for (int r = r_from; r <= r_to; ++r)
         {
             float const u = invr[r];
-            float4 const *ma = reinterpret_cast<float4 const *>(mom) + 2*(i + fsteps - r);    // cell f - r: offset +r
-            float4 const *mb = reinterpret_cast<float4 const *>(mom) + 2*(i + fsteps + r);    // cell f + r: offset -r
+            float4 const *ma = reinterpret_cast<float4 const *>(mom) + (i + fsteps - r);      // cell f - r: offset +r
+            float4 const *mb = reinterpret_cast<float4 const *>(mom) + (i + fsteps + r);      // cell f + r: offset -r
             float a[8], b[8];
             {
                 float4 const a0 = ma[0], b0 = mb[0];
@@ -2261,7 +2261,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_far_kernel(GrtGasOpticsArgs
                 b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w;
                 if (TERMS > 4)
                 {
-                    float4 const a1 = ma[1], b1 = mb[1];
+                    float4 const a1 = ma[ncell], b1 = mb[ncell];
                     a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
                     b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
                 }
@@ -2284,7 +2284,64 @@ __global__ __launch_bounds__(kBlock) void gas_optics_far_kernel(GrtGasOpticsArgs
         }
         return sum;
     };
-    for (int i = tid; i < F1 - F0; i += kBlock)
+    // Short windows with one near-field radius all around (1 cm-1: always): a lane takes TWO neighbouring points f, f + 1.
+    // Point f wants the cells f - r and f + r, point f + 1 the cells f + 1 - r and f + 1 + r: of the four, f + 1 - r and
+    // f + r were read one step earlier (as f - (r - 1) and f + 1 + (r - 1)), so a step reads two cells for four series
+    // instead of four for two (5.4 -> 4.8 ms per shortwave launch of 64 columns).
+    bool const pair_form = fsteps <= GRT_FAR_GRADED_MIN && rmin == rmax && rmin >= 1;
+    if (pair_form)
+    {
+        // (all eight terms at every distance, as the general loop below takes them for short windows: the same terms in the
+        // same order per point, the same doubles.  Fewer terms for the far cells -- five beyond r = 14 at 1 cm-1 -- were
+        // measured slower here: four short loops and their hand-overs instead of one, 4.84 -> 5.1 ms per shortwave launch)
+        float4 const *m4 = reinterpret_cast<float4 const *>(mom);
+        auto series = [](float4 const &lo, float4 const &hi, float u) -> float
+        {
+            float p = hi.w;
+            p = fmaf(p, u, hi.z); p = fmaf(p, u, hi.y); p = fmaf(p, u, hi.x);
+            p = fmaf(p, u, lo.w); p = fmaf(p, u, lo.z); p = fmaf(p, u, lo.y); p = fmaf(p, u, lo.x);
+            return p;
+        };
+        for (int i = 2*tid; i < F1 - F0; i += 2*kBlock)
+        {
+            double sum0 = 0., sum1 = 0.;
+            int const dn = i + fsteps, up = i + 1 + fsteps;           // LDS indices of cells f and f + 1
+            float4 l0 = m4[dn - rmin], l1 = m4[ncell + dn - rmin];    // cell f - rmin     = (f + 1) - (rmin + 1)
+            float4 u0 = m4[up + rmin], u1 = m4[ncell + up + rmin];    // cell f + 1 + rmin = f + (rmin + 1)
+            int r = rmin + 1;
+            for (; r + 1 <= fsteps; r += 2)
+            {
+                float4 const x0 = m4[dn - r], x1 = m4[ncell + dn - r], y0 = m4[up + r], y1 = m4[ncell + up + r];
+                {
+                    float const u = invr[r];
+                    float const uu = u*u;
+                    sum0 += (double)((series(x0, x1, u) + series(u0, u1, -u))*uu);
+                    sum1 += (double)((series(l0, l1, u) + series(y0, y1, -u))*uu);
+                }
+                l0 = m4[dn - r - 1]; l1 = m4[ncell + dn - r - 1]; u0 = m4[up + r + 1]; u1 = m4[ncell + up + r + 1];
+                {
+                    float const u = invr[r + 1];
+                    float const uu = u*u;
+                    sum0 += (double)((series(l0, l1, u) + series(y0, y1, -u))*uu);
+                    sum1 += (double)((series(x0, x1, u) + series(u0, u1, -u))*uu);
+                }
+            }
+            if (r <= fsteps)
+            {
+                float4 const x0 = m4[dn - r], x1 = m4[ncell + dn - r], y0 = m4[up + r], y1 = m4[ncell + up + r];
+                float const u = invr[r];
+                float const uu = u*u;
+                sum0 += (double)((series(x0, x1, u) + series(u0, u1, -u))*uu);
+                sum1 += (double)((series(l0, l1, u) + series(y0, y1, -u))*uu);
+            }
+            acc[i] += sum0;
+            if (i + 1 < F1 - F0)
+            {
+                acc[i + 1] += sum1;
+            }
+        }
+    }
+    for (int i = tid; i < F1 - F0 && !pair_form; i += kBlock)
     {
         int const f = F0 + i;
         int r = rmin + 1;

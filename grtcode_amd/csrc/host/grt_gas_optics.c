@@ -1134,10 +1134,12 @@ static int upload_lines(GasOptics_t *go, SortKey const *keys, uint64_t total, Gr
     size_t bytes = 0;
     size_t const sizes[12] = {8, 8, 4, 4, 4, 4, 4, 1, 1, 16, 16, 4};
     int const narr = with_lean ? 12 : 9;
+    uint64_t const npair = (total + 1)/2;
     for (int a = 0; a < narr; ++a)
     {
         off[a] = bytes;
-        bytes = align256(bytes + sizes[a]*total);
+        /* (the lean records are kept per PAIR of lines: an odd store has one line of padding) */
+        bytes = align256(bytes + sizes[a]*(a >= 9 ? 2*npair : total));
     }
     off[narr] = bytes;
     unsigned char *host = malloc(bytes);
@@ -1228,13 +1230,28 @@ static int upload_lines(GasOptics_t *go, SortKey const *keys, uint64_t total, Gr
             {
                 flags |= GRT_LEAN_GENERAL;
             }
-            la[4*k] = (float)(uu - c0);
-            memcpy(&la[4*k + 1], &ci, sizeof(ci));
-            la[4*k + 2] = (float)v0[k];
-            la[4*k + 3] = (flags & GRT_LEAN_GENERAL) ? 0.f : (float)ss;
-            lb[4*k] = yair[k]; lb[4*k + 1] = yself[k]; lb[4*k + 2] = en[k]; lb[4*k + 3] = delta[k];
+            /* pair q = k/2, half h = k%2: every field of the two lines side by side (GrtLineStore) */
+            uint64_t const q = k >> 1, h = k & 1;
+            float const sv = (flags & GRT_LEAN_GENERAL) ? 0.f : (float)ss;
+            float const v0f = (float)v0[k];
+            la[4*q + h] = (float)(uu - c0);
+            memcpy(&la[4*q + 2 + h], &ci, sizeof(ci));
+            la[4*(npair + q) + h] = v0f;
+            la[4*(npair + q) + 2 + h] = sv;
+            lb[4*q + h] = yair[k]; lb[4*q + 2 + h] = yself[k];
+            lb[4*(npair + q) + h] = en[k]; lb[4*(npair + q) + 2 + h] = delta[k];
             uint32_t const ti = (uint32_t)slot[k]*GRT_MAX_ISO + (uint32_t)(iso[k] >= 1 ? iso[k] - 1 : 0);
             lc[k] = ik | ((uint32_t)slot[k] << 8) | ((ti & 1023u) << 14) | flags;
+            if (k + 1 == total && h == 0)
+            {
+                /* padding: the last line again, strength zero (never a line of any workgroup's range; finite numbers for
+                   the lanes that prepare it) */
+                la[4*q + 1] = la[4*q]; la[4*q + 3] = la[4*q + 2];
+                la[4*(npair + q) + 1] = v0f; la[4*(npair + q) + 3] = 0.f;
+                lb[4*q + 1] = yair[k]; lb[4*q + 3] = yself[k];
+                lb[4*(npair + q) + 1] = en[k]; lb[4*(npair + q) + 3] = delta[k];
+                lc[k + 1] = lc[k] | GRT_LEAN_GENERAL;
+            }
         }
     }
     if (with_lean)
@@ -1266,12 +1283,14 @@ static int upload_lines(GasOptics_t *go, SortKey const *keys, uint64_t total, Gr
     st->slot = d + off[8];
     st->lean_a = st->lean_b = NULL;
     st->lean_c = NULL;
+    st->lean_npair = 0;
     st->lean_w0 = st->lean_wres = 0.;
     if (with_lean)
     {
         st->lean_a = (float const *)(d + off[9]);
         st->lean_b = (float const *)(d + off[10]);
         st->lean_c = (uint32_t const *)(d + off[11]);
+        st->lean_npair = npair;
         st->lean_w0 = go->bins.w0;
         st->lean_wres = go->bins.wres;
     }

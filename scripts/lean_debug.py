@@ -15,6 +15,8 @@ elif case == "dense":
     band = Band(tmp, 900.0, 1100.0, 1.0, 20000); col = syn.profile(2, 13)
 elif case == "sw":
     band = Band(tmp, 30000.0, 30600.0, 1.0, 20000, sw=True, with_cfc=False); col = syn.profile(3, 13)
+elif case == "det4":       # tests/test_gpu_deterministic.py, case 4
+    band = Band(tmp, 500.0, 900.0, 1.0, 8000); col = syn.profile(3, 21)
 elif case == "farir":
     band = Band(tmp, 40.0, 400.0, 1.0, 9000); col = syn.profile(0, 25)
 elif case.startswith("seed"):      # the cases of tests/test_gpu_moment_kernel.py::test_randomised_grids_profiles_and_launch_shapes
@@ -36,12 +38,14 @@ else:
     band = Band(tmp, 300.0, 700.0, 1.0, 6000); col = syn.profile(5, 13)
 V = col["p"].size
 lib = api.load_library(); device = api.create_device(0); orc = Oracle()
+if os.environ.get("DBG_DET"):
+    api.check(lib.grt_set_deterministic(1))
 want = band.oracle_tau(orc, orc, lib, col)
 out = {}
 for name, env in (("lean", "1"), ("general", "0")):
     os.environ["GRT_LEAN"] = env
     go, grid = band.gas_optics(device, V, from_file=False)
-    go.tune(fast=3); band.set_column(go, col)
+    go.tune(fast=3, tile=int(os.environ.get("DBG_TILE", "0"))); band.set_column(go, col)
     opt = api.OpticsObject(V - 1, grid, device)
     go.calculate_optical_depth(col["p"], col["t"], opt)
     out[name] = opt.read()[0]; print(name, go.last_launch()); opt.destroy(); go.destroy()
