@@ -134,6 +134,19 @@ __device__ __forceinline__ Prepared prepare_line(RawLine const &ln,
     return p;
 }
 
+// Two fp32 values in an aligned register pair: the operand form of gfx950's packed fp32 instructions (v_pk_fma_f32,
+// v_pk_mul_f32, v_pk_add_f32: one instruction, both halves; measured 4.6 cycles per wave against 2 x 3.3-4.2 for the plain
+// ones, profiles/r4_valu_mix2.txt).  The lean line loop (k_gas_optics_mp.hip) keeps its two
+// lines per lane in the halves; region 4 of the Voigt function below its -T and +T branches.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f splat2(float x) { return (v2f){x, x}; }
+__device__ __forceinline__ v2f rcp2(v2f a) { return (v2f){__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}; }
+__device__ __forceinline__ v2f exp2_2(v2f a) { return (v2f){__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)}; }
+__device__ __forceinline__ v2f rint2(v2f a) { return (v2f){rintf(a.x), rintf(a.y)}; }
+__device__ __forceinline__ unsigned long long ballot_b(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+__device__ __forceinline__ v2f sel2(bool c0, bool c1, v2f a, v2f b) { return (v2f){c0 ? a.x : b.x, c1 ? a.y : b.y}; }
+
 // RFM_voigt.c:172-277: Humlicek regions 1-4 for one point (region 0 is handled by the
 // callers).  Returns K before the final RSQRPI*REPWID scaling (:278).  The region
 // coefficients depend on y only; the reference caches them per line, we evaluate them
@@ -304,6 +317,9 @@ __device__ __forceinline__ double voigt_near(float xi, float y)
     // same sequence of roundings reproduces it; the divisions are hardware reciprocals refined to the
     // reference's rounding (quot_rounded) and exp(-x^2) the hardware exp2 after an fp64 range reduction)
     double k = 0.0;
+    // (round 4: the -T[J] and +T[J] branches of a term side by side in packed registers -- half the fp32 instructions of
+    // this region -- were measured SLOWER in the lean kernel, whose waves are at their register limit: longwave launch
+    // 32.3 -> 34.8 ms, shortwave 90.1 -> 91.8; so was one shared copy of the queues' evaluation code behind a call: 98.7)
     if (ONLY == 1 || (ONLY < 0 && abx <= xlim4))
     {
 #pragma unroll

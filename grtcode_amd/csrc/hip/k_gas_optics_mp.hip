@@ -78,18 +78,6 @@ __device__ __forceinline__ int dpp_i(int v)
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
 }
 
-// Two fp32 values in an aligned register pair: the operand form of gfx950's packed fp32 instructions (v_pk_fma_f32,
-// v_pk_mul_f32, v_pk_add_f32: one instruction, both halves; measured 4.6 cycles per wave against 2 x 3.3-4.2 for the plain
-// ones, profiles/r4_valu_mix2.txt).  The lean line loop keeps its two lines per lane in the halves.
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ v2f splat2(float x) { return (v2f){x, x}; }
-__device__ __forceinline__ v2f rcp2(v2f a) { return (v2f){__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)}; }
-__device__ __forceinline__ v2f exp2_2(v2f a) { return (v2f){__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)}; }
-__device__ __forceinline__ v2f rint2(v2f a) { return (v2f){rintf(a.x), rintf(a.y)}; }
-__device__ __forceinline__ unsigned long long ballot_b(bool b) { return __builtin_amdgcn_ballot_w64(b); }
-__device__ __forceinline__ v2f sel2(bool c0, bool c1, v2f a, v2f b) { return (v2f){c0 ? a.x : b.x, c1 ? a.y : b.y}; }
-
 // Wave-wide integer max as a scalar: rotations inside the rows of 16 lanes (every lane of a row
 // ends up with the row's extreme, whatever the direction of row_ror), then the four rows on the
 // scalar unit.
