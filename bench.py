@@ -387,7 +387,7 @@ class PlaceholderEngine:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=24)       # (a timed region of >= 3 s at ~134 ms per step)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cols", type=int, default=int(os.environ.get("GRT_BENCH_COLS", 64)), help="columns per GPU per step (weak scaling)")
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("GRT_BENCH_CHUNK", 64)), help="columns per launch of the pipeline "
@@ -686,7 +686,10 @@ def main():
                          "note": "measured on gfx950 (scripts/valu_mix*.hip, profiles/r4_valu_mix*.txt): at this kernel's occupancy a wave64 "
                                  "fp32 fma/mul/add occupies the pipe ~2.5-4 cycles, every fp64 op, conversion, compare, select and DPP "
                                  "move ~4.6, rcp/exp/sqrt ~10 -- so the two-cycle issue peak is not reachable with this instruction mix; "
-                                 "SQ_ACTIVE_INST_VALU of the PMC pass puts the pipe at >90 % busy"},
+                                 "SQ_ACTIVE_INST_VALU of the PMC pass puts the pipe at >90 % busy.  The lean loop's fp32 arithmetic "
+                                 "runs as packed instructions (v_pk_fma/mul/add_f32: two lines per instruction, 4.6 cycles), which "
+                                 "this count takes as one: fewer, longer instructions lower `frac` while the launch gets shorter -- "
+                                 "instructions_per_64_lines and avg_launch_ms are the figures to follow across rounds"},
             "roofline_hbm": {"kernel": f"{line_kernel} (line-by-line tau), SW-band launch", "bound": "hbm",
                              "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                              "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": dom_ms, "launches": ms[2][1],

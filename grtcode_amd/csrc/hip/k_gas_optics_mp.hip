@@ -1344,7 +1344,9 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
             a_norm = (float)(1./(3.14159265358979323846*a.wres));
             wres_v = wres_f;
             inv_wres_v = inv_wres_f;
+#ifndef GRT_LEAN_NOPIN
             asm volatile("" : "+v"(kh), "+v"(kl), "+v"(c2t), "+v"(pw), "+v"(pavg_f), "+v"(a_norm), "+v"(wres_v), "+v"(inv_wres_v));
+#endif
             // stimulated emission 1 - exp(c2 v0/T) (kernels.c:84): 1 to fp32 and beyond below exp(-20); the tile's lowest
             // wavenumber decides for the whole workgroup (sorted store, shifts of a fraction of a grid step)
             double const x2_tile = ((double)(-1.4387686f)*lay[2])*(a.w0 + ((double)F0 - 2.)*a.wres - 1.);
