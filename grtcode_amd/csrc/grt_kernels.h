@@ -51,9 +51,12 @@ typedef struct GrtLineStore
          lean_c [npair][2]: per line: bits 0-7   index of the temperature exponent, nexp*100 (255: not a whole number of
                         hundredths below 128), bits 8-13  molecule slot,  bits 14-23  slot*GRT_MAX_ISO + iso - 1,
                         bit 31     the line always takes the general path (strength outside the scaled fp32 range, ...) */
+    /*   lean_x [n][2] doubles: what the exact preparation of a core point needs of its line in ONE 16-byte load: the fp64
+                        centre v0, and yair, yself (two f32 in the second double's place) */
     float const *lean_a;
     float const *lean_b;
     uint32_t const *lean_c;
+    double const *lean_x;
     uint64_t lean_npair;
     double lean_w0, lean_wres;
 } GrtLineStore;

@@ -202,9 +202,9 @@ struct LeanRaw
     unsigned long long xl_mask[kWaves][kLeanListCap][kLeanMaxP];
     unsigned j[kWaves][kRawCap];             // the line
     float amp[kWaves][kRawCap];              // S(T) N_s
-    float y[kWaves][kRawCap];
     float delta[kWaves][kRawCap];            // its pressure shift coefficient
     unsigned idx[kWaves][kRawCap];           // accumulator index f - A0 | the point's k << 12 | the line's molecule slot << 16
+                                             // | the index of its temperature exponent << 22
     unsigned xl_base[kWaves][kLeanListCap];
 };
 
@@ -1378,11 +1378,13 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
     uint64_t const walk_first = a.deterministic ? (wave == 0 ? jal : jend) : jal + (uint64_t)wave*64*kLinesPerLane;
     unsigned const walk_stride = (a.deterministic ? 64u : (unsigned)kBlock)*kLinesPerLane;
 
-    // The raw queue's entries -- core points (|x| < XLIM1: Humlicek regions 2-4) -- get the reference's x, 64 at a time with
-    // all lanes busy, and are sorted into the class queues.  K(x, y) there changes by 2 x^2 times a relative change of x, so
-    // x has to be the reference's fp32 number to the bit: its fp64 expressions from the line's fp64 centre (general_block's;
-    // one 8-byte load per point -- everything else the entry brings along or LDS holds), REPWID rounded to fp32 as the
-    // reference has it.  y only scales smoothly: the lean loop's fp32 value serves.
+    // The raw queue's entries -- core points (|x| < XLIM1: Humlicek regions 2-4) -- get the reference's x and y, 64 at a time
+    // with all lanes busy, and are sorted into the class queues.  K(x, y) there changes by 2 x^2 times a relative change of
+    // x, and region 4's sums cancel so that only the reference's own sequence of fp32 roundings reproduces its value
+    // (gas_optics_dev.h): x AND y have to be the reference's fp32 numbers to the bit -- its fp64 expressions from the line's
+    // fp64 centre and its two broadening coefficients (general_block's; ONE 16-byte load per point, GrtLineStore.lean_x:
+    // everything else the entry brings along or LDS holds), REPWID rounded to fp32 as the reference has it.  (The loop's own fp32 y, 1e-7 off, made
+    // the shortwave launch 3 % shorter and three of 600 soak cases 2e-6 to 4e-6 wrong.)
     [[maybe_unused]] auto drain_raw = [&](int const first, int const count)
     {
         if constexpr (LEANP > 0)
@@ -1390,18 +1392,24 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
             bool const on = lane < count;
             int const i = first + (on ? lane : 0);
             unsigned const packed = raw->idx[wave][i];
+            unsigned const j = raw->j[wave][i];
             int const idx = (int)(packed & 4095u);                                      // f - A0
             // the centre index is the lean loop's (it is exact there, or the line would not be here): the point is its
             // grid point c + k - 3
             int const c = idx + A0 - ((int)((packed >> 12) & 15u) - 3);
-            double const wnoadj = a.lines.v0[raw->j[wave][i]] + (double)raw->delta[wave][i]*lay[0];     // kernels.c:44
+            // (the line's fp64 centre and its two broadening coefficients: one 16-byte load)
+            double2 const lx = reinterpret_cast<double2 const *>(a.lines.lean_x)[j];
+            float const yair = __int_as_float(__double2loint(lx.y)), yself = __int_as_float(__double2hiint(lx.y));
+            double const *ms = ms_l + ((packed >> 16) & 63u)*4;
+            double const wnoadj = lx.x + (double)raw->delta[wave][i]*lay[0];           // kernels.c:44
             int const s = c - fsteps < 0 ? 0 : c - fsteps;                             // kernels.c:435
-            double const alpha = ((double)0.83255461115f*wnoadj)*ms_l[(packed >> 16)*4 + 3];           // kernels.c:127
+            double const gamma = ptab[(packed >> 22) & 127u]*((double)yair*ms[1] + (double)yself*ms[0]);    // kernels.c:105-106
+            double const alpha = ((double)0.83255461115f*wnoadj)*ms[3];                // kernels.c:127
             double const r0 = (double)__builtin_amdgcn_rcpf((float)alpha);
             float const repwid = (float)((double)kSqrln2*(r0*fma(-alpha, r0, 2.0)));   // RFM_voigt.c:94
+            float const y = (float)((double)repwid*gamma);                             // RFM_voigt.c:95
             double const dwno = (double)s*a.wres + a.w0;                               // kernels.c:438
             float const xr = voigt_x(dwno, idx + A0 - s, a.wres, wnoadj, repwid);      // the reference's x
-            float const y = raw->y[wave][i];
             int const cls = on ? voigt_class<true, kSplit>(xr, y) : -1;
             // (RFM_voigt.c:278; the product of two fp32 numbers rounded once, as the general form's fp64 product rounded to fp32)
             queue_push(cls, raw->amp[wave][i]*(kRsqrpi*repwid), xr, y, (unsigned short)idx);
@@ -1823,8 +1831,8 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                     }
                 }
             }
-            // ---- core points (|x| < XLIM1: Humlicek regions 2-4) -> raw queue (line, strength, y, shift coefficient, grid
-            // point and molecule slot); full batches are given the reference's x (drain_raw).
+            // ---- core points (|x| < XLIM1: Humlicek regions 2-4) -> raw queue (line, strength, shift coefficient, grid point,
+            // molecule slot and exponent index); full batches are given the reference's x and y (drain_raw).
             // Bits 0-6: points of the lane's first line, 7-13: of its second ----
             unsigned nc2 = ncm[0] | (ncm[1] << 7);
             while (ballot_b(nc2 != 0u) != 0ull)
@@ -1840,9 +1848,9 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                     int const pos = rawcount + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
                     raw->j[wave][pos] = (unsigned)base + 2u*(unsigned)lane + (second ? 1u : 0u);
                     raw->amp[wave][pos] = second ? amp.y : amp.x;
-                    raw->y[wave][pos] = second ? y.y : y.x;
                     raw->delta[wave][pos] = second ? dsh.y : dsh.x;
-                    raw->idx[wave][pos] = (unsigned)((second ? c[1] : c[0]) - 3 + k - A0) | ((unsigned)k << 12) | ((second ? si[1] : si[0]) << 16);
+                    raw->idx[wave][pos] = (unsigned)((second ? c[1] : c[0]) - 3 + k - A0) | ((unsigned)k << 12) | ((second ? si[1] : si[0]) << 16)
+                                         | (((second ? rc[1] : rc[0]) & 127u) << 22);
                 }
                 rawcount += __popcll(mk);
                 if (rawcount >= 64)
@@ -3087,7 +3095,7 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
         size_t lds = mp_lds_bytes(nacc, ncell, 0, a->lay.num_slots, tree, tree && ncell == 0 ? a->tile : 0);
         // the lean line loop: single-level gather, packed records built for this very grid, room for its tables in LDS
         b.lean = !tree && a->probe == NULL && lean_wanted() && a->lines.lean_a != NULL && a->lines.lean_b != NULL
-                 && a->lines.lean_c != NULL && a->lines.lean_w0 == a->w0 && a->lines.lean_wres == a->wres
+                 && a->lines.lean_c != NULL && a->lines.lean_x != NULL && a->lines.lean_w0 == a->w0 && a->lines.lean_wres == a->wres
                  && a->lines.n < 0xffffffffull && halo >= 8 && nacc <= 4096
                  && lds + lean_lds_bytes(a->lay.num_slots) <= kLdsPerWorkgroup;
         if (b.lean)

@@ -1130,10 +1130,10 @@ static int upload_lines(GasOptics_t *go, SortKey const *keys, uint64_t total, Gr
                         size_t *bytes_out, int with_lean)
 {
     GrtGasOpticsImpl *im = impl_of(go);
-    size_t off[13];
+    size_t off[14];
     size_t bytes = 0;
-    size_t const sizes[12] = {8, 8, 4, 4, 4, 4, 4, 1, 1, 16, 16, 4};
-    int const narr = with_lean ? 12 : 9;
+    size_t const sizes[13] = {8, 8, 4, 4, 4, 4, 4, 1, 1, 16, 16, 4, 16};
+    int const narr = with_lean ? 13 : 9;
     uint64_t const npair = (total + 1)/2;
     for (int a = 0; a < narr; ++a)
     {
@@ -1196,6 +1196,7 @@ static int upload_lines(GasOptics_t *go, SortKey const *keys, uint64_t total, Gr
            the temperature exponent as an index into the per-layer table of (296/T)^(k/100) (kernels.c:105). */
         float *la = (float *)(host + off[9]), *lb = (float *)(host + off[10]);
         uint32_t *lc = (uint32_t *)(host + off[11]);
+        double *lx = (double *)(host + off[12]);
         double const w0 = go->bins.w0, wres = go->bins.wres;
         for (uint64_t k = 0; k < total; ++k)
         {
@@ -1242,6 +1243,9 @@ static int upload_lines(GasOptics_t *go, SortKey const *keys, uint64_t total, Gr
             lb[4*(npair + q) + h] = en[k]; lb[4*(npair + q) + 2 + h] = delta[k];
             uint32_t const ti = (uint32_t)slot[k]*GRT_MAX_ISO + (uint32_t)(iso[k] >= 1 ? iso[k] - 1 : 0);
             lc[k] = ik | ((uint32_t)slot[k] << 8) | ((ti & 1023u) << 14) | flags;
+            lx[2*k] = v0[k];
+            memcpy((char *)&lx[2*k + 1], &yair[k], 4);
+            memcpy((char *)&lx[2*k + 1] + 4, &yself[k], 4);
             if (k + 1 == total && h == 0)
             {
                 /* padding: the last line again, strength zero (never a line of any workgroup's range; finite numbers for
@@ -1283,6 +1287,7 @@ static int upload_lines(GasOptics_t *go, SortKey const *keys, uint64_t total, Gr
     st->slot = d + off[8];
     st->lean_a = st->lean_b = NULL;
     st->lean_c = NULL;
+    st->lean_x = NULL;
     st->lean_npair = 0;
     st->lean_w0 = st->lean_wres = 0.;
     if (with_lean)
@@ -1290,6 +1295,7 @@ static int upload_lines(GasOptics_t *go, SortKey const *keys, uint64_t total, Gr
         st->lean_a = (float const *)(d + off[9]);
         st->lean_b = (float const *)(d + off[10]);
         st->lean_c = (uint32_t const *)(d + off[11]);
+        st->lean_x = (double const *)(d + off[12]);
         st->lean_npair = npair;
         st->lean_w0 = go->bins.w0;
         st->lean_wres = go->bins.wres;
