@@ -657,8 +657,10 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         }
     };
 
-    // A near-centre point per lane (cls: its class of formula, -1: none) goes to its class's queue; full batches of 64
-    // are evaluated off the top, and a queue that cannot take this push is emptied first.
+    // A near-centre point per lane (cls: its class of formula, -1: none) goes to its class's queue, which is evaluated in
+    // FULL batches of 64 -- one formula, all lanes busy.  A push that does not fit (the queues hold 64 ... 88 entries) is
+    // split: as many points as fill the batch go in, the batch is evaluated, the rest follow.  (Until round 4 a queue that
+    // could not take a push was emptied first, whatever it held: with 64-entry queues most batches were partial ones.)
     auto queue_push = [&](int const cls, float const amp_q, float const xr, float const y_q, unsigned short const idx_q)
     {
 #pragma unroll
@@ -671,25 +673,30 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
             }
             int const npush = __popcll(mk);
             if constexpr (PROBE) pc_near += (unsigned)npush;
-            if (qcount[q] + npush > Queue::capacity)
+            int const rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+            int pos = qcount[q] + rank;                  // (qcount < 64 on entry: pos < 64 + 64)
+            bool mine = cls == q;
+            if (mine & (pos < 64))
             {
-                drain(q, 0, qcount[q]);
-                qcount[q] = 0;
-            }
-            if (cls == q)
-            {
-                int const pos = qcount[q] + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32),
-                                __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
                 nq->amp[q][wave][pos] = amp_q;
                 nq->xi[q][wave][pos] = xr;
                 nq->y[q][wave][pos] = y_q;
                 nq->idx[q][wave][pos] = idx_q;
+                mine = false;
             }
             qcount[q] += npush;
             if (qcount[q] >= 64)
             {
+                drain(q, 0, 64);                         // a full batch
                 qcount[q] -= 64;
-                drain(q, qcount[q], 64);        // a full batch off the top
+                pos -= 64;
+                if (mine)
+                {
+                    nq->amp[q][wave][pos] = amp_q;
+                    nq->xi[q][wave][pos] = xr;
+                    nq->y[q][wave][pos] = y_q;
+                    nq->idx[q][wave][pos] = idx_q;
+                }
             }
         }
     };
