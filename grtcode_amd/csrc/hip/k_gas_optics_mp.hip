@@ -1842,8 +1842,23 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
             // molecule slot and exponent index); full batches are given the reference's x and y (drain_raw).
             // Bits 0-6: points of the lane's first line, 7-13: of its second ----
             unsigned nc2 = ncm[0] | (ncm[1] << 7);
-            while (ballot_b(nc2 != 0u) != 0ull)
+            // (the wave's last lean block also empties the raw queue: ONE place in the code prepares entries, so the kernel
+            // carries one copy less of that and of the four evaluation formulas behind it)
+            bool const flush = base + walk_stride >= jend || xcount == kLeanListCap;
+            for (;;)
             {
+                bool const more = ballot_b(nc2 != 0u) != 0ull;
+                if (rawcount >= 64 || (flush && !more && rawcount > 0))
+                {
+                    int const n = rawcount < 64 ? rawcount : 64;
+                    rawcount -= n;
+                    drain_raw(rawcount, n);
+                    continue;
+                }
+                if (!more)
+                {
+                    break;
+                }
                 bool const push = nc2 != 0u;
                 int const kb = push ? __builtin_ctz(nc2) : 0;
                 nc2 &= nc2 - 1u;
@@ -1860,11 +1875,6 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                                          | (((second ? rc[1] : rc[0]) & 127u) << 22);
                 }
                 rawcount += __popcll(mk);
-                if (rawcount >= 64)
-                {
-                    rawcount -= 64;
-                    drain_raw(rawcount, 64);
-                }
             }
         }
     };
@@ -1888,11 +1898,6 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                     base += walk_stride;
                     break;
                 }
-            }
-            if (rawcount > 0)
-            {
-                drain_raw(0, rawcount);
-                rawcount = 0;
             }
         }
     }
