@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Turn gpurun_out/prof_<tag>/ (written by scripts/profile_round.sh on the GPU box) into the small,
-tracked summaries under profiles/: kernel stats, HBM-side traffic per launch (FETCH_SIZE doubled as
-MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as is, both in KiB units), SQ counters.
+tracked summaries under profiles/: kernel stats, HBM-side traffic per launch (reads from the L2's read requests by size
+where that pass exists -- exact; else FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950's vector loads;
+WRITE_SIZE as is, in KiB units), SQ counters.
 
     python scripts/summarize_profile.py r1
 """
@@ -60,6 +61,7 @@ def counters(sub, names):
 
 fetch = counters("pmc_fetch", {"FETCH_SIZE"})
 write = counters("pmc_write", {"WRITE_SIZE"})
+rdreq = counters("pmc_rdreq", {"TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"})
 sq = counters("pmc_sq", {"SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY",
                          "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES"})
 summary = {"tag": tag, "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras  (%d columns per step in launches of %d)" % (bench["config"]["columns_per_step"], bench["config"]["chunk_columns"]),
@@ -75,6 +77,16 @@ for key in sorted(set(fetch) | set(write)):
              "hbm_bytes_per_launch": (2.0 * (f or 0.0) + (w or 0.0)) * 1024.0,
              "note": "FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B); WRITE_SIZE checked against the "
                      "memset/solver kernels' known byte counts in this run"}
+    if key in rdreq:
+        r = {c: mean(v) for c, v in rdreq[key].items()}
+        rb = 32.0*r.get("TCC_EA0_RDREQ_32B_sum", 0.0) + 64.0*r.get("TCC_EA0_RDREQ_64B_sum", 0.0) + 128.0*r.get("TCC_EA0_RDREQ_128B_sum", 0.0)
+        entry["read_requests_per_launch"] = r
+        entry["read_bytes_per_launch"] = rb
+        entry["hbm_bytes_from_fetch_size_doubled"] = entry["hbm_bytes_per_launch"]
+        entry["hbm_bytes_per_launch"] = rb + (w or 0.0)*1024.0
+        entry["note"] = ("reads: the L2's memory-side read requests by size, 32 n32 + 64 n64 + 128 n128 (exact: "
+                         "profiles/r4_fetch_calibration.json); FETCH_SIZE doubled is kept beside it; WRITE_SIZE checked against "
+                         "the memset/solver kernels' known byte counts")
     if key in sq:
         entry["sq"] = {c: mean(v) for c, v in sq[key].items()}
     summary["kernels"][f"{name}@{grid}"] = entry
