@@ -1215,6 +1215,59 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
             }
         };
         std::integral_constant<int, 0> const general{};
+        // Two passes of sixteen points at once, [fbp, fbp + 16) and [fbp + 16, fbp + 32), their tokens and line shapes in the
+        // halves of packed fp32 registers (MODE 1 or 2 for both: the fine grids' long near fields).  The same operations in
+        // the same order as two calls of ring_block: the same tokens.
+        [[maybe_unused]] auto ring_block2 = [&](int fbp, auto mode_tag)
+        {
+            constexpr int MODE = decltype(mode_tag)::value;
+            static_assert(MODE == 0 || MODE == 1 || MODE == 2, "general | inside every line's near field | ... and beyond region 1");
+            if constexpr (PROBE)
+            {
+                pc_ring += 32;
+                pc_ring_inside += MODE == 1 ? 32 : 0;
+                pc_ring_lorentz += MODE == 2 ? 32 : 0;
+            }
+            v2f token = splat2(0.f);
+            float slotf = (float)(lane & 15);
+            v2f const base_rel = {(float)(fbp - c), (float)(fbp + 16 - c)};
+            v2f const wr2 = splat2(wr), ndcr2 = splat2(ndcr), yq2 = splat2(yq), cl2 = splat2(cl), amp2 = splat2(amp_f32);
+#pragma unroll 4
+            for (int t = 0; t < 16; ++t)
+            {
+                v2f const rel = base_rel + slotf;
+                v2f const xi = pk_fma(rel, wr2, ndcr2);
+                v2f const xq = xi*xi;
+                v2f const d = pk_fma(xi, xi, yq2);
+                v2f kf;
+                if (MODE == 2)
+                {
+                    kf = cl2*rcp2(d);
+                }
+                else
+                {
+                    bool const outer0 = xq.x >= xq_near, outer1 = xq.y >= xq_near;
+                    bool const reg10 = outer0 & (xq.x < x0q), reg11 = outer1 & (xq.y < x0q);
+                    v2f const den = sel2(reg10, reg11, pk_fma(xq, d2r + xq, splat2(d0r)), d);
+                    v2f const num = sel2(reg10, reg11, cl2*(a0 + xq), cl2);
+                    v2f const off = rel - mid;
+                    bool const in0 = MODE == 1 || fabsf(off.x) <= half, in1 = MODE == 1 || fabsf(off.y) <= half;
+                    kf = sel2(outer0 & in0, outer1 & in1, num*rcp2(den), splat2(0.f));
+                }
+                token = pk_fma(amp2, kf, token);
+                token = (v2f){dpp_f<0x121>(token.x), dpp_f<0x121>(token.y)};
+                slotf = dpp_f<0x121>(slotf);
+            }
+            int const f = fbp + (int)slotf;
+            if (f <= fe)
+            {
+                GRT_ACC_ADD(&acc[f - A0], (double)token.x);
+            }
+            if (f + 16 <= fe)
+            {
+                GRT_ACC_ADD(&acc[f + 16 - A0], (double)token.y);
+            }
+        };
         std::integral_constant<int, 3> const lean{};
         // the distance from the centre index within which a line has region-1 points (none: pure Lorentz line)
         float const reach1 = (valid & !lorentz) ? fmaf(xlim0, rwr, 1.5f) : -1e30f;
@@ -1236,6 +1289,30 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
             else
             {
                 int const fbp = fb + done;
+                if constexpr (TREE)
+                {
+                    if (span >= 128 && left >= 32)
+                    {
+                        // thirty-two points inside every line's near field: both blocks of sixteen in one pass
+                        bool const inside = (fbp >= lo_n) & (fbp + 31 <= hi_n);
+                        float const r0 = (float)(fbp - c);
+                        bool const reg1_here = (r0 + 31.f > -reach1) & (r0 < reach1);
+                        if (__ballot(valid & !inside) != 0ull)
+                        {
+                            ring_block2(fbp, general);
+                        }
+                        else if (__ballot(valid & reg1_here) != 0ull)
+                        {
+                            ring_block2(fbp, std::integral_constant<int, 1>{});
+                        }
+                        else
+                        {
+                            ring_block2(fbp, std::integral_constant<int, 2>{});
+                        }
+                        done += 32;
+                        continue;
+                    }
+                }
                 if (TREE && span >= 128)
                 {
                     bool const inside = (fbp >= lo_n) & (fbp + 15 <= hi_n);
