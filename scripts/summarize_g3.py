@@ -34,7 +34,8 @@ for r in csv.DictReader(open(newest(os.path.join(src, "pmc_sq", "*", "*counter_c
         cnt[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 mean = lambda v: sum(v) / len(v)
 # traffic passes (optional): FETCH_SIZE / WRITE_SIZE in KiB (FETCH doubled on gfx950, as in summarize_profile.py), L2 atomics
-for sub in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_TCC_ATOMIC_sum_TCC_EA0_ATOMIC_sum"):
+for sub in ("pmc_FETCH_SIZE", "pmc_WRITE_SIZE", "pmc_TCC_ATOMIC_sum_TCC_EA0_ATOMIC_sum",
+            "pmc_TCC_EA0_RDREQ_32B_sum_TCC_EA0_RDREQ_64B_sum_TCC_EA0_RDREQ_128B_sum"):
     files = glob.glob(os.path.join(src, sub, "*", "*counter_collection.csv"))
     if files:
         for r in csv.DictReader(open(sorted(files, key=os.path.getmtime)[-1])):
@@ -50,6 +51,12 @@ for k, v in dur.items():
             e["issue_utilisation"] = e["sq"]["SQ_INSTS_VALU"] / (1024 * ms * 1e-3 * 2.4e9 * 0.5)
         if "FETCH_SIZE" in e["sq"] and "WRITE_SIZE" in e["sq"]:
             e["hbm_bytes_per_launch"] = 1024.0 * (2.0 * e["sq"]["FETCH_SIZE"] + e["sq"]["WRITE_SIZE"])
+            if "TCC_EA0_RDREQ_128B_sum" in e["sq"]:
+                # exact reads (profiles/r4_fetch_calibration.json); the FETCH_SIZE-doubled figure is kept beside it
+                e["hbm_bytes_from_fetch_size_doubled"] = e["hbm_bytes_per_launch"]
+                e["read_bytes_per_launch"] = (32.0*e["sq"].get("TCC_EA0_RDREQ_32B_sum", 0.0) + 64.0*e["sq"].get("TCC_EA0_RDREQ_64B_sum", 0.0)
+                                              + 128.0*e["sq"]["TCC_EA0_RDREQ_128B_sum"])
+                e["hbm_bytes_per_launch"] = e["read_bytes_per_launch"] + 1024.0*e["sq"]["WRITE_SIZE"]
             e["hbm_gb_per_s"] = e["hbm_bytes_per_launch"] / (ms * 1e-3) / 1e9
     g3["kernels"][k] = e
 path = os.path.join(ROOT, "profiles", "traffic_latest.json")
