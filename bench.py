@@ -719,8 +719,10 @@ def main():
         # the solvers (fused form: Rayleigh + optics combination + solver + spectral trapezoid in one kernel).  HBM view
         # with SURVEY a19/a20's algorithmic bytes of the materialised interface (1 944 / 2 440 B per wavenumber) and with
         # what the fused kernels must move (tau_gas once + the per-wavenumber tables); the shortwave kernel's arithmetic
-        # (two delta-Eddington solutions per layer: ~13 divisions, 6 exp in fp64) is done once, in the first sweep, which
-        # parks the five properties of every layer for the second: `traffic_with_park`
+        # (two delta-Eddington solutions per layer: ~13 divisions, 6 exp in fp64) is done once, in ONE sweep from the top
+        # (round 4: the slab's direct-beam reflectance and upward transmission ride along, nothing is parked; with
+        # GRT_SW_TWO_SWEEPS=1, or a user level between top and surface, the first of two sweeps parks the five properties
+        # of every layer for the second: `traffic_with_park`)
         sol = {}
         for name, tag, n, surv, fused_b in (("lw", 3, n_lw, 16.0 * L + 8 + 16.0 * V, 8.0 * L + 8), ("sw", 4, n_sw, 24.0 * L + 24 + 16.0 * V, 8.0 * L + 24)):
             if ms[tag][1]:
@@ -730,14 +732,13 @@ def main():
                              "frac_hbm_survey": surv * n * cols_launch / t / 1e9 / HBM_PEAK_GBS,
                              "compulsory_bytes_fused": fused_b * n * cols_launch, "achieved_gb_per_s_fused": fused_b * n * cols_launch / t / 1e9,
                              "traffic": solver_traffic.get(name + "_kernel")}
-                if name == "sw":
-                    # tau_gas once, albedo + solar, layer properties (5 L rows) written and read back (round 4: the 2 V rows of
-                    # reflectances are no longer parked -- only three levels' fluxes leave the fused kernel)
+                if name == "sw" and os.environ.get("GRT_SW_TWO_SWEEPS", "0") == "1":
+                    # tau_gas once, albedo + solar, layer properties (5 L rows) written and read back
                     park_b = (8.0 * L + 24 + 2 * 8.0 * (5 * L)) * n * cols_launch
                     sol[name].update({"traffic_with_park": park_b, "achieved_gb_per_s_with_park": park_b / t / 1e9,
                                       "frac_hbm_with_park": park_b / t / 1e9 / HBM_PEAK_GBS})
-        line["roofline_solvers"] = dict(sol, bound="hbm (shortwave: layer properties parked by the first sweep, read back by the second); "
-                                                   "latency (longwave: 26 000 threads)", peak=HBM_PEAK_GBS, unit="GB/s")
+        line["roofline_solvers"] = dict(sol, bound="fp64 arithmetic (shortwave: two delta-Eddington solutions per layer and wavenumber in one "
+                                                   "sweep, tau_gas read once); latency (longwave: 26 000 threads)", peak=HBM_PEAK_GBS, unit="GB/s")
         if world == 1 and not args.no_extras:
             # what an unchanged caller of calculate_optical_depth gets: the reference-order form (fast = 0)
             wl.go_lw.tune(fast=0, tile=args.tile, nslice=args.lw_nslice)

@@ -245,6 +245,9 @@ typedef struct GrtSwArgs
     double const *tau_gas, *n_layer;
     double w0;
     double *partials, *park;
+    /* fused form, no flux asked for between top and surface (user_level -1, 0 or num_levels - 1): ONE sweep from the top,
+       nothing parked (k_shortwave.hip); 0: the two sweeps of the reference's order (GRT_SW_TWO_SWEEPS=1 in the environment) */
+    int one_sweep;
 } GrtSwArgs;
 int grt_launch_sw(void *stream, GrtSwArgs const *a);
 

@@ -187,6 +187,54 @@ __global__ __launch_bounds__(kBlock) void sw_kernel(GrtSwArgs a)
         return layer_props(omega[o], g[o], tau[o], mu_dir, mu_dif);
     };
 
+    // Fused form, no flux asked for between the top and the surface (user level -1, 0 or L -- the pipeline's usual call):
+    // ONE sweep, top to surface, nothing parked.  The reference's downward sweep (shortwave.c:299-329) carries the direct
+    // beam, the diffuse beam over a black lower boundary and the reflectance R_up of the atmosphere above; two more numbers
+    // ride along -- Rd, the reflectance of the slab above to the direct beam, and Tu, its transmission of diffuse light
+    // from below to the top: adding layer p below the slab,
+    //     Rd' = Rd + Tu (dir Rdir_p + dif Rdif_p) C,   Tu' = Tu Tdif_p C,   C = 1/(1 - Rdif_p R_up)
+    // (the slab's own reflection plus what layer p sends back up through it; all orders of reflection between the two in
+    // C).  At the surface the reference's expressions give the fluxes there, and the top's upward flux is
+    // Rd + Tu x (the upward flux at the surface): the adding method's identity for what shortwave.c:280-294 builds from
+    // the bottom (R_dir_downward[0]) -- the same number to rounding (1e-15), not to the bit; the surface fluxes are the
+    // reference's own operations.  Two delta-Eddington solutions per layer instead of two plus 80 bytes per layer and
+    // wavenumber written and read back (16.8 GB per launch of 64 columns).
+    if (FUSED && (user < 0 || user == 0 || user == L) && a.one_sweep)
+    {
+        double dir = 1., dif = 0., Ru = 0., Rd = 0., Tu = 1.;
+        for (int j = 0; j < L; ++j)
+        {
+            LayerProps const p = props_of(j);
+            double const C = 1./(1. - p.Rdif*Ru);
+            Rd = Rd + Tu*((dir*p.Rdir + dif*p.Rdif)*C);
+            Tu = Tu*(p.Tdif*C);
+            dif = (dir*p.Rdir*Ru + dif)*p.Tdif*C + dir*(p.Tdir - p.Tpure);          // shortwave.c:312-316
+            Ru = p.Rdif + p.Tdif*p.Tdif*Ru*C;                                        // :299-306
+            dir *= p.Tpure;
+        }
+        double const scale = a.solar[ii]*mu_dir;
+        double const tsi = a.tsi[col];
+        double const rdir = a.alb_dir[(uint64_t)col*a.alb_stride + ii], rdif = a.alb_dif[(uint64_t)col*a.alb_stride + ii];
+        double const B = 1./(1. - rdif*Ru);
+        double const up_s = (dir*rdir + dif*rdif)*B;                                // :318-329 at the surface
+        double const dn_s = dir*(1. + rdir*Ru*B) + dif*B;
+        double const up_t = Rd + Tu*up_s;
+        out[0] = tsi*(up_t*scale);
+        out[3] = tsi*(1.*scale);
+        out[1] = tsi*(up_s*scale);
+        out[4] = tsi*(dn_s*scale);
+        out[2] = user == 0 ? out[0] : (user == L ? out[1] : 0.);
+        out[5] = user == 0 ? out[3] : (user == L ? out[4] : 0.);
+        double const wt = !live ? 0. : ((i == 0 || i + 1 == nw) ? 0.5*a.dw : a.dw);
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+        {
+            out[k] *= wt;
+        }
+        block_partials<6, kBlock>(out, a.partials, (uint64_t)col*6, gridDim.x, blockIdx.x);
+        return;
+    }
+
     // sweep 1: shortwave.c:280-294
     double Rdir_dn = a.alb_dir[(uint64_t)col*a.alb_stride + ii];
     double Rdif_dn = a.alb_dif[(uint64_t)col*a.alb_stride + ii];

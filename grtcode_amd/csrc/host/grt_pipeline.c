@@ -371,6 +371,11 @@ EXTERN int grt_pipeline_run(GrtPipeline_t *p, GrtColumns_t const *cols, fp_t *fl
                 a.tsi = p->small_d + p->off_tsi; a.solar = p->solar_d;
                 a.user_level = p->user_level;
                 a.partials = b->partials; a.park = b->park;
+                {
+                    /* (read at every step, so that a test can compare the two forms in one process) */
+                    char const *env = getenv("GRT_SW_TWO_SWEEPS");
+                    a.one_sweep = !(env != NULL && env[0] == '1');
+                }
                 slot = grt_profile_begin(s, 4);
                 krc = grt_launch_sw(s, &a);
                 grt_profile_end(s, slot);

@@ -186,6 +186,42 @@ def test_fused_production_pipeline_equals_materialised_pipeline(bands, oracle, l
     go_sw.destroy()
 
 
+@pytest.mark.parametrize("user_level", [-1, 0, 15])
+def test_one_sweep_shortwave_solver_equals_the_two_sweeps(bands, lib, device, user_level, monkeypatch):
+    """The fused shortwave solver with no flux asked for between top and surface runs ONE sweep from the top (k_shortwave.hip:
+    the slab's direct-beam reflectance and its upward diffuse transmission ride along with the reference's downward sweep)
+    instead of the reference's two with the layer properties parked in between (GRT_SW_TWO_SWEEPS=1).  The surface fluxes
+    are the reference's own operations -- the same doubles; the top's upward flux is the adding method's identity for what
+    the upward sweep builds -- the same number to rounding."""
+    lwb, swb = bands
+    V, ncol = 16, 4
+    cols = [syn.profile(40 + c, V) for c in range(ncol)]
+    go_lw, grid_lw = lwb.gas_optics(device, V)
+    go_sw, grid_sw = swb.gas_optics(device, V)
+    emis, alb = np.full(lwb.nw, 0.98), np.full(swb.nw, 0.35)
+    solar = api.create_solar_flux(grid_sw, swb.files["solar"])
+    gcols, keep = api.make_columns(cols, MOL_ORDER, cfc_order=(0, 1))
+    api.check(lib.grt_set_deterministic(1))
+    try:
+        got = {}
+        for two in ("0", "1"):
+            monkeypatch.setenv("GRT_SW_TWO_SWEEPS", two)
+            pipe = api.Pipeline(go_lw, go_sw, ncol, user_level, emis, alb, solar, spectral=False)
+            pipe.run(gcols)
+            got[two] = pipe.fluxes(ncol)
+            pipe.destroy()
+    finally:
+        api.check(lib.grt_set_deterministic(-1))
+    one, ref = got["0"], got["1"]
+    assert np.array_equal(one[:, :6], ref[:, :6])                                   # longwave: untouched
+    sw_one, sw_ref = one[:, 6:], ref[:, 6:]                                         # up top, up sfc, up user, down top, down sfc, down user
+    assert np.array_equal(sw_one[:, [1, 3, 4]], sw_ref[:, [1, 3, 4]])               # surface up/down, top down: the same doubles
+    assert np.max(np.abs(sw_one - sw_ref)) <= 1e-13*np.abs(sw_ref).max()
+    assert np.all(sw_ref[:, 0] > 0.0)
+    go_lw.destroy()
+    go_sw.destroy()
+
+
 def test_two_pipelines_on_two_lanes_equal_one(bands, lib, device):
     """grt_device_use_lane (grt_ext.h): two pipelines with gas-optics objects of their own, each on a stream of its own,
     batches alternating between them without a wait in between -- the fluxes are those of one pipeline run batch by batch."""
