@@ -377,7 +377,8 @@ __global__ __launch_bounds__(kBlock) void sw_kernel(GrtSwArgs a)
 extern "C" int grt_launch_sw(void *stream, GrtSwArgs const *a)
 {
     bool const fused = a->tau_gas != nullptr;
-    if (a->ncol < 1 || a->nw < 2 || (fused ? (a->partials == nullptr || a->park == nullptr || a->n_layer == nullptr)
+    bool const one_sweep = fused && a->one_sweep && (a->user_level < 0 || a->user_level == 0 || a->user_level == a->num_levels - 1);
+    if (a->ncol < 1 || a->nw < 2 || (fused ? (a->partials == nullptr || (a->park == nullptr && !one_sweep) || a->n_layer == nullptr)
                                            : (a->flux_up == nullptr || a->flux_down == nullptr)))
     {
         return (int)hipErrorInvalidValue;

@@ -66,16 +66,14 @@ static int band_alloc(GrtPipeline_t *p, GrtBand *b, GasOptics_t *gas)
     void *blk = NULL;
     if (!p->keep_spectra)
     {
-        /* fused form: tau_gas, (shortwave) the parked reflectances, the partial sums */
+        /* fused form: tau_gas and the partial sums (the shortwave solver's park block -- 2 V + 5 L rows per column, 10.8 GB
+           for 64 columns of the 1 cm-1 band -- is allocated when a launch first needs it: its two-sweep form, see run) */
         b->nblocks = grt_solver_blocks(b->n);
-        int const sw = b == &p->band[1];
-        /* (shortwave: 2 V rows of reflectances and 5 L rows of layer properties per column, k_shortwave.hip) */
-        size_t const park_rows = sw ? 2*V + 5*L : 0;
-        size_t const park = sizeof(double)*C*park_rows*b->n, part = sizeof(double)*C*6*b->nblocks;
-        GRT_TRY(grt_dev_alloc(p->device, &blk, opt + park + part));
+        size_t const part = sizeof(double)*C*6*b->nblocks;
+        GRT_TRY(grt_dev_alloc(p->device, &blk, opt + part));
         b->tau_gas = blk;
-        b->park = sw ? b->tau_gas + C*L*b->n : NULL;
-        b->partials = b->tau_gas + C*L*b->n + C*park_rows*b->n;
+        b->park = NULL;
+        b->partials = b->tau_gas + C*L*b->n;
         return GRTCODE_SUCCESS;
     }
     GRT_TRY(grt_dev_alloc(p->device, &blk, 4*opt + 2*flx + sizeof(double)*b->n));
@@ -209,6 +207,7 @@ static void grt_pipeline_release(GrtPipeline_t **pipeline)
     for (int b = 0; b < 2; ++b)
     {
         grt_dev_free(p->device, p->band[b].tau_gas);
+        grt_dev_free(p->device, p->band[b].park);
         grt_dev_free(p->device, p->band[b].rows_d);
     }
     grt_dev_free(p->device, p->small_d);
@@ -370,12 +369,20 @@ EXTERN int grt_pipeline_run(GrtPipeline_t *p, GrtColumns_t const *cols, fp_t *fl
                 a.alb_dir = p->albedo_d; a.alb_dif = p->albedo_d; a.alb_stride = 0;   /* driver.c:118-119 */
                 a.tsi = p->small_d + p->off_tsi; a.solar = p->solar_d;
                 a.user_level = p->user_level;
-                a.partials = b->partials; a.park = b->park;
+                a.partials = b->partials;
                 {
                     /* (read at every step, so that a test can compare the two forms in one process) */
                     char const *env = getenv("GRT_SW_TWO_SWEEPS");
                     a.one_sweep = !(env != NULL && env[0] == '1');
                 }
+                if (!(a.one_sweep && (p->user_level < 0 || p->user_level == 0 || p->user_level == V - 1)) && b->park == NULL)
+                {
+                    /* the two-sweep form: reflectances of 2 V levels and five properties of L layers per column and wavenumber */
+                    void *pk = NULL;
+                    GRT_TRY(grt_dev_alloc(p->device, &pk, sizeof(double)*(size_t)p->max_cols*(2*(size_t)V + 5*((size_t)V - 1))*b->n));
+                    b->park = pk;
+                }
+                a.park = b->park;
                 slot = grt_profile_begin(s, 4);
                 krc = grt_launch_sw(s, &a);
                 grt_profile_end(s, slot);

@@ -120,9 +120,10 @@ EXTERN int grt_pipeline_create(GrtPipeline_t **pipeline, GasOptics_t *lw_gas, Ga
                                fp_t const *albedo, fp_t const *solar_flux);
 /* keep_spectra = 0 (what grt_pipeline_create does): production form -- the solvers form Rayleigh and the optics
    combination in registers from tau_gas, keep nothing spectral and integrate in-kernel; device memory per column is
-   tau_gas -- plus, in the shortwave, the first sweep's parked rows [2 V + 5 L][n] per column (reflectances of V levels
-   twice, five properties of every layer: 422 rows at 60 layers, 1.35 GB for 8 columns of 50 000 points) and
-   6 x nblocks partial sums -- instead of four optics and two flux arrays.  (api.Pipeline in Python defaults to
+   tau_gas and 6 x nblocks partial sums -- instead of four optics and two flux arrays.  The shortwave solver runs ONE
+   sweep from the top when user_level is -1, 0 or the surface; with a user level in between (or GRT_SW_TWO_SWEEPS=1 in the
+   environment) it takes the reference's two sweeps and parks, between them, [2 V + 5 L][n] rows per column (422 rows at
+   60 layers: 1.35 GB for 8 columns of 50 000 points) in a block allocated at the first such launch.  (api.Pipeline in Python defaults to
    spectral=True, i.e. keep_spectra = 1, because the parity tests want spectra; this C entry point defaults to 0.)
    keep_spectra = 1: tau, omega, g and flux_up/down are materialised as the reference's calls would leave them
    (grt_pipeline_views; parity tests, spectral output). */
