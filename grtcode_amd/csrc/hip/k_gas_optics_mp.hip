@@ -1648,6 +1648,9 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
             // ---- moments of the Lorentzian about the cell centre (see general_block) ----
             v2f const A = (amp*eta)*splat2(a_norm);                             // K(r) = A/((r - dl)^2 + eta^2)
             v2f m[kMom];
+#ifdef GRT_ABL_NOMOM     // (timing experiments only, scripts/lean_ablation.sh: results are wrong by construction)
+            for (int k = 0; k < kMom; ++k) m[k] = splat2(0.f);
+#else
             {
                 v2f uu = A, pk = splat2(0.f);
 #pragma unroll
@@ -1659,6 +1662,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                     m[k] = pk;
                 }
             }
+#endif
             // Voigt constants (RFM_voigt.c:97-126, :177-179); a pure Lorentz line (y >= 70.55) has no region 1
             v2f const yq = y*y;
             v2f const x0q = sel2(!valid[0] | (y.x >= 70.55f), !valid[1] | (y.y >= 70.55f), splat2(0.f), pk_fma(y, pk_fma(y, splat2(-3.6f), splat2(40.0f)), splat2(15100.0f)));   // XLIM0^2
@@ -1708,7 +1712,11 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                 }
             }
             // ---- the row's moment sums: eight per cell end in sixteen lanes (one cell: in eight) ----
+#ifdef GRT_ABL_NOREDUCE
+            if (hi < 0)
+#else
             if (single)
+#endif
             {
                 float g0[kMom];
 #pragma unroll
@@ -1718,12 +1726,20 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                 }
                 float tsum = row_sum_transposed(g0, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0);       // value (lane >> 1) & 7, twice
                 tsum = (lane & 1) == 0 ? tsum : 0.f;
+#ifdef GRT_ABL_NOLDSADD
+                if ((tsum == 123.456f) & (cr < F1))
+#else
                 if ((tsum != 0.f) & (cr < F1))
+#endif
                 {
                     mom_add((lane >> 1) & 7, cr, tsum);
                 }
             }
+#ifdef GRT_ABL_NOREDUCE
+            else if (hi < 0)
+#else
             else
+#endif
             {
                 float g0[kMom], g1[kMom];
 #pragma unroll
@@ -1735,7 +1751,11 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                 }
                 float const tsum = row_sum_two_groups(g0, g1, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0, (lane & 1) != 0);
                 int const cell = cr + ((lane >> 3) & 1);
+#ifdef GRT_ABL_NOLDSADD
+                if ((tsum == 123.456f) & (cell < F1))
+#else
                 if ((tsum != 0.f) & (cell < F1))
+#endif
                 {
                     mom_add(lane & 7, cell, tsum);
                 }
@@ -1762,7 +1782,12 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
             // | the point's region picks the formula.  Near-centre points (|x| < XLIM1) are left out and noted in ncm. ----
             v2f v[7];
             unsigned ncm[2] = {0u, 0u};
+#ifdef GRT_ABL_NOSLOTS
+            for (int k = 0; k < 7; ++k) v[k] = splat2(0.f);
+            if (hi < 0)
+#else
             if (tfl & kTfLreg)
+#endif
             {
                 // every point but the line's own: the Lorentzian, A/(rel^2 + eta^2) (RFM_voigt.c:103,170,278)
 #pragma unroll
@@ -1784,7 +1809,11 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                 ncm[0] = nc[0] ? 8u : 0u;
                 ncm[1] = nc[1] ? 8u : 0u;
             }
+#ifdef GRT_ABL_NOSLOTS
+            else if (hi < 0)
+#else
             else
+#endif
             {
                 v2f const acl = amp*cl;
                 v2f xq[7];
@@ -1849,6 +1878,9 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                 }
             }
             // into the row's eight slots (grid points cr - 3 .. cr + 4): a line of cell cr + o has its points in slots o .. 6 + o
+#ifdef GRT_ABL_NOREDUCE
+            if (hi < 0)
+#endif
             {
                 float nvs[8];
                 if (single)
@@ -1872,7 +1904,11 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                     }
                 }
                 float const s8 = row_sum_transposed(nvs, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0);
+#ifdef GRT_ABL_NOLDSADD
+                if (((lane & 1) == 0) & (s8 == 123.456f))
+#else
                 if (((lane & 1) == 0) & (s8 != 0.f))
+#endif
                 {
                     GRT_ACC_ADD(&acc[cr - 3 + ((lane >> 1) & 7) - A0], (double)s8);
                 }
@@ -1919,6 +1955,9 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
             // molecule slot and exponent index); full batches are given the reference's x and y (drain_raw).
             // Bits 0-6: points of the lane's first line, 7-13: of its second ----
             unsigned nc2 = ncm[0] | (ncm[1] << 7);
+#ifdef GRT_ABL_NORAW
+            nc2 = 0u;
+#endif
             // (the wave's last lean block also empties the raw queue: ONE place in the code prepares entries, so the kernel
             // carries one copy less of that and of the four evaluation formulas behind it)
             bool const flush = base + walk_stride >= jend || xcount == kLeanListCap;

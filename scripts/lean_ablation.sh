@@ -20,7 +20,7 @@ if [ "$1" = "build" ]; then
     done
 else
     for n in $NAMES; do
-        GRT_LIB_PATH=$PWD/$V/libgrt_$n.so python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --cols 32 --chunk 32 2>/dev/null \
+        GRT_LIB_PATH=$PWD/$V/libgrt_$n.so python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --cols 64 --chunk 64 2>/dev/null \
             | python3 -c "import json,sys;d=json.loads(sys.stdin.read());k=d['kernel_ms_per_step'];print('$n', round(d['value'],1), 'lw', round(k['gas_optics_lw'],2), 'sw', round(k['gas_optics_sw'],2))"
     done
 fi
