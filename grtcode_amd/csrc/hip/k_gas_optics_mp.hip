@@ -91,6 +91,30 @@ __device__ __forceinline__ int wave_max_s(int v)
                max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
+// a + (a of the lane's partner under CTRL) where the lane's bit is clear, b + (b of the partner) where it is set -- the bit
+// being one that splits a row of 16 lanes into whole banks of four (8: row_mirror partner, lanes 8-15 = banks 2, 3;
+// 4: row_half_mirror partner, lanes 4-7 and 12-15 = banks 1, 3).  A DPP instruction writes only the banks its bank_mask
+// names, so two adds do what two selects and an add did.  (Inline assembly: the compiler's DPP folding takes full masks
+// only.  s_nop: a DPP operand may not be read within two wait states of its write, and the hazard recogniser does not
+// look into assembly.)
+template <int BIT>
+__device__ __forceinline__ float dpp_add_by_bit(float a, float b)
+{
+    static_assert(BIT == 8 || BIT == 4, "");
+    float w;
+    if constexpr (BIT == 8)
+    {
+        asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %0, %2, %2 row_mirror row_mask:0xf bank_mask:0xc" : "=&v"(w) : "v"(a), "v"(b));
+    }
+    else
+    {
+        asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa" : "=&v"(w) : "v"(a), "v"(b));
+    }
+    return w;
+}
+
 // Row sums of eight values per lane, transposed: on return lane l holds the sum over its row of 16
 // lanes of m[4 b3 + 2 b2 + b1] (b_i = bits of l & 15).  Three halving exchanges (partner = lane ^ 15,
 // lane ^ 7, lane ^ 3: row_mirror, row_half_mirror, reversed quad), each lane keeping the half of the
@@ -98,21 +122,18 @@ __device__ __forceinline__ int wave_max_s(int v)
 // 14 selects + 8 DPP adds instead of 8 x 4 DPP adds.
 __device__ __forceinline__ float row_sum_transposed(float const (&m)[8], bool b3, bool b2, bool b1)
 {
+    (void)b3; (void)b2;
     float w[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
     {
-        float const keep = b3 ? m[i + 4] : m[i];
-        float const send = b3 ? m[i] : m[i + 4];
-        w[i] = keep + dpp_f<0x140>(send);               // row_mirror
+        w[i] = dpp_add_by_bit<8>(m[i], m[i + 4]);       // b3 clear: m[i] + partner's m[i]; set: m[i + 4] + partner's (row_mirror)
     }
     float x[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
     {
-        float const keep = b2 ? w[i + 2] : w[i];
-        float const send = b2 ? w[i] : w[i + 2];
-        x[i] = keep + dpp_f<0x141>(send);               // row_half_mirror
+        x[i] = dpp_add_by_bit<4>(w[i], w[i + 2]);       // likewise by b2 (row_half_mirror)
     }
     float const keep = b1 ? x[1] : x[0];
     float const send = b1 ? x[0] : x[1];
@@ -163,21 +184,18 @@ __device__ __forceinline__ float row_sum_transposed_pair(float const (&m)[8], bo
 // value l & 7.
 __device__ __forceinline__ float row_sum_two_groups(float const (&g0)[8], float const (&g1)[8], bool b3, bool b2, bool b1, bool b0)
 {
+    (void)b3; (void)b2;
     float w[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
     {
-        float const keep = b3 ? g1[i] : g0[i];
-        float const send = b3 ? g0[i] : g1[i];
-        w[i] = keep + dpp_f<0x140>(send);               // row_mirror: the partner is in the other half
+        w[i] = dpp_add_by_bit<8>(g0[i], g1[i]);         // row_mirror: the partner is in the other half
     }
     float x[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
     {
-        float const keep = b2 ? w[i + 4] : w[i];
-        float const send = b2 ? w[i] : w[i + 4];
-        x[i] = keep + dpp_f<0x141>(send);               // row_half_mirror
+        x[i] = dpp_add_by_bit<4>(w[i], w[i + 4]);       // row_half_mirror
     }
     float y[2];
 #pragma unroll
