@@ -215,6 +215,16 @@ __device__ __forceinline__ float row_sum_two_groups(float const (&g0)[8], float 
 constexpr int kRawCap = 128;
 constexpr int kLeanListCap = 12;
 constexpr int kLeanMaxP = 4;
+// The lean loop's per-layer tables sit at FIXED distances from one LDS address (room for kLeanSlots molecule slots, whatever
+// the object has: a launch with more slots takes the general loop), so that one address register per index serves all the
+// tables that index reads -- the distances go into the ds_read's offset field instead of a vector add per table.
+constexpr int kLeanSlots = 16;
+struct LeanTables
+{
+    float ps[kLeanSlots], p_ps[kLeanSlots], dop[kLeanSlots];          // per slot: ps | p - ps | sqrt(ln 2) x doppler factor
+    float qn_m[kLeanSlots*GRT_MAX_ISO], qn_e[kLeanSlots*GRT_MAX_ISO]; // per (slot, isotopologue): N_s/Q as mantissa | exponent
+    float ptab[kPowTable];                                            // (296/T)^(k/100)
+};
 struct LeanRaw
 {
     unsigned long long xl_mask[kWaves][kLeanListCap][kLeanMaxP];
@@ -1386,9 +1396,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
     constexpr int kLinesPerLane = LEANP > 0 ? LEANP : 1;
     [[maybe_unused]] bool lean_ok = false;
     // (per-slot and per-isotopologue tables, one array per quantity: a line's look-up then lands in its half of a register pair)
-    [[maybe_unused]] float *msf = nullptr;
-    [[maybe_unused]] float *qnf = nullptr;
-    [[maybe_unused]] float *ptabf = nullptr;
+    [[maybe_unused]] LeanTables *lt = nullptr;
     [[maybe_unused]] LeanRaw *raw = nullptr;
     [[maybe_unused]] int rawcount = 0;              // wave-uniform: entries waiting in the raw queue
     [[maybe_unused]] int xcount = 0;                // wave-uniform: blocks with lines handed over to general_block
@@ -1408,10 +1416,8 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
     if constexpr (LEANP > 0)
     {
         size_t const lean_off = ((size_t)(reinterpret_cast<unsigned char *>(invr + 1) - smem) + 15) & ~(size_t)15;
-        msf = reinterpret_cast<float *>(smem + lean_off);                         // [4][num_slots]: ps | p - ps | sqrt(ln 2) x doppler factor | -
-        qnf = msf + 4*a.lay.num_slots;                                            // [2][num_slots][GRT_MAX_ISO]: N_s/Q as mantissa | exponent
-        ptabf = qnf + 2*(size_t)a.lay.num_slots*GRT_MAX_ISO;                      // [kPowTable]
-        raw = reinterpret_cast<LeanRaw *>(ptabf + kPowTable);
+        lt = reinterpret_cast<LeanTables *>(smem + lean_off);
+        raw = reinterpret_cast<LeanRaw *>(lt + 1);
         lean_ok = uniform_flag(a.lean != 0 && use_moments && R == 3 && F0 >= 8 && F1 + 8 <= nw_i && fsteps >= 8 && halo >= 8
                                && a.lines.lean_a != nullptr);
         if (lean_ok)
@@ -1419,9 +1425,9 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
             for (int i = tid; i < a.lay.num_slots; i += kBlock)
             {
                 // (third entry: alpha of kernels.c:127 over the line centre, divided by RFM_voigt.c:94's sqrt(ln 2) -- 1/REPWID per cm-1)
-                msf[i] = (float)ms_l[4*i];
-                msf[a.lay.num_slots + i] = (float)ms_l[4*i + 1];
-                msf[2*a.lay.num_slots + i] = (float)(((double)0.83255461115f/(double)kSqrln2)*ms_l[4*i + 3]);
+                lt->ps[i] = (float)ms_l[4*i];
+                lt->p_ps[i] = (float)ms_l[4*i + 1];
+                lt->dop[i] = (float)(((double)0.83255461115f/(double)kSqrln2)*ms_l[4*i + 3]);
             }
             for (int i = tid; i < a.lay.num_slots*GRT_MAX_ISO; i += kBlock)
             {
@@ -1429,12 +1435,12 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                 int e = 0;
                 double const m = frexp(v, &e);                                      // v = m 2^e, 1/2 <= m < 1
                 bool const ok = v > 0. && v < 1e300;
-                qnf[i] = ok ? (float)(2.*m) : 0.f;
-                qnf[a.lay.num_slots*GRT_MAX_ISO + i] = ok ? (float)(e - 1 - GRT_LEAN_S0_SHIFT) : 0.f;
+                lt->qn_m[i] = ok ? (float)(2.*m) : 0.f;
+                lt->qn_e[i] = ok ? (float)(e - 1 - GRT_LEAN_S0_SHIFT) : 0.f;
             }
             for (int i = tid; i < kPowTable; i += kBlock)
             {
-                ptabf[i] = (float)ptab[i];
+                lt->ptab[i] = (float)ptab[i];
             }
             __syncthreads();
             double const kTd = ((double)(-1.4387686f)*1.4426950408889634)*lay[2];  // c2 log2(e)/T (kernels.c:75)
@@ -1584,10 +1590,9 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
             v2f const nz = rint2(en*kh2);
             v2f const rz = pk_fma(en, kl2, pk_fma(en, kh2, -nz));       // en c2 log2(e)/T - nz, to ~1e-8
             unsigned const qi[2] = {(rc[0] >> 14) & 1023u, (rc[1] >> 14) & 1023u};
-            float const *qnx = qnf + a.lay.num_slots*GRT_MAX_ISO;
-            v2f amp = (ss*(v2f){qnf[qi[0]], qnf[qi[1]]})*exp2_2(rz);
+            v2f amp = (ss*(v2f){lt->qn_m[qi[0]], lt->qn_m[qi[1]]})*exp2_2(rz);
             {
-                v2f const ex = (v2f){qnx[qi[0]], qnx[qi[1]]} + nz;
+                v2f const ex = (v2f){lt->qn_e[qi[0]], lt->qn_e[qi[1]]} + nz;
                 amp = (v2f){ldexpf(amp.x, (int)ex.x), ldexpf(amp.y, (int)ex.y)};
             }
             if (tfl & kTfStim)
@@ -1618,10 +1623,9 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
             }
             // ---- widths (kernels.c:105-106, :127; RFM_voigt.c:94-95) ----
             unsigned const si[2] = {(rc[0] >> 8) & 63u, (rc[1] >> 8) & 63u};
-            float const *msy = msf + a.lay.num_slots, *msz = msf + 2*a.lay.num_slots;
-            v2f const ptv = {ptabf[rc[0] & 127u], ptabf[rc[1] & 127u]};
-            v2f const gam = ptv*pk_fma(yair, (v2f){msy[si[0]], msy[si[1]]}, yself*(v2f){msf[si[0]], msf[si[1]]});
-            v2f const ad = wn*(v2f){msz[si[0]], msz[si[1]]};                              // alpha/sqrt(ln 2) (kernels.c:127, RFM_voigt.c:94)
+            v2f const ptv = {lt->ptab[rc[0] & 127u], lt->ptab[rc[1] & 127u]};
+            v2f const gam = ptv*pk_fma(yair, (v2f){lt->p_ps[si[0]], lt->p_ps[si[1]]}, yself*(v2f){lt->ps[si[0]], lt->ps[si[1]]});
+            v2f const ad = wn*(v2f){lt->dop[si[0]], lt->dop[si[1]]};                              // alpha/sqrt(ln 2) (kernels.c:127, RFM_voigt.c:94)
             v2f const r0 = rcp2(ad);
             v2f const rep = pk_fma(pk_fma(-ad, r0, splat2(1.f)), r0, r0);       // REPWID (one Newton step: the far wings scale with it)
             v2f y = rep*gam;
@@ -3085,7 +3089,8 @@ void launch_tree(hipStream_t s, GrtGasOpticsArgs const &b, long long fsteps, int
 // coarser cells in two LDS buffers (tile/2 + tile/4 cells of twelve moments) where the accumulator was
 size_t lean_lds_bytes(int num_slots)
 {
-    return 16 + sizeof(float4)*num_slots + sizeof(float2)*(size_t)num_slots*GRT_MAX_ISO + sizeof(float)*kPowTable + sizeof(LeanRaw);
+    (void)num_slots;
+    return 16 + sizeof(LeanTables) + sizeof(LeanRaw);
 }
 
 size_t mp_lds_bytes(int nacc, int ncell, int fsteps, int num_slots, bool tree = false, int subtree_tile = 0)
@@ -3241,7 +3246,7 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
         size_t lds = mp_lds_bytes(nacc, ncell, 0, a->lay.num_slots, tree, tree && ncell == 0 ? a->tile : 0);
         // the lean line loop: single-level gather, packed records built for this very grid, room for its tables in LDS
         b.lean = !tree && a->probe == NULL && lean_wanted() && a->lines.lean_a != NULL && a->lines.lean_b != NULL
-                 && a->lines.lean_c != NULL && a->lines.lean_x != NULL && a->lines.lean_w0 == a->w0 && a->lines.lean_wres == a->wres
+                 && a->lines.lean_c != NULL && a->lines.lean_x != NULL && a->lay.num_slots <= kLeanSlots && a->lines.lean_w0 == a->w0 && a->lines.lean_wres == a->wres
                  && a->lines.n < 0xffffffffull && halo >= 8 && nacc <= 4096
                  && lds + lean_lds_bytes(a->lay.num_slots) <= kLdsPerWorkgroup;
         if (b.lean)
