@@ -1528,18 +1528,23 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
     // its last pair) -- requested one block ahead of their use.
     [[maybe_unused]] float4 next_a0 = make_float4(0.f, 0.f, 0.f, 0.f), next_a1 = next_a0, next_b0 = next_a0, next_b1 = next_a0;
     [[maybe_unused]] uint2 next_c = make_uint2(0u, 0u);
-    [[maybe_unused]] auto lean_fetch = [&](uint64_t const b)
+    // (the lean loop counts its lines from jal, in 32 bits -- the store has fewer than 2^32 lines where this loop runs: its
+    // range tests are scalar compares then; 64-bit ones are vector instructions on this chip)
+    [[maybe_unused]] unsigned const nrel = (unsigned)(jend - jal);          // the range ends at jal + nrel
+    [[maybe_unused]] unsigned const lo_first = (unsigned)(jbeg - jal);      // 0, or 1: the range begins on an odd index
+    [[maybe_unused]] auto lean_fetch = [&](unsigned const b)
     {
         if constexpr (LEANP > 0)
         {
-            uint64_t const qlast = (jend - 1) >> 1;
-            uint64_t const qb = b < jend ? (b >> 1) : qlast;
-            unsigned const room = (unsigned)(qlast - qb);
+            unsigned const qlast = (nrel - 1u) >> 1;
+            unsigned const qb = b < nrel ? (b >> 1) : qlast;
+            unsigned const room = qlast - qb;
             unsigned const off = (unsigned)lane < room ? (unsigned)lane : room;
             // (byte offsets in 32 bits: scalar base + vector offset addressing instead of 64-bit vector address arithmetic)
-            float4 const *pa = reinterpret_cast<float4 const *>(a.lines.lean_a) + qb;
-            float4 const *pb = reinterpret_cast<float4 const *>(a.lines.lean_b) + qb;
-            uint2 const *pc = reinterpret_cast<uint2 const *>(a.lines.lean_c) + qb;
+            uint64_t const q0 = (jal >> 1) + qb;
+            float4 const *pa = reinterpret_cast<float4 const *>(a.lines.lean_a) + q0;
+            float4 const *pb = reinterpret_cast<float4 const *>(a.lines.lean_b) + q0;
+            uint2 const *pc = reinterpret_cast<uint2 const *>(a.lines.lean_c) + q0;
             next_a0 = *reinterpret_cast<float4 const *>(reinterpret_cast<char const *>(pa) + (off << 4));
             next_a1 = *reinterpret_cast<float4 const *>(reinterpret_cast<char const *>(pa + a.lines.lean_npair) + (off << 4));
             next_b0 = *reinterpret_cast<float4 const *>(reinterpret_cast<char const *>(pb) + (off << 4));
@@ -1554,13 +1559,13 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
     // operations and their order are those of a line on its own, so the halves hold what two passes over single lines
     // would.  Lines that have to go through general_block instead are recorded, block by block, in the wave's list
     // (raw->xl_*).
-    [[maybe_unused]] auto lean_block = [&](uint64_t const base)
+    [[maybe_unused]] auto lean_block = [&](unsigned const base)      // (base: counted from jal)
     {
         if constexpr (LEANP > 0)
         {
             // lines of this block: base + lo .. base + hi - 1 (lo = 1: the workgroup's range begins on an odd index)
-            int const lo = jbeg > base ? (int)(jbeg - base) : 0;
-            int const hi = jend - base < (uint64_t)128 ? (int)(jend - base) : 128;
+            int const lo = base == 0u ? (int)lo_first : 0;
+            int const hi = nrel - base < 128u ? (int)(nrel - base) : 128;
             float4 const ra0 = next_a0, ra1 = next_a1, rb0 = next_b0, rb1 = next_b1;
             uint2 const rcc = next_c;
             lean_fetch(base + walk_stride);
@@ -1638,7 +1643,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                 {
                     if (lane == 0)
                     {
-                        raw->xl_base[wave][xcount] = (unsigned)(base - jal);
+                        raw->xl_base[wave][xcount] = base;
                         raw->xl_mask[wave][xcount][0] = handed0;
                         raw->xl_mask[wave][xcount][1] = handed1;
                     }
@@ -1982,7 +1987,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
 #endif
             // (the wave's last lean block also empties the raw queue: ONE place in the code prepares entries, so the kernel
             // carries one copy less of that and of the four evaluation formulas behind it)
-            bool const flush = base + walk_stride >= jend || xcount == kLeanListCap;
+            bool const flush = base + walk_stride >= nrel || xcount == kLeanListCap;
             for (;;)
             {
                 bool const more = ballot_b(nc2 != 0u) != 0ull;
@@ -2006,7 +2011,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                 if (push)
                 {
                     int const pos = rawcount + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-                    raw->j[wave][pos] = (unsigned)base + 2u*(unsigned)lane + (second ? 1u : 0u);
+                    raw->j[wave][pos] = ((unsigned)jal + base) + 2u*(unsigned)lane + (second ? 1u : 0u);
                     raw->amp[wave][pos] = second ? amp.y : amp.x;
                     raw->delta[wave][pos] = second ? dsh.y : dsh.x;
                     raw->idx[wave][pos] = (unsigned)((second ? c[1] : c[0]) - 3 + k - A0) | ((unsigned)k << 12) | ((second ? si[1] : si[0]) << 16)
@@ -2022,21 +2027,20 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
     uint64_t base = walk_first;
     if constexpr (LEANP > 0)
     {
-        if (lean_ok)
+        if (lean_ok && walk_first < jend)
         {
-            if (base < jend)
+            unsigned brel = (unsigned)(walk_first - jal);
+            lean_fetch(brel);
+            for (; brel < nrel; brel += walk_stride)
             {
-                lean_fetch(base);
-            }
-            for (; base < jend; base += walk_stride)
-            {
-                lean_block(base);
+                lean_block(brel);
                 if (xcount == kLeanListCap)
                 {
-                    base += walk_stride;
+                    brel += walk_stride;
                     break;
                 }
             }
+            base = jal + brel;
         }
     }
     for (int x = 0;;)
