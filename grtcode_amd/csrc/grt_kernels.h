@@ -179,9 +179,9 @@ int grt_launch_line_prep(void *stream, GrtGasOpticsArgs const *a, int col,
 int grt_launch_voigt_debug(void *stream, int fast, double w_start, uint64_t n, double wres, double center,
                            double gamma, double alpha, double *K_dev);
 
-/* rayleigh.c:29-68: n_layer [L] on device. */
+/* rayleigh.c:29-68: n_layer [L] on the HOST (it travels as a kernel argument). */
 int grt_launch_rayleigh(void *stream, int num_layers, double w0, double dw, uint64_t nw,
-                        double const *n_layer, double *tau, double *omega, double *g);
+                        double const *n_layer_host, double *tau, double *omega, double *g);
 
 /* optics.c:128-148: K objects, each [n]; pointers passed by value (K <= 8). */
 typedef struct GrtOpticsPtrs { double const *tau[8]; double const *omega[8]; double const *g[8]; } GrtOpticsPtrs;
@@ -218,6 +218,10 @@ typedef struct GrtLwArgs
        down surface, down user) at partials[(c*6 + k)*nblocks + block]; grt_launch_reduce_partials finishes. */
     double const *tau_gas, *n_layer;
     double *partials;
+    /* spectral form, optional: scratch [ncol][6 L][nw].  When set, the four streams' extinctions and the two effective
+       Planck terms of every layer are worked out first by one thread per (layer, wavenumber), and the two sweeps read
+       them (the same doubles through the same expressions: identical fluxes) -- see GrtSwArgs.layer_props */
+    double *layer_terms;
 } GrtLwArgs;
 int grt_launch_lw(void *stream, GrtLwArgs const *a);
 unsigned grt_solver_blocks(uint64_t nw);     /* workgroups along the spectrum of one solver launch (size of `partials`) */
@@ -248,6 +252,11 @@ typedef struct GrtSwArgs
     /* fused form, no flux asked for between top and surface (user_level -1, 0 or num_levels - 1): ONE sweep from the top,
        nothing parked (k_shortwave.hip); 0: the two sweeps of the reference's order (GRT_SW_TWO_SWEEPS=1 in the environment) */
     int one_sweep;
+    /* spectral form (flux_up/flux_down set), optional: scratch [ncol][5 L][nw].  When set, the five properties of every
+       layer are worked out first by one thread per (layer, wavenumber) -- a column of 50 000 wavenumbers is then 3 million
+       independent delta-Eddington pairs instead of 50 000 chains of 120 -- and the two sweeps read them (the same
+       doubles through the same expressions: identical fluxes) */
+    double *layer_props;
 } GrtSwArgs;
 int grt_launch_sw(void *stream, GrtSwArgs const *a);
 

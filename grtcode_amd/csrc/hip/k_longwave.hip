@@ -189,6 +189,146 @@ __global__ __launch_bounds__(kBlock) void lw_kernel(GrtLwArgs a)
     }
 }
 
+// ---- spectral form of few columns: the layers' terms first, by one thread per (layer, wavenumber) ----
+// One column of the longwave band is 3 250 threads for lw_kernel<false> -- fifty waves on a thousand SIMDs, each with 120
+// dependent layer steps of six exp.  What costs in a step does not depend on the step before: lw_terms_kernel fills
+// terms[col][6 j + k][nw] with the four streams' extinctions exp(c1[s] t) and the effective Planck terms of the
+// downward and of the upward sweep; lw_sweeps_kernel carries the four intensities through them, six layers' terms read
+// ahead of the chain at a time.  Same expressions, same order, same doubles as lw_kernel<false>: identical fluxes.
+constexpr int kTermsBlock = 256;
+constexpr int kSweepBlock = 64;
+constexpr int kSweepChunk = 6;
+
+__global__ __launch_bounds__(kTermsBlock) void lw_terms_kernel(GrtLwArgs a)
+{
+    double const c1[4] = {-14.402613260847248, -3.0302159969901132,
+                          -1.4925584280108841, -1.0746123148178333};   // longwave.c:160-163
+    int const col = blockIdx.y;
+    int const V = a.num_levels;
+    int const L = V - 1;
+    uint64_t const nw = a.nw;
+    uint64_t const o = (uint64_t)blockIdx.x*kTermsBlock + threadIdx.x;       // j nw + i
+    if (o >= (uint64_t)L*nw)
+    {
+        return;
+    }
+    uint64_t const j = o/nw;
+    uint64_t const i = o - j*nw;
+    double const w = a.w0 + i*a.dw;                                      // longwave.c:246
+    uint64_t const at = (uint64_t)col*a.optics_stride + o;
+    double const t = a.omega ? a.tau[at]*(1. - a.omega[at]) : a.tau[at]*(1. - 0.);     // longwave.c:252
+    double const *tl = a.t_layers + (uint64_t)col*L;
+    double const *tv = a.t_levels + (uint64_t)col*V;
+    double const bc = planck(tl[j], w);
+    double *q = a.layer_terms + ((uint64_t)col*6*(uint64_t)L + 6*j)*nw + i;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+    {
+        q[(uint64_t)s*nw] = extinction(c1[s], t);
+    }
+    q[4*nw] = effective_planck(bc, planck(tv[j + 1], w), t);             // the downward sweep's (longwave.c:186-193)
+    q[5*nw] = effective_planck(bc, planck(tv[j], w), t);                 // the upward sweep's (:204-211)
+}
+
+__global__ __launch_bounds__(kSweepBlock) void lw_sweeps_kernel(GrtLwArgs a)
+{
+    double const c2[4] = {0.07587638482015649, 0.676114979733751,
+                          1.3726594476601073, 1.0169418413757783};     // longwave.c:165-168
+    uint64_t const i = (uint64_t)blockIdx.x*kSweepBlock + threadIdx.x;
+    int const col = blockIdx.y;
+    if (i >= a.nw)
+    {
+        return;
+    }
+    int const V = a.num_levels;
+    int const L = V - 1;
+    uint64_t const nw = a.nw;
+    double const w = a.w0 + i*a.dw;
+    double const emis = a.emis[(uint64_t)col*a.emis_stride + i];
+    double const *tt = a.layer_terms + (uint64_t)col*6*(uint64_t)L*nw + i;
+    double *fu = a.flux_up + (uint64_t)col*a.flux_stride + i;
+    double *fd = a.flux_down + (uint64_t)col*a.flux_stride + i;
+    double I[4] = {0., 0., 0., 0.};
+    fd[0] = 0.;                                                          // longwave.c:171
+    for (int jb = 0; jb < L; jb += kSweepChunk)
+    {
+        double ex[kSweepChunk][4], vl[kSweepChunk];
+#pragma unroll
+        for (int u = 0; u < kSweepChunk; ++u)
+        {
+            double const *q = tt + (uint64_t)(6*(jb + u < L ? jb + u : L - 1))*nw;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+            {
+                ex[u][s] = q[(uint64_t)s*nw];
+            }
+            vl[u] = q[4*nw];
+        }
+#pragma unroll
+        for (int u = 0; u < kSweepChunk; ++u)
+        {
+            int const j = jb + u;
+            if (j < L)
+            {
+                double const val = vl[u];
+                double f = 0.;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                {
+                    double const ext = ex[u][s];
+                    double const p = (1. - ext)*val;                     // longwave.c:193
+                    I[s] = p + I[s]*ext;
+                    f += c2[s]*I[s];                                     // longwave.c:195
+                }
+                fd[(uint64_t)(j + 1)*nw] = f;
+            }
+        }
+    }
+    double const bs = planck(a.t_surf[col], w);
+    double f = 0.;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+    {
+        I[s] = emis*bs + (1 - emis)*I[s];                                // longwave.c:202
+        f += c2[s]*I[s];
+    }
+    fu[(uint64_t)L*nw] = f;
+    for (int jb = L - 1; jb >= 0; jb -= kSweepChunk)
+    {
+        double ex[kSweepChunk][4], vl[kSweepChunk];
+#pragma unroll
+        for (int u = 0; u < kSweepChunk; ++u)
+        {
+            double const *q = tt + (uint64_t)(6*(jb - u >= 0 ? jb - u : 0))*nw;
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+            {
+                ex[u][s] = q[(uint64_t)s*nw];
+            }
+            vl[u] = q[5*nw];
+        }
+#pragma unroll
+        for (int u = 0; u < kSweepChunk; ++u)
+        {
+            int const j = jb - u;
+            if (j >= 0)
+            {
+                double const val = vl[u];
+                double g = 0.;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                {
+                    double const ext = ex[u][s];
+                    double const p = (1. - ext)*val;                     // longwave.c:211
+                    I[s] = p + I[s]*ext;
+                    g += c2[s]*I[s];
+                }
+                fu[(uint64_t)j*nw] = g;
+            }
+        }
+    }
+}
+
 } // namespace
 
 extern "C" unsigned grt_solver_blocks(uint64_t nw)
@@ -203,6 +343,19 @@ extern "C" int grt_launch_lw(void *stream, GrtLwArgs const *a)
                                            : (a->flux_up == nullptr || a->flux_down == nullptr)))
     {
         return (int)hipErrorInvalidValue;
+    }
+    if (!fused && a->layer_terms != nullptr)
+    {
+        uint64_t const cells = (uint64_t)(a->num_levels - 1)*a->nw;
+        if (cells > 0xffffffffull*kTermsBlock)
+        {
+            return (int)hipErrorInvalidValue;
+        }
+        hipLaunchKernelGGL(lw_terms_kernel, dim3((unsigned)((cells + kTermsBlock - 1)/kTermsBlock), a->ncol, 1),
+                           dim3(kTermsBlock), 0, (hipStream_t)stream, *a);
+        hipLaunchKernelGGL(lw_sweeps_kernel, dim3((unsigned)((a->nw + kSweepBlock - 1)/kSweepBlock), a->ncol, 1),
+                           dim3(kSweepBlock), 0, (hipStream_t)stream, *a);
+        return (int)hipGetLastError();
     }
     dim3 const grid(grt_solver_blocks(a->nw), a->ncol, 1);
     if (fused)

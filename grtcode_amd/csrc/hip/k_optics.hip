@@ -19,10 +19,16 @@ inline unsigned grid_for(uint64_t n)
     return (unsigned)(b < 2048 ? (b ? b : 1) : 2048);
 }
 
+// the layers' number densities travel as a kernel argument (at most 200 doubles): the one-column call has nothing to
+// upload and nothing to wait for
+constexpr int kRayleighMaxLayers = 200;            // MAX_NUM_LAYERS of the public header
+struct RayleighLayers { double n[kRayleighMaxLayers]; };
+
 __global__ __launch_bounds__(kBlock) void rayleigh_kernel(int L, double w0, double dw, uint64_t nw,
-                                                          double const *n_layer, double *tau,
+                                                          RayleighLayers lay, double *tau,
                                                           double *omega, double *g)
 {
+    double const *n_layer = lay.n;
     uint64_t const total = (uint64_t)L*nw;
     for (uint64_t o = (uint64_t)blockIdx.x*kBlock + threadIdx.x; o < total; o += (uint64_t)gridDim.x*kBlock)
     {
@@ -187,10 +193,19 @@ extern "C" int grt_launch_reduce_partials(void *stream, double const *partials, 
 }
 
 extern "C" int grt_launch_rayleigh(void *stream, int num_layers, double w0, double dw, uint64_t nw,
-                                   double const *n_layer, double *tau, double *omega, double *g)
+                                   double const *n_layer_host, double *tau, double *omega, double *g)
 {
+    if (num_layers < 1 || num_layers > kRayleighMaxLayers)
+    {
+        return (int)hipErrorInvalidValue;
+    }
+    RayleighLayers lay;
+    for (int i = 0; i < kRayleighMaxLayers; ++i)
+    {
+        lay.n[i] = i < num_layers ? n_layer_host[i] : 0.;
+    }
     hipLaunchKernelGGL(rayleigh_kernel, dim3(grid_for((uint64_t)num_layers*nw)), dim3(kBlock), 0,
-                       (hipStream_t)stream, num_layers, w0, dw, nw, n_layer, tau, omega, g);
+                       (hipStream_t)stream, num_layers, w0, dw, nw, lay, tau, omega, g);
     return (int)hipGetLastError();
 }
 

@@ -372,6 +372,162 @@ __global__ __launch_bounds__(kBlock) void sw_kernel(GrtSwArgs a)
     }
 }
 
+// ---- spectral form of few columns: the layer properties first, by one thread per (layer, wavenumber) ----
+// One column of the 1 cm-1 shortwave band is 50 000 threads for sw_kernel<false>: not one wave per SIMD, each working
+// through 120 layer steps of two delta-Eddington solutions (six exp and a dozen divisions) one after the other.  The
+// solutions of different layers do not depend on each other; only the adding sweeps do, and they are a few operations
+// per layer.  So: sw_props_kernel fills props[col][5 j + k][nw] (k: Rdir, Tdir, Tpure, Rdif, Tdif -- the park layout of
+// the fused form) with layer_props() of every (layer, wavenumber), and sw_sweeps_kernel runs the two sweeps of
+// sw_kernel<false> -- the same expressions in the same order on the same doubles, so the fluxes are the same to the last
+// bit -- reading six layers' properties at a time ahead of the dependent chain.
+constexpr int kPropsBlock = 256;
+constexpr int kSweepBlock = 64;
+constexpr int kSweepChunk = 6;
+
+__global__ __launch_bounds__(kPropsBlock) void sw_props_kernel(GrtSwArgs a)
+{
+    int const col = blockIdx.y;
+    int const L = a.num_levels - 1;
+    uint64_t const nw = a.nw;
+    uint64_t const o = (uint64_t)blockIdx.x*kPropsBlock + threadIdx.x;       // j nw + i: the optics arrays' own index
+    if (o >= (uint64_t)L*nw)
+    {
+        return;
+    }
+    uint64_t const j = o/nw;
+    uint64_t const i = o - j*nw;
+    uint64_t const at = (uint64_t)col*a.optics_stride + o;
+    LayerProps const p = layer_props(a.omega[at], a.g[at], a.tau[at], a.mu_dir[col], a.mu_dif);
+    double *q = a.layer_props + ((uint64_t)col*5*(uint64_t)L + 5*j)*nw + i;
+    q[0] = p.Rdir; q[nw] = p.Tdir; q[2*nw] = p.Tpure; q[3*nw] = p.Rdif; q[4*nw] = p.Tdif;
+}
+
+__global__ __launch_bounds__(kSweepBlock) void sw_sweeps_kernel(GrtSwArgs a)
+{
+    uint64_t const i = (uint64_t)blockIdx.x*kSweepBlock + threadIdx.x;
+    int const col = blockIdx.y;
+    if (i >= a.nw)
+    {
+        return;
+    }
+    int const V = a.num_levels;
+    int const L = V - 1;
+    uint64_t const nw = a.nw;
+    double const mu_dir = a.mu_dir[col];
+    double const *pp = a.layer_props + (uint64_t)col*5*(uint64_t)L*nw + i;
+    double *fu = a.flux_up + (uint64_t)col*a.flux_stride + i;
+    double *fd = a.flux_down + (uint64_t)col*a.flux_stride + i;
+    auto load = [&](int j) -> LayerProps
+    {
+        double const *q = pp + (uint64_t)(5*j)*nw;
+        LayerProps p;
+        p.Rdir = q[0]; p.Tdir = q[nw]; p.Tpure = q[2*nw]; p.Rdif = q[3*nw]; p.Tdif = q[4*nw];
+        return p;
+    };
+
+    // sweep 1: shortwave.c:280-294 (as in sw_kernel<false>: the downward-beam reflectances are parked in the output rows)
+    double Rdir_dn = a.alb_dir[(uint64_t)col*a.alb_stride + i];
+    double Rdif_dn = a.alb_dif[(uint64_t)col*a.alb_stride + i];
+    fu[(uint64_t)L*nw] = Rdir_dn;
+    fd[(uint64_t)L*nw] = Rdif_dn;
+    for (int jb = L - 1; jb >= 0; jb -= kSweepChunk)
+    {
+        LayerProps pr[kSweepChunk];
+#pragma unroll
+        for (int u = 0; u < kSweepChunk; ++u)
+        {
+            pr[u] = load(jb - u >= 0 ? jb - u : 0);
+        }
+#pragma unroll
+        for (int u = 0; u < kSweepChunk; ++u)
+        {
+            int const j = jb - u;
+            if (j >= 0)
+            {
+                LayerProps const p = pr[u];
+                uint64_t const o = (uint64_t)j*nw;
+                double const A = p.Tpure;
+                double const B = 1./(1. - p.Rdif*Rdif_dn);
+                double const ndir = p.Rdir + (A*Rdir_dn + (p.Tdir - A)*Rdif_dn)*p.Tdif*B;
+                double const ndif = p.Rdif + p.Tdif*p.Tdif*Rdif_dn*B;
+                Rdir_dn = ndir;
+                Rdif_dn = ndif;
+                fu[o] = Rdir_dn;
+                fd[o] = Rdif_dn;
+            }
+        }
+    }
+
+    // sweep 2: shortwave.c:299-329 fused, then the scalings of :401-405 and :447-451
+    double const scale = a.solar[i]*mu_dir;
+    double const tsi = a.tsi[col];
+    double dir_beam = 1.;
+    double dif_beam = 0.;
+    {
+        double up = dir_beam*Rdir_dn;     // R[0] = dir_beam*R_dir_downward[0] (the value sweep 1 has just stored in fu[0])
+        double dn = dir_beam;             // T[0]
+        up *= scale;
+        dn *= scale;
+        fu[0] = tsi*up;
+        fd[0] = tsi*dn;
+    }
+    double Rup_prev2 = 0.;    // R_dif_upward[lev-2]
+    double Rup_prev = 0.;     // R_dif_upward[lev-1]
+    for (int lb = 1; lb < V; lb += kSweepChunk)
+    {
+        LayerProps pr[kSweepChunk];
+        double rd[kSweepChunk], rf[kSweepChunk];
+#pragma unroll
+        for (int u = 0; u < kSweepChunk; ++u)
+        {
+            int const lev = lb + u < V ? lb + u : V - 1;
+            pr[u] = load(lev - 1);
+            rd[u] = fu[(uint64_t)lev*nw];          // R_dir_downward[lev] of sweep 1
+            rf[u] = fd[(uint64_t)lev*nw];          // R_dif_downward[lev]
+        }
+#pragma unroll
+        for (int u = 0; u < kSweepChunk; ++u)
+        {
+            int const lev = lb + u;
+            if (lev < V)
+            {
+                LayerProps const p = pr[u];        // layer lev-1
+                // R_dif_upward[lev-1]  (:299-306)
+                Rup_prev2 = Rup_prev;
+                if (lev == 1)
+                {
+                    Rup_prev = p.Rdif;
+                }
+                else
+                {
+                    double const Bu = 1./(1. - p.Rdif*Rup_prev2);
+                    Rup_prev = p.Rdif + p.Tdif*p.Tdif*Rup_prev2*Bu;
+                }
+                if (lev > 1)
+                {
+                    double const C = 1./(1. - p.Rdif*Rup_prev2);
+                    dif_beam = (dir_beam*p.Rdir*Rup_prev2 + dif_beam)*p.Tdif*C + dir_beam*(p.Tdir - p.Tpure);
+                }
+                else
+                {
+                    dif_beam = dir_beam*(p.Tdir - p.Tpure);
+                }
+                dir_beam *= p.Tpure;
+                uint64_t const ol = (uint64_t)lev*nw;
+                double const rdir = rd[u];
+                double const rdif = rf[u];
+                double const B = 1./(1. - rdif*Rup_prev);
+                double up = (dir_beam*rdir + dif_beam*rdif)*B;
+                double dn = dir_beam*(1. + rdir*Rup_prev*B) + dif_beam*B;
+                up *= scale;
+                dn *= scale;
+                fu[ol] = tsi*up;
+                fd[ol] = tsi*dn;
+            }
+        }
+    }
+}
+
 } // namespace
 
 extern "C" int grt_launch_sw(void *stream, GrtSwArgs const *a)
@@ -382,6 +538,19 @@ extern "C" int grt_launch_sw(void *stream, GrtSwArgs const *a)
                                            : (a->flux_up == nullptr || a->flux_down == nullptr)))
     {
         return (int)hipErrorInvalidValue;
+    }
+    if (!fused && a->layer_props != nullptr)
+    {
+        uint64_t const cells = (uint64_t)(a->num_levels - 1)*a->nw;
+        if (cells > 0xffffffffull*kPropsBlock || a->omega == nullptr || a->g == nullptr)
+        {
+            return (int)hipErrorInvalidValue;
+        }
+        hipLaunchKernelGGL(sw_props_kernel, dim3((unsigned)((cells + kPropsBlock - 1)/kPropsBlock), a->ncol, 1),
+                           dim3(kPropsBlock), 0, (hipStream_t)stream, *a);
+        hipLaunchKernelGGL(sw_sweeps_kernel, dim3((unsigned)((a->nw + kSweepBlock - 1)/kSweepBlock), a->ncol, 1),
+                           dim3(kSweepBlock), 0, (hipStream_t)stream, *a);
+        return (int)hipGetLastError();
     }
     dim3 const grid((unsigned)((a->nw + kBlock - 1)/kBlock), a->ncol, 1);   // == grt_solver_blocks(nw): same kBlock
     if (fused)

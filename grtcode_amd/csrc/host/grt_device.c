@@ -143,6 +143,67 @@ void *grt_dev_stream_of_lane(Device_t device, int lane)
     return (void *)*s;
 }
 
+/* A stream of its own for the inputs of a one-column solver call (calculate_sw_fluxes uploads three spectra): a copy
+   from pageable memory holds the calling thread until it has been carried out, and on the library stream that would be
+   after the optical-depth kernels still running there.  Here it is carried out at once, next to them. */
+static hipStream_t g_upload_streams[GRT_MAX_DEVICES];
+
+void *grt_dev_upload_stream(Device_t device)
+{
+    if (device < 0 || device >= GRT_MAX_DEVICES)
+    {
+        return NULL;
+    }
+    hipStream_t *s = &g_upload_streams[device];
+    if (*s == NULL)
+    {
+        if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(s, hipStreamNonBlocking) != hipSuccess)
+        {
+            *s = NULL;
+        }
+    }
+    return (void *)*s;
+}
+
+/* waits for this stream alone (grt_dev_sync waits for the whole device once lanes are in use) */
+int grt_dev_stream_sync(Device_t device, void *stream)
+{
+    GRT_TRY(grt_dev_require(device));
+    GRT_TRY(grt_dev_check((int)hipStreamSynchronize((hipStream_t)stream), "hipStreamSynchronize"));
+    return GRTCODE_SUCCESS;
+}
+
+/* work queued on `stream` after this call starts only when `ev` (recorded on another stream) has happened */
+int grt_dev_stream_wait_event(Device_t device, void *stream, void *ev)
+{
+    GRT_TRY(grt_dev_require(device));
+    GRT_TRY(grt_dev_check((int)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0), "hipStreamWaitEvent"));
+    return GRTCODE_SUCCESS;
+}
+
+/* 1 when `p` is host memory the device writes in place (grt_dev_alloc_host_visible): a call that fills such an array
+   must have finished when it returns, because the caller reads the array itself */
+int grt_dev_is_host_memory(void const *p)
+{
+    hipPointerAttribute_t attr;
+    memset(&attr, 0, sizeof(attr));
+    if (hipPointerGetAttributes(&attr, p) == hipSuccess)
+    {
+        return attr.type == hipMemoryTypeHost ? 1 : 0;
+    }
+    (void)hipGetLastError();
+    return 0;
+}
+
+int grt_dev_sync_if_host_memory(Device_t device, void const *p, void *stream)
+{
+    if (grt_dev_is_host_memory(p))
+    {
+        GRT_TRY(grt_dev_sync(device, stream));
+    }
+    return GRTCODE_SUCCESS;
+}
+
 int grt_dev_alloc(Device_t device, void **p, size_t bytes)
 {
     GRT_REQUIRE_PTR(p);

@@ -2004,7 +2004,10 @@ EXTERN int calculate_optical_depth(GasOptics_t * const gas_optics, fp_t * const 
                              gas_optics->x_cia, im->colstate_h));
     uint64_t const per_col = (uint64_t)gas_optics->num_layers*gas_optics->grid.n;
     GRT_TRY(launch_columns(gas_optics, 1, optics->tau, per_col));
-    GRT_TRY(grt_dev_sync(gas_optics->device, grt_dev_stream(gas_optics->device)));
+    /* no wait here: what reads optics->tau next (rayleigh_scattering, add_optics, a solver, a download) is queued behind
+       these kernels on the same stream, and the caller's host work between the calls goes on meanwhile.  Only an
+       object in host-visible memory, which the caller may read itself, must be complete at the return. */
+    GRT_TRY(grt_dev_sync_if_host_memory(gas_optics->device, optics->tau, grt_dev_stream(gas_optics->device)));
     return GRTCODE_SUCCESS;
 }
 

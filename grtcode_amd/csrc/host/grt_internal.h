@@ -52,6 +52,11 @@ int grt_dev_upload(Device_t device, void *dst, void const *src, size_t bytes, vo
 int grt_dev_download(Device_t device, void *dst, void const *src, size_t bytes, void *stream);
 int grt_dev_copy(Device_t device, void *dst, void const *src, size_t bytes, void *stream);
 int grt_dev_sync(Device_t device, void *stream);
+int grt_dev_is_host_memory(void const *p);              /* 1: host memory the device writes in place */
+int grt_dev_sync_if_host_memory(Device_t device, void const *p, void *stream);
+void *grt_dev_upload_stream(Device_t device);           /* a stream of its own for the inputs of a one-column solver call */
+int grt_dev_stream_sync(Device_t device, void *stream); /* this stream alone */
+int grt_dev_stream_wait_event(Device_t device, void *stream, void *ev);
 int grt_dev_event_record(Device_t device, void **ev, void *stream);
 int grt_dev_event_wait(Device_t device, void *ev);
 int grt_dev_event_destroy(Device_t device, void **ev);

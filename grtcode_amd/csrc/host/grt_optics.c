@@ -90,7 +90,7 @@ EXTERN int grt_optics_cache_flush(void)
    (driver.c:507-525 writes the cloud objects' tau/omega/g on the host).  Slower for the kernels (host link instead of
    HBM); results of add_optics are always device memory. */
 static int create_optics_in(Optics_t * const optics, int const num_layers, SpectralGrid_t const * const grid,
-                            Device_t const * const device, int host_visible)
+                            Device_t const * const device, int host_visible, int zeroed)
 {
     GRT_REQUIRE_PTR(optics);
     GRT_REQUIRE_PTR(grid);
@@ -113,8 +113,11 @@ static int create_optics_in(Optics_t * const optics, int const num_layers, Spect
     {
         GRT_TRY(grt_dev_alloc(*device, &block, 3*bytes));
     }
-    GRT_TRY(grt_dev_zero(*device, block, 3*bytes, s));          /* optics.c:194-199 */
-    GRT_TRY(grt_dev_sync(*device, s));
+    if (zeroed)
+    {
+        GRT_TRY(grt_dev_zero(*device, block, 3*bytes, s));      /* optics.c:194-199 */
+        GRT_TRY(grt_dev_sync(*device, s));
+    }
     optics->tau = (fp_t *)block;
     optics->omega = optics->tau + (size_t)num_layers*grid->n;
     optics->g = optics->omega + (size_t)num_layers*grid->n;
@@ -128,7 +131,7 @@ EXTERN int create_optics(Optics_t * const optics, int const num_layers,
                          SpectralGrid_t const * const grid, Device_t const * const device)
 {
     char const *env = getenv("GRT_OPTICS_HOST_VISIBLE");
-    GRT_TRY(create_optics_in(optics, num_layers, grid, device, env != NULL && env[0] == '1'));
+    GRT_TRY(create_optics_in(optics, num_layers, grid, device, env != NULL && env[0] == '1', 1));
     return GRTCODE_SUCCESS;
 }
 
@@ -194,7 +197,10 @@ EXTERN int add_optics(Optics_t const * const * const optics, int const num_optic
                      (void const *)first, (void const *)optics[j]);
         }
     }
-    GRT_TRY(create_optics_in(result, first->num_layers, &first->grid, &first->device, 0));
+    /* the result is device memory, every element of it is written by the kernel below, and whatever reads it next is
+       queued behind that kernel on the library's stream: no zero fill, and no wait (a one-column caller's host work
+       goes on while the optical-depth kernels it has just queued still run) */
+    GRT_TRY(create_optics_in(result, first->num_layers, &first->grid, &first->device, 0, 0));
     void *s = grt_dev_stream(first->device);
     uint64_t const n = (uint64_t)first->num_layers*first->grid.n;
     int rc;
@@ -211,7 +217,6 @@ EXTERN int add_optics(Optics_t const * const * const optics, int const num_optic
         }
         rc = grt_dev_check(grt_launch_add_optics(s, n, num_optics, &in, result->tau, result->omega, result->g),
                            "add_optics kernel");
-        if (rc == GRTCODE_SUCCESS) rc = grt_dev_sync(first->device, s);
     }
     else
     {

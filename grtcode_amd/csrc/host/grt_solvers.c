@@ -111,7 +111,8 @@ EXTERN int create_longwave(Longwave_t * const lw, int const num_levels,
     lw->device = *device;
     size_t const n = grid->n;
     /* one block: T_layers | T_levels | T_surf | emissivity | flux_up | flux_down */
-    size_t const doubles = (size_t)(num_levels - 1) + num_levels + 1 + n + 2*n*num_levels;
+    /* (+ 6 L rows behind flux_down: scratch of the solver's layer-parallel first step, k_longwave.hip) */
+    size_t const doubles = (size_t)(num_levels - 1) + num_levels + 1 + n + 2*n*num_levels + 6*n*(size_t)(num_levels - 1);
     void *block = NULL;
     GRT_TRY(grt_dev_alloc(*device, &block, sizeof(fp_t)*doubles));
     lw->layer_temperature = block;
@@ -157,11 +158,17 @@ EXTERN int calculate_lw_fluxes(Longwave_t * const lw, Optics_t const * const opt
         GRT_REQUIRE_RANGE(emis[i], 0., 1.);
     }
     void *s = grt_dev_stream(lw->device);
+    /* the inputs go up on a stream of their own, at once: the optical-depth kernels of this column may still be
+       running on `s` (calculate_optical_depth does not wait), and a copy from the caller's pageable arrays queued
+       behind them would hold this thread until they end.  The solver is queued on `s` after the copies are done. */
+    void *us = grt_dev_upload_stream(lw->device);
+    GRT_REQUIRE_PTR(us);
     fp_t *t_surf_d = lw->level_temperature + V;
-    GRT_TRY(grt_dev_upload(lw->device, lw->layer_temperature, T_layers, sizeof(fp_t)*L, s));
-    GRT_TRY(grt_dev_upload(lw->device, lw->level_temperature, T_levels, sizeof(fp_t)*V, s));
-    GRT_TRY(grt_dev_upload(lw->device, t_surf_d, &T_surf, sizeof(fp_t), s));
-    GRT_TRY(grt_dev_upload(lw->device, lw->emissivity, emis, sizeof(fp_t)*n, s));
+    GRT_TRY(grt_dev_upload(lw->device, lw->layer_temperature, T_layers, sizeof(fp_t)*L, us));
+    GRT_TRY(grt_dev_upload(lw->device, lw->level_temperature, T_levels, sizeof(fp_t)*V, us));
+    GRT_TRY(grt_dev_upload(lw->device, t_surf_d, &T_surf, sizeof(fp_t), us));
+    GRT_TRY(grt_dev_upload(lw->device, lw->emissivity, emis, sizeof(fp_t)*n, us));
+    GRT_TRY(grt_dev_stream_sync(lw->device, us));
     GrtLwArgs a;
     memset(&a, 0, sizeof(a));
     a.num_levels = V; a.ncol = 1; a.w0 = lw->grid.w0; a.dw = lw->grid.dw; a.nw = n;
@@ -170,6 +177,9 @@ EXTERN int calculate_lw_fluxes(Longwave_t * const lw, Optics_t const * const opt
     a.emis = lw->emissivity; a.emis_stride = 0;
     a.flux_up = lw->flux_up; a.flux_down = lw->flux_down; a.flux_stride = (uint64_t)V*n;
     a.user_level = -1;
+    /* GRT_LW_COLUMN_CHAINS=1: one thread per wavenumber through all the layers, as before round 4 (same fluxes) */
+    char const *chains = getenv("GRT_LW_COLUMN_CHAINS");
+    a.layer_terms = (chains != NULL && chains[0] == '1') ? NULL : lw->flux_down + n*(size_t)V;
     GRT_TRY(grt_dev_check(grt_launch_lw(s, &a), "longwave kernel"));
     GRT_TRY(download_fluxes(lw->device, V, n, flux_up, flux_down, lw->flux_up, lw->flux_down, s));
     GRT_TRY(grt_dev_sync(lw->device, s));
@@ -190,9 +200,10 @@ EXTERN int create_shortwave(Shortwave_t * const sw, int const num_levels,
     sw->grid = *grid;
     sw->device = *device;
     size_t const n = grid->n;
-    /* one block: solar | alb_dir | alb_dif | mu_dir,tsi | flux_up | flux_down */
+    /* one block: solar | alb_dir | alb_dif | mu_dir,tsi | flux_up | flux_down | the layers' five properties
+       (5 L rows behind flux_down: scratch of the solver's layer-parallel first step, k_shortwave.hip) */
     void *block = NULL;
-    GRT_TRY(grt_dev_alloc(*device, &block, sizeof(fp_t)*(3*n + 2 + 2*n*num_levels)));
+    GRT_TRY(grt_dev_alloc(*device, &block, sizeof(fp_t)*(3*n + 2 + 2*n*num_levels + 5*n*(size_t)(num_levels - 1))));
     sw->solar_flux = block;
     sw->sfc_alpha_dir = sw->solar_flux + n;
     sw->sfc_alpha_dif = sw->sfc_alpha_dir + n;
@@ -236,13 +247,15 @@ EXTERN int calculate_sw_fluxes(Shortwave_t * const sw, Optics_t const * const op
     }
     int const V = sw->num_levels, L = V - 1;
     void *s = grt_dev_stream(sw->device);
+    void *us = grt_dev_upload_stream(sw->device);      /* see calculate_lw_fluxes */
+    GRT_REQUIRE_PTR(us);
     fp_t *scal_d = sw->sfc_alpha_dif + n;      /* [0] mu_dir, [1] tsi */
     fp_t const scal_h[2] = {mu_dir, total_solar_irradiance};
-    GRT_TRY(grt_dev_upload(sw->device, sw->solar_flux, solar_flux, sizeof(fp_t)*n, s));
-    GRT_TRY(grt_dev_upload(sw->device, sw->sfc_alpha_dir, sfc_alpha_dir, sizeof(fp_t)*n, s));
-    GRT_TRY(grt_dev_upload(sw->device, sw->sfc_alpha_dif, sfc_alpha_dif, sizeof(fp_t)*n, s));
-    GRT_TRY(grt_dev_upload(sw->device, scal_d, scal_h, sizeof(scal_h), s));
-    GRT_TRY(grt_dev_sync(sw->device, s));      /* scal_h is a stack array */
+    GRT_TRY(grt_dev_upload(sw->device, sw->solar_flux, solar_flux, sizeof(fp_t)*n, us));
+    GRT_TRY(grt_dev_upload(sw->device, sw->sfc_alpha_dir, sfc_alpha_dir, sizeof(fp_t)*n, us));
+    GRT_TRY(grt_dev_upload(sw->device, sw->sfc_alpha_dif, sfc_alpha_dif, sizeof(fp_t)*n, us));
+    GRT_TRY(grt_dev_upload(sw->device, scal_d, scal_h, sizeof(scal_h), us));
+    GRT_TRY(grt_dev_stream_sync(sw->device, us));      /* scal_h is a stack array; the solver below starts after them */
     GrtSwArgs a;
     memset(&a, 0, sizeof(a));
     a.num_levels = V; a.ncol = 1; a.nw = n; a.dw = sw->grid.dw;
@@ -252,6 +265,9 @@ EXTERN int calculate_sw_fluxes(Shortwave_t * const sw, Optics_t const * const op
     a.tsi = scal_d + 1; a.solar = sw->solar_flux;
     a.flux_up = sw->flux_up; a.flux_down = sw->flux_down; a.flux_stride = (uint64_t)V*n;
     a.user_level = -1;
+    /* GRT_SW_COLUMN_CHAINS=1: one thread per wavenumber through all the layers, as before round 4 (same fluxes) */
+    char const *chains = getenv("GRT_SW_COLUMN_CHAINS");
+    a.layer_props = (chains != NULL && chains[0] == '1') ? NULL : sw->flux_down + n*(size_t)V;
     GRT_TRY(grt_dev_check(grt_launch_sw(s, &a), "shortwave kernel"));
     GRT_TRY(download_fluxes(sw->device, V, n, flux_up, flux_down, sw->flux_up, sw->flux_down, s));
     GRT_TRY(grt_dev_sync(sw->device, s));
@@ -285,18 +301,11 @@ EXTERN int rayleigh_scattering(Optics_t * const optics, fp_t * const pressure)
         n[i] = c_air*dp;
     }
     void *s = grt_dev_stream(optics->device);
-    fp_t *n_d = NULL;
-    GRT_TRY(grt_dev_alloc(optics->device, (void **)&n_d, sizeof(fp_t)*L));
-    int rc = grt_dev_upload(optics->device, n_d, n, sizeof(fp_t)*L, s);
-    if (rc == GRTCODE_SUCCESS)
-    {
-        rc = grt_dev_check(grt_launch_rayleigh(s, L, optics->grid.w0, optics->grid.dw, optics->grid.n,
-                                               n_d, optics->tau, optics->omega, optics->g),
-                           "rayleigh kernel");
-    }
-    if (rc == GRTCODE_SUCCESS) rc = grt_dev_sync(optics->device, s);
-    grt_dev_free(optics->device, n_d);
-    GRT_TRY(rc);
+    /* the sixty numbers travel as a kernel argument: nothing to allocate, upload or wait for */
+    GRT_TRY(grt_dev_check(grt_launch_rayleigh(s, L, optics->grid.w0, optics->grid.dw, optics->grid.n,
+                                              n, optics->tau, optics->omega, optics->g),
+                          "rayleigh kernel"));
+    GRT_TRY(grt_dev_sync_if_host_memory(optics->device, optics->tau, s));
     return GRTCODE_SUCCESS;
 }
 

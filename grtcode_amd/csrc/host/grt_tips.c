@@ -155,6 +155,30 @@ static double q_vib(VibModes const *v, double T)
     return q;
 }
 
+typedef struct ModelFactors { double T; double power, ratio; VibModes const *v; int beta15; int valid; } ModelFactors;
+#define GRT_MODEL_MEMO 2048
+static ModelFactors g_memo[GRT_MODEL_MEMO];
+
+static ModelFactors model_factors(VibModes const *v, double beta, double T)
+{
+    uint64_t bits;
+    memcpy(&bits, &T, sizeof(bits));
+    uint64_t h = (bits ^ (uint64_t)(uintptr_t)v*0x9E3779B97F4A7C15ull) + (beta > 1.2 ? 0x51ull : 0ull);
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    ModelFactors *m = &g_memo[h & (GRT_MODEL_MEMO - 1)];
+    int const b15 = beta > 1.2;
+    if (m->valid && m->T == T && m->v == v && m->beta15 == b15)
+    {
+        return *m;
+    }
+    ModelFactors f;
+    f.T = T; f.v = v; f.beta15 = b15; f.valid = 1;
+    f.power = pow(T/296., beta);
+    f.ratio = v != NULL ? q_vib(v, T)/q_vib(v, 296.) : 1.;
+    *m = f;
+    return f;
+}
+
 unsigned long grt_tips_generation(void)
 {
     return g_generation;
@@ -313,10 +337,16 @@ EXTERN fp_t Q(int const mol_id, fp_t const T, int const iso)
     {
         warn_model(mol_id, v == NULL);
     }
-    double q = q296_of(mol_id, iso)*pow(T/296., beta);
+    /* The two factors that cost something -- the power of T/296 and the ratio of the vibrational sums -- depend on the
+       temperature and on the molecule's mode set, not on the isotopologue, and a column asks for every isotopologue of a
+       molecule at each layer's temperature, once per band: they are kept in a small table keyed by (mode set, T) and
+       multiplied in the order of the expression they come from (same doubles, same result).  Process-global like the
+       rest of this file's state (not for concurrent callers). */
+    ModelFactors const f = model_factors(v, beta, T);
+    double q = q296_of(mol_id, iso)*f.power;
     if (v != NULL)
     {
-        q *= q_vib(v, T)/q_vib(v, 296.);
+        q *= f.ratio;
     }
     return q;
 }

@@ -112,6 +112,30 @@ def test_longwave_matches_oracle(oracle, device, L, w0, wn, dw):
     o.destroy()
 
 
+@pytest.mark.parametrize("L", [1, 5, 6, 7, 13, 60])
+def test_longwave_layer_parallel_form_equals_the_chains(device, monkeypatch, L):
+    """calculate_lw_fluxes works the layers' extinctions and Planck terms out first, one thread per (layer, wavenumber),
+    and its sweeps read them six layers at a time; GRT_LW_COLUMN_CHAINS=1 is the one-thread-per-wavenumber kernel of
+    before.  The fluxes are equal to the last bit."""
+    rng = np.random.default_rng(800 + L)
+    grid = api.create_spectral_grid(1.0, 3250.0, 1.0)
+    n = grid.n
+    col = syn.profile(3, L + 1)
+    tau, omega, g = random_optics(rng, L, n)
+    tau[0, : n // 8] = 1e4          # clamped exponent (longwave.c:177-183)
+    emis = rng.uniform(0.9, 1.0, n)
+    o = api.OpticsObject(L, grid, device)
+    o.update(tau, omega, g)
+    lw = api.LongwaveObject(L + 1, grid, device)
+    up, dn = (x.copy() for x in lw.fluxes(o, col["t_surf"], col["t_layer"], col["t"], emis))
+    monkeypatch.setenv("GRT_LW_COLUMN_CHAINS", "1")
+    up1, dn1 = lw.fluxes(o, col["t_surf"], col["t_layer"], col["t"], emis)
+    assert np.array_equal(up, up1) and np.array_equal(dn, dn1)
+    assert np.all(np.isfinite(up)) and up.max() > 0.0
+    lw.destroy()
+    o.destroy()
+
+
 @pytest.mark.parametrize("case", ["random", "huge", "tiny", "near_overflow"])
 def test_longwave_extreme_optical_depths(oracle, device, case):
     # the four regimes of longwave/test/test_longwave.c:102-209 (there only checked for SUCCESS)
@@ -173,6 +197,32 @@ def test_shortwave_matches_oracle(oracle, device, L, dw, scatter):
     assert np.all(np.isfinite(up)) and np.all(np.isfinite(dn))
     scale = max(np.abs(wu).max(), np.abs(wd).max())
     assert np.max(np.abs(up - wu)) / scale < 1e-12 and np.max(np.abs(dn - wd)) / scale < 1e-12
+    sw.destroy()
+    o.destroy()
+
+
+@pytest.mark.parametrize("L", [1, 5, 6, 7, 13, 60])
+def test_shortwave_layer_parallel_form_equals_the_chains(device, monkeypatch, L):
+    """calculate_sw_fluxes works the layers' properties out first, one thread per (layer, wavenumber), and its sweeps
+    read them six layers at a time; GRT_SW_COLUMN_CHAINS=1 is the one-thread-per-wavenumber kernel of before.  Same
+    expressions on the same doubles: the fluxes are equal to the last bit (layer counts around the sweeps' chunk of six)."""
+    rng = np.random.default_rng(700 + L)
+    grid = api.create_spectral_grid(1.0, 5000.0, 1.0)
+    n = grid.n
+    tau, omega, g = random_optics(rng, L, n, True)
+    omega[0, : n // 4] = 1.0
+    omega[-1, n // 4: n // 2] = 0.0
+    tau[L // 2, : n // 8] = 0.0
+    alb = rng.uniform(0.0, 0.6, n)
+    solar = rng.uniform(0.0, 1e-4, n)
+    o = api.OpticsObject(L, grid, device)
+    o.update(tau, omega, g)
+    sw = api.ShortwaveObject(L + 1, grid, device)
+    up, dn = (x.copy() for x in sw.fluxes(o, 0.6, 0.5, alb, alb, 1360.0, solar))
+    monkeypatch.setenv("GRT_SW_COLUMN_CHAINS", "1")
+    up1, dn1 = sw.fluxes(o, 0.6, 0.5, alb, alb, 1360.0, solar)
+    assert np.array_equal(up, up1) and np.array_equal(dn, dn1)
+    assert np.all(np.isfinite(up)) and up.max() > 0.0
     sw.destroy()
     o.destroy()
 
