@@ -430,13 +430,21 @@ __global__ __launch_bounds__(kSweepBlock) void sw_sweeps_kernel(GrtSwArgs a)
     double Rdif_dn = a.alb_dif[(uint64_t)col*a.alb_stride + i];
     fu[(uint64_t)L*nw] = Rdir_dn;
     fd[(uint64_t)L*nw] = Rdif_dn;
+    // (the next six layers' properties are asked for before the chain works through the six it has: the loads' latency
+    // is as long as the six steps)
+    LayerProps pr[kSweepChunk], nx[kSweepChunk];
+#pragma unroll
+    for (int u = 0; u < kSweepChunk; ++u)
+    {
+        pr[u] = load(L - 1 - u >= 0 ? L - 1 - u : 0);
+    }
     for (int jb = L - 1; jb >= 0; jb -= kSweepChunk)
     {
-        LayerProps pr[kSweepChunk];
 #pragma unroll
         for (int u = 0; u < kSweepChunk; ++u)
         {
-            pr[u] = load(jb - u >= 0 ? jb - u : 0);
+            int const j = jb - kSweepChunk - u;
+            nx[u] = load(j >= 0 ? j : 0);
         }
 #pragma unroll
         for (int u = 0; u < kSweepChunk; ++u)
@@ -456,6 +464,11 @@ __global__ __launch_bounds__(kSweepBlock) void sw_sweeps_kernel(GrtSwArgs a)
                 fd[o] = Rdif_dn;
             }
         }
+#pragma unroll
+        for (int u = 0; u < kSweepChunk; ++u)
+        {
+            pr[u] = nx[u];
+        }
     }
 
     // sweep 2: shortwave.c:299-329 fused, then the scalings of :401-405 and :447-451
@@ -473,17 +486,24 @@ __global__ __launch_bounds__(kSweepBlock) void sw_sweeps_kernel(GrtSwArgs a)
     }
     double Rup_prev2 = 0.;    // R_dif_upward[lev-2]
     double Rup_prev = 0.;     // R_dif_upward[lev-1]
+    double rd[kSweepChunk], rf[kSweepChunk], nrd[kSweepChunk], nrf[kSweepChunk];
+#pragma unroll
+    for (int u = 0; u < kSweepChunk; ++u)
+    {
+        int const lev = 1 + u < V ? 1 + u : V - 1;
+        pr[u] = load(lev - 1);
+        rd[u] = fu[(uint64_t)lev*nw];              // R_dir_downward[lev] of sweep 1
+        rf[u] = fd[(uint64_t)lev*nw];              // R_dif_downward[lev]
+    }
     for (int lb = 1; lb < V; lb += kSweepChunk)
     {
-        LayerProps pr[kSweepChunk];
-        double rd[kSweepChunk], rf[kSweepChunk];
 #pragma unroll
         for (int u = 0; u < kSweepChunk; ++u)
         {
-            int const lev = lb + u < V ? lb + u : V - 1;
-            pr[u] = load(lev - 1);
-            rd[u] = fu[(uint64_t)lev*nw];          // R_dir_downward[lev] of sweep 1
-            rf[u] = fd[(uint64_t)lev*nw];          // R_dif_downward[lev]
+            int const lev = lb + kSweepChunk + u < V ? lb + kSweepChunk + u : V - 1;
+            nx[u] = load(lev - 1);
+            nrd[u] = fu[(uint64_t)lev*nw];
+            nrf[u] = fd[(uint64_t)lev*nw];
         }
 #pragma unroll
         for (int u = 0; u < kSweepChunk; ++u)
@@ -524,6 +544,13 @@ __global__ __launch_bounds__(kSweepBlock) void sw_sweeps_kernel(GrtSwArgs a)
                 fu[ol] = tsi*up;
                 fd[ol] = tsi*dn;
             }
+        }
+#pragma unroll
+        for (int u = 0; u < kSweepChunk; ++u)
+        {
+            pr[u] = nx[u];
+            rd[u] = nrd[u];
+            rf[u] = nrf[u];
         }
     }
 }

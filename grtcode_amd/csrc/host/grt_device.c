@@ -509,7 +509,7 @@ void grt_profile_end(void *stream, int slot)
 }
 
 /* Sum of elapsed milliseconds and number of launches recorded with `tag` since the last
-   reset; call after the stream has been synchronised.  reset != 0 clears the records. */
+   reset (waits for the brackets it reads).  reset != 0 clears the records. */
 EXTERN int grt_profile_read(int tag, double *total_ms, int *launches, int reset)
 {
     GRT_REQUIRE_PTR(total_ms);
@@ -521,6 +521,8 @@ EXTERN int grt_profile_read(int tag, double *total_ms, int *launches, int reset)
         if (g_profile_tag[i] == tag)
         {
             float ms = 0.f;
+            /* (the one-column calls return before their kernels end: wait for this bracket's closing event) */
+            GRT_TRY(grt_dev_check((int)hipEventSynchronize(g_profile_ev[i][1]), "hipEventSynchronize"));
             GRT_TRY(grt_dev_check((int)hipEventElapsedTime(&ms, g_profile_ev[i][0], g_profile_ev[i][1]),
                                   "hipEventElapsedTime"));
             sum += ms;

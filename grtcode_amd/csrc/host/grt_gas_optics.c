@@ -1571,7 +1571,9 @@ static void auto_tune(GasOptics_t const *go, int ncol, int moments, int *tile, i
            workgroups of a tile read one slice of the line store, which should stay in an XCD's 4 MB L2 next to everything
            else: G1 longwave, 64 columns per launch, 256-cell tiles (79 000 lines, 2.8 MB of packed records) 40.2 ms,
            128-cell 36.5, 64-cell 34.9 (scripts/tile_sweep.sh). */
-        while (moments == 2 && want > 64 && per_cell*(double)(want/2) >= 6000.
+        /* ONE column of that band with the round-4 lean first pass: 128-cell tiles in four slices 0.559 ms, 64-cell tiles
+           in two 0.594, 256-cell in eight 0.581 (scripts/sweep_one_column.py) -- a lone column stops at 128 */
+        while (moments == 2 && want > (ncol == 1 ? 128 : 64) && per_cell*(double)(want/2) >= 6000.
                && (((nw + want - 1)/want)*(uint64_t)go->num_layers*(uint64_t)ncol < 16384 || per_cell*(double)want > 24000.))
         {
             want >>= 1;

@@ -190,12 +190,12 @@ def test_randomised_grids_profiles_and_launch_shapes(tmp_path, oracle, lib, devi
     check(band, device, oracle, lib, col, tile=tile, nslice=nslice)
 
 
-@pytest.mark.parametrize("lines_per_cell,cells,want", [(308, 200, (64, 2)), (30, 1000, (256, 1)), (2, 600, (256, 1))])
+@pytest.mark.parametrize("lines_per_cell,cells,want", [(308, 200, (128, 4)), (30, 1000, (256, 1)), (2, 600, (256, 1))])
 def test_one_column_launch_shape_keeps_a_few_thousand_lines_per_workgroup(tmp_path, device, lines_per_cell, cells, want):
     """auto_tune (grt_gas_optics.c) for the reference-shaped one-column call: tiles are narrowed and cut into line slices
     to make more workgroups only while a workgroup keeps ~6 000-8 000 lines -- its fixed costs are paid per tile and slice.
-    Measured on G1: the longwave band's density wants 64-cell tiles in 2 slices (0.81 ms; 8 slices: 0.99),
-    the shortwave band's 256-cell tiles unsliced (1.91 ms; 128-cell tiles: 2.14)."""
+    Measured on G1 (round 4's lean first pass): the longwave band's density wants 128-cell tiles in 4 slices
+    (0.56 ms; 64-cell tiles in 2: 0.59), the shortwave band's 256-cell tiles unsliced (1.52 ms; 128-cell tiles: 1.58)."""
     band = Band(str(tmp_path), 1000.0, 1000.0 + cells - 1, 1.0, lines_per_cell * cells, with_cfc=False, with_cia=False, with_ctm=False)
     V = 61
     go, grid = band.gas_optics(device, V, from_file=False)
