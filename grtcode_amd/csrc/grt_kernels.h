@@ -137,6 +137,13 @@ typedef struct GrtGasOpticsArgs
     int lean;                 /* set by the launcher (two-pass form, single-level gather, lines.lean_a built for this grid): the
                                  first pass takes the lean fp32 form of the line loop wherever a workgroup's near fields are
                                  seven points wide (GRT_LEAN=0 in the environment switches it off: comparison runs) */
+    uint32_t const *tile_items;    /* two-pass form, or NULL: the launch's work list [n_items][4] = {cell tile, first line, one past
+                                 the last line, ordinal of this piece within its tile} in place of tiles x nslice equal slices --
+                                 a tile that holds many lines appears in several pieces, a sparse one once (the host cuts by
+                                 line count: a lone column of a band whose lines crowd into a few tiles, as real line lists'
+                                 do, would otherwise be a few hundred long workgroups and thousands of short ones).  nslice is
+                                 then 1 when no tile is cut and 2 when any is (moments and tau are added with atomics) */
+    uint32_t n_items;
 } GrtGasOpticsArgs;
 
 int grt_launch_gas_optics(void *stream, GrtGasOpticsArgs const *a);

@@ -462,6 +462,7 @@ __device__ __forceinline__ void drain_near(double *acc, double const *q_amp, flo
 struct WorkItem
 {
     int col, layer, tile_idx, slice;
+    unsigned group;
 };
 
 // XCD-aware work order.  Workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share
@@ -482,6 +483,14 @@ __device__ __forceinline__ WorkItem decode_work(GrtGasOpticsArgs const &a, unsig
     WorkItem w;
     w.col = (int)(rem/(unsigned)a.lay.num_layers);
     w.layer = (int)(rem - (unsigned)w.col*(unsigned)a.lay.num_layers);
+    w.group = group;
+    if (a.tile_items != nullptr)
+    {
+        // the host's work list: pieces of tiles cut by line count (GrtGasOpticsArgs.tile_items)
+        w.tile_idx = (int)a.tile_items[4*(uint64_t)group];
+        w.slice = (int)a.tile_items[4*(uint64_t)group + 3];
+        return w;
+    }
     w.tile_idx = (int)(group/(unsigned)a.nslice);
     w.slice = (int)(group - (unsigned)w.tile_idx*(unsigned)a.nslice);
     return w;

@@ -569,7 +569,12 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
     if (TWO_PASS && a.tile_ranges != nullptr)
     {
         // the host has searched the sorted store for this tile (a superset for any pressure shift up to its bound)
-        if (tid == 0)
+        if (tid == 0 && a.tile_items != nullptr)
+        {
+            range[0] = (long long)a.tile_items[4*(uint64_t)wi.group + 1];
+            range[1] = (long long)a.tile_items[4*(uint64_t)wi.group + 2];
+        }
+        else if (tid == 0)
         {
             uint64_t const jlo = a.tile_ranges[2*tile_idx], jhi = a.tile_ranges[2*tile_idx + 1];
             uint64_t const per = (jhi - jlo + a.nslice - 1)/a.nslice;
@@ -3207,7 +3212,8 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
         return (int)hipErrorInvalidValue;
     }
     unsigned long long const tiles = (a->nw + a->tile - 1)/a->tile;
-    unsigned long long const ngroups = tiles*a->nslice;
+    bool const items = a->fast == 3 && a->tile_items != nullptr && a->tile_ranges != nullptr && a->n_items > 0;
+    unsigned long long const ngroups = items ? a->n_items : tiles*a->nslice;
     unsigned long long const blocks = ngroups*a->lay.num_layers*a->ncol;
     if (blocks == 0 || blocks > 0x7fffffffull)
     {
@@ -3237,6 +3243,15 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
             return (int)e;
         }
         GrtGasOpticsArgs b = *a;
+        if (!items || tree || a->deterministic || a->probe != NULL)
+        {
+            if (items)
+            {
+                return (int)hipErrorInvalidValue;       // (the host builds a work list for none of these)
+            }
+            b.tile_items = nullptr;
+            b.n_items = 0;
+        }
         b.halo = halo;
         b.direct_near = direct_near_wanted();
         b.near_block = (tree && tree_gather_by_wave(fsteps)) ? 64 : 0;

@@ -740,6 +740,9 @@ static int free_store(GasOptics_t *go)
     im->sorted_v0_h = NULL;
     GRT_TRY(grt_dev_free(go->device, im->tile_ranges_d));
     im->tile_ranges_d = NULL;
+    GRT_TRY(grt_dev_free(go->device, im->tile_items_d));
+    im->tile_items_d = NULL;
+    im->n_items = 0;
     im->tr_tile = 0;
     return GRTCODE_SUCCESS;
 }
@@ -1694,20 +1697,66 @@ static int tile_ranges(GasOptics_t *go, int ncol, GrtGasOpticsArgs *a)
             }
             host[2*t + 1] = (uint32_t)l;
         }
-        GRT_TRY(grt_dev_sync(go->device, grt_dev_stream(go->device)));      /* (a launch may still read the old table) */
+        /* The same ranges as a work list cut by line count (GrtGasOpticsArgs.tile_items): a tile that holds more than
+           ~16 000 candidate lines goes in pieces of ~10 000 (at most 16) -- what the measured one-column optimum of a dense
+           band comes to (G1 longwave, 308 lines per cell: 128-cell tiles in four slices) -- and a sparse tile in one. */
+        uint32_t *items = malloc(sizeof(uint32_t)*4*16*(size_t)tiles);
+        uint32_t n_items = 0;
+        int cut = 1;                    /* the largest number of pieces a tile goes in */
+        for (uint64_t t = 0; t < tiles && items != NULL; ++t)
+        {
+            uint32_t const lo_j = host[2*t], hi_j = host[2*t + 1], cnt = hi_j - lo_j;
+            uint32_t pieces = cnt > 16000u ? (cnt + 5000u)/10000u : 1u;
+            pieces = pieces > 16u ? 16u : pieces;
+            cut = (int)pieces > cut ? (int)pieces : cut;
+            uint32_t const per = (cnt + pieces - 1u)/pieces;
+            for (uint32_t k = 0; k < pieces; ++k)
+            {
+                uint32_t const b = lo_j + per*k < hi_j ? lo_j + per*k : hi_j;
+                uint32_t const e = b + per < hi_j ? b + per : hi_j;
+                items[4*(size_t)n_items] = (uint32_t)t;
+                items[4*(size_t)n_items + 1] = b;
+                items[4*(size_t)n_items + 2] = e;
+                items[4*(size_t)n_items + 3] = k;
+                ++n_items;
+            }
+        }
+        GRT_TRY(grt_dev_sync(go->device, grt_dev_stream(go->device)));      /* (a launch may still read the old tables) */
         GRT_TRY(grt_dev_free(go->device, im->tile_ranges_d));
         im->tile_ranges_d = NULL;
+        GRT_TRY(grt_dev_free(go->device, im->tile_items_d));
+        im->tile_items_d = NULL;
+        im->n_items = 0;
         int rc = grt_dev_alloc(go->device, (void **)&im->tile_ranges_d, sizeof(uint32_t)*2*(size_t)tiles);
         void *s = grt_dev_stream(go->device);
         if (rc == GRTCODE_SUCCESS) rc = grt_dev_upload(go->device, im->tile_ranges_d, host, sizeof(uint32_t)*2*(size_t)tiles, s);
+        if (rc == GRTCODE_SUCCESS && items != NULL)
+        {
+            rc = grt_dev_alloc(go->device, (void **)&im->tile_items_d, sizeof(uint32_t)*4*(size_t)n_items);
+            if (rc == GRTCODE_SUCCESS) rc = grt_dev_upload(go->device, im->tile_items_d, items, sizeof(uint32_t)*4*(size_t)n_items, s);
+        }
         if (rc == GRTCODE_SUCCESS) rc = grt_dev_sync(go->device, s);
         free(host);
+        free(items);
         GRT_TRY(rc);
+        im->n_items = im->tile_items_d != NULL ? n_items : 0;
+        im->items_cut = cut;
         im->tr_tile = a->tile;
         im->tr_tiles = tiles;
         im->tr_pbound = pbound;
     }
     a->tile_ranges = im->tile_ranges_d;
+    /* the work list instead of tiles x nslice equal slices: few workgroups (a lone column, a small batch), the flat
+       two-pass form, slices left to the library (tune(nslice = 0)); GRT_TILE_ITEMS=0 keeps the equal slices */
+    char const *env = getenv("GRT_TILE_ITEMS");
+    if (im->n_items > 0 && im->nslice == 0 && a->tree_levels == 0 && a->probe == NULL && !grt_deterministic()
+        && !(env != NULL && env[0] == '0')
+        && tiles*(uint64_t)go->num_layers*(uint64_t)ncol < 16384)
+    {
+        a->tile_items = im->tile_items_d;
+        a->n_items = im->n_items;
+        a->nslice = im->items_cut > 1 ? 2 : 1;
+    }
     return GRTCODE_SUCCESS;
 }
 
@@ -1963,7 +2012,8 @@ static int launch_columns(GasOptics_t *go, int ncol, double *tau_dev, uint64_t t
         GRT_TRY(grt_dev_zero(go->device, tau_dev, sizeof(double)*tau_col_stride*ncol, s));
     }
     int const tag = im->profile_tag ? im->profile_tag : (args.nw <= 10000 ? 1 : 2);
-    long long const info[8] = {args.fast, args.tile, args.nslice, args.tree_levels, args.fast == 3 ? args.halo : 0,
+    /* (with a work list, "nslice" reports the largest number of pieces a tile was cut into) */
+    long long const info[8] = {args.fast, args.tile, args.tile_items != NULL ? im->items_cut : args.nslice, args.tree_levels, args.fast == 3 ? args.halo : 0,
                                args.fast == 3 ? (long long)im->gmom_bytes : 0,
                                (args.fast == 1 || args.fast == 3) ? (args.mom_terms ? args.mom_terms : 8) : 0, 0};
     memcpy(im->last_launch, info, sizeof(info));

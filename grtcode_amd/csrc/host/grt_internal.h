@@ -90,6 +90,9 @@ typedef struct GrtGasOpticsImpl
     int tr_tile;
     uint64_t tr_tiles;
     double tr_pbound;
+    uint32_t *tile_items_d;        /* device [n_items][4], see GrtGasOpticsArgs.tile_items; built with tile_ranges_d */
+    uint32_t n_items;
+    int items_cut;                 /* the largest number of pieces a tile appears in (1: none is cut) */
     /* sweep methods only: one store per molecule (each sorted by centre), prep/sort scratch, bin arrays */
     GrtLineStore mstore[NUM_MOLS];
     void *mstore_block[NUM_MOLS];

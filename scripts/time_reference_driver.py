@@ -61,6 +61,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--columns", type=int, nargs=2, default=[40, 640])   # (a 600-column difference: the start-up, 0.7 s of parsing, varies by tens of ms)
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r4_reference_driver_timing.json"))
+    ap.add_argument("--api-timing", action="store_true",
+                    help="one more default run of the larger column count under scripts/api_timing_shim.c (LD_PRELOAD): the "
+                         "time spent inside each per-column entry point of the library, printed and kept in the record")
     args = ap.parse_args()
     V = W.NUM_LEVELS
     root = tempfile.mkdtemp(prefix="grt_drv_")
@@ -96,6 +99,14 @@ def main():
                 if r.returncode != 0:
                     raise SystemExit(r.stderr[-3000:])
             runs[f"fast{fast}_{n}_columns_wall_s"] = wall
+            if args.api_timing and fast == "3" and n == args.columns[1]:
+                shim = os.path.join(root, "libgrt_api_timing.so")
+                subprocess.run(["gcc", "-std=gnu99", "-O2", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
+                                os.path.join(ROOT, "scripts", "api_timing_shim.c"), "-ldl", "-o", shim], check=True)
+                r = subprocess.run(cmd, capture_output=True, text=True, env=dict(env, LD_PRELOAD=shim))
+                api_lines = [ln for ln in r.stderr.splitlines() if ln.startswith("api_timing")]
+                print("\n".join(api_lines), file=sys.stderr, flush=True)
+                runs["api_timing_of_the_default_run"] = {"columns": n, "lines": api_lines}
             print(f"fast={fast} {n} columns: {wall:.2f} s", file=sys.stderr, flush=True)
     n1, n2 = args.columns
     out = {"binary": "oracle/_ref/grtcode_driver (reference framework/src/driver.c + utilities/src/argparse.c unchanged, "

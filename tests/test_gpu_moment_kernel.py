@@ -81,6 +81,33 @@ def test_dense_lines_many_per_cell(tmp_path, oracle, lib, device, tile, nslice):
     check(band, device, oracle, lib, syn.profile(2, 13), tile=tile, nslice=nslice)
 
 
+def test_lone_column_of_a_crowded_band_is_cut_by_line_count(tmp_path, oracle, lib, device, monkeypatch):
+    """A band whose lines crowd into one tile (real line lists: the infrared end of a shortwave band) as ONE column: the
+    launch's work list (GrtGasOpticsArgs.tile_items) cuts that tile into pieces of ~10 000 lines and leaves the empty
+    tiles whole; same optical depths as the equal slices it replaces (GRT_TILE_ITEMS=0) and as the oracle."""
+    band = Band(str(tmp_path), 1000.0, 2599.0, 1.0, 60000, line_range=(1000.0, 1100.0), with_cfc=False, with_cia=False)
+    col = syn.profile(5, 13)
+    V = col["p"].size
+    want = band.oracle_tau(oracle, oracle, lib, col)
+    taus = {}
+    for label, env in (("items", None), ("slices", "0")):
+        if env is not None:
+            monkeypatch.setenv("GRT_TILE_ITEMS", env)
+        go, grid = band.gas_optics(device, V, from_file=False)
+        go.tune(fast=3)
+        band.set_column(go, col)
+        opt = api.OpticsObject(V - 1, grid, device)
+        go.calculate_optical_depth(col["p"], col["t"], opt)
+        taus[label] = opt.read()[0]
+        info = go.last_launch()
+        if label == "items" and not api.load_library().grt_deterministic():
+            assert info["tile"] == 256 and info["nslice"] == 6, info       # 60 000 lines in tile 0: six pieces
+        opt.destroy()
+        go.destroy()
+    assert tau_close(taus["items"], want) < FAST_TOL
+    assert tau_close(taus["items"], taus["slices"]) < 6e-7
+
+
 def test_sparse_lines_many_cells_per_wave(tmp_path, oracle, lib, device):
     """One line every ~10 grid points: a wave's lines span hundreds of cells (per-lane LDS adds of the moments)."""
     band = Band(str(tmp_path), 1.0, 3000.0, 1.0, 300)
