@@ -1703,10 +1703,14 @@ static int tile_ranges(GasOptics_t *go, int ncol, GrtGasOpticsArgs *a)
         uint32_t *items = malloc(sizeof(uint32_t)*4*16*(size_t)tiles);
         uint32_t n_items = 0;
         int cut = 1;                    /* the largest number of pieces a tile goes in */
+        /* (GRT_ITEM_LINES=n: pieces of ~n lines, tiles of more than 1.6 n cut -- for sweeps; the default is the measured one) */
+        char const *il = getenv("GRT_ITEM_LINES");
+        uint32_t const per_piece = (il != NULL && atoi(il) >= 1000) ? (uint32_t)atoi(il) : 10000u;
+        uint32_t const cut_from = per_piece + per_piece*3u/5u;
         for (uint64_t t = 0; t < tiles && items != NULL; ++t)
         {
             uint32_t const lo_j = host[2*t], hi_j = host[2*t + 1], cnt = hi_j - lo_j;
-            uint32_t pieces = cnt > 16000u ? (cnt + 5000u)/10000u : 1u;
+            uint32_t pieces = cnt > cut_from ? (cnt + per_piece/2u)/per_piece : 1u;
             pieces = pieces > 16u ? 16u : pieces;
             cut = (int)pieces > cut ? (int)pieces : cut;
             uint32_t const per = (cnt + pieces - 1u)/pieces;

@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--api-timing", action="store_true",
                     help="one more default run of the larger column count under scripts/api_timing_shim.c (LD_PRELOAD): the "
                          "time spent inside each per-column entry point of the library, printed and kept in the record")
+    ap.add_argument("--sweep-item-lines", type=int, nargs="*", default=[],
+                    help="instead of the timing runs: 100 default columns under the shim for each GRT_ITEM_LINES given "
+                         "(lines per piece of the lone-column work list), the library's kernel brackets printed")
     args = ap.parse_args()
     V = W.NUM_LEVELS
     root = tempfile.mkdtemp(prefix="grt_drv_")
@@ -78,6 +81,25 @@ def main():
     runs = {}
     # "3rows": the default arithmetic with the driver's opt-in GRT_FLUX_ROWS=toa,sfc (only the rows `-integrated` integrates
     # cross PCIe: INTEGRATION.md section 7)
+    if args.sweep_item_lines:
+        shim = os.path.join(root, "libgrt_api_timing.so")
+        subprocess.run(["gcc", "-std=gnu99", "-O2", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "scripts", "api_timing_shim.c"), "-ldl", "-o", shim], check=True)
+        cols = os.path.join(root, "columns_100.txt")
+        with open(cols, "w") as f:
+            f.write("".join(column_text(c, V) for c in range(100)))
+        cmd = [DRIVER, par, files["solar"], cols, *("-" + NAME[m] for m in W.MOL_ORDER), "-h2o-ctm", files["h2o_dir"],
+               "-o3-ctm", files["o3_ctm"], "-CFC-11", files["cfc11"], "-CFC-12", files["cfc12"], "-N2-N2", files["cia_n2n2"],
+               "-O2-N2", files["cia_o2n2"], "-O2-O2", files["cia_o2o2"], "-a", "0.2", "-e", "0.98",
+               "-w-lw", "1", "-W-lw", "3250", "-r-lw", "1", "-w-sw", "1", "-W-sw", "50000", "-r-sw", "1",
+               "-integrated", "-o", os.path.join(root, "out_sweep.txt")]
+        for n in args.sweep_item_lines:
+            env = dict(os.environ, GRT_GAS_OPTICS_FAST="3", GRT_TIPS_QUIET="1", GRT_HITRAN_CACHE_DIR=root, LD_PRELOAD=shim,
+                       GRT_ITEM_LINES=str(n))
+            r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+            print(f"GRT_ITEM_LINES={n}", file=sys.stderr)
+            print("\n".join(ln for ln in r.stderr.splitlines() if "bracket" in ln or "inside" in ln), file=sys.stderr, flush=True)
+        return
     for fast in ("3", "3rows", "0"):
         for n in args.columns:
             cols = os.path.join(root, f"columns_{n}.txt")
@@ -113,6 +135,25 @@ def main():
                      "examples/driver_app.c, libgrtcode_hip.so)", "options": "-integrated, LW 1-3250 + SW 1-50000 cm-1 @1 cm-1, 61 levels",
            "lines": {"lw_band": int(sum((ln["v0"] <= 3250.0).sum() for ln in lists.values())),
                      "sw_band": int(sum(ln["v0"].size for ln in lists.values()))}, "runs": runs}
+    if args.sweep_item_lines:
+        shim = os.path.join(root, "libgrt_api_timing.so")
+        subprocess.run(["gcc", "-std=gnu99", "-O2", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "scripts", "api_timing_shim.c"), "-ldl", "-o", shim], check=True)
+        cols = os.path.join(root, "columns_100.txt")
+        with open(cols, "w") as f:
+            f.write("".join(column_text(c, V) for c in range(100)))
+        cmd = [DRIVER, par, files["solar"], cols, *("-" + NAME[m] for m in W.MOL_ORDER), "-h2o-ctm", files["h2o_dir"],
+               "-o3-ctm", files["o3_ctm"], "-CFC-11", files["cfc11"], "-CFC-12", files["cfc12"], "-N2-N2", files["cia_n2n2"],
+               "-O2-N2", files["cia_o2n2"], "-O2-O2", files["cia_o2o2"], "-a", "0.2", "-e", "0.98",
+               "-w-lw", "1", "-W-lw", "3250", "-r-lw", "1", "-w-sw", "1", "-W-sw", "50000", "-r-sw", "1",
+               "-integrated", "-o", os.path.join(root, "out_sweep.txt")]
+        for n in args.sweep_item_lines:
+            env = dict(os.environ, GRT_GAS_OPTICS_FAST="3", GRT_TIPS_QUIET="1", GRT_HITRAN_CACHE_DIR=root, LD_PRELOAD=shim,
+                       GRT_ITEM_LINES=str(n))
+            r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+            print(f"GRT_ITEM_LINES={n}", file=sys.stderr)
+            print("\n".join(ln for ln in r.stderr.splitlines() if "bracket" in ln or "inside" in ln), file=sys.stderr, flush=True)
+        return
     for fast in ("3", "3rows", "0"):
         dt = (runs[f"fast{fast}_{n2}_columns_wall_s"] - runs[f"fast{fast}_{n1}_columns_wall_s"]) / (n2 - n1)
         out[f"fast{fast}"] = {"seconds_per_column": dt, "columns_per_s": 1.0 / dt,
