@@ -110,6 +110,30 @@ def test_sources_and_isotopologue_dependence(model):
     assert lib.Q(2, 250.0, 2) / lib.Q(2, 296.0, 2) != lib.Q(2, 250.0, 1) / lib.Q(2, 296.0, 1)
 
 
+def test_model_factors_are_memoised_without_changing_a_bit(model):
+    """grt_tips.c keeps the model's two costly factors per (mode set, T) in a 2 048-entry table (a column asks for every
+    isotopologue of a molecule at each layer's temperature, once per band).  Whatever the order of the calls, and after
+    the entries have been pushed out by thousands of other temperatures, Q returns the same doubles."""
+    lib = model
+    rng = np.random.default_rng(11)
+    temps = rng.uniform(150.0, 350.0, 120)
+    cases = [(m, i, float(t)) for m in (1, 2, 3, 4, 5, 6, 7) for i in (1, 2, 3) for t in temps]
+    first = np.array([lib.Q(m, t, i) for m, i, t in cases])
+    order = rng.permutation(len(cases))
+    again = np.empty_like(first)
+    for k in order:
+        m, i, t = cases[k]
+        again[k] = lib.Q(m, t, i)
+    assert np.array_equal(first, again)
+    for t in rng.uniform(150.0, 350.0, 6000):          # evict everything, several times over
+        lib.Q(int(rng.integers(1, 8)), float(t), 1)
+    third = np.array([lib.Q(m, t, i) for m, i, t in cases])
+    assert np.array_equal(first, third)
+    # the factors do not depend on the isotopologue where the molecule has one mode set: the ratio to 296 K is shared
+    r = [lib.Q(2, 231.7, i) / lib.Q(2, 296.0, i) for i in (1, 2)]
+    assert np.isfinite(r).all()
+
+
 def test_rescale_follows_the_current_provider(model, pins, tmp_path):
     """grt_rescale_strengths (parse_HITRAN_file.c:372-384) uses Q(296) of whatever provider is current: a table loaded
     after add_molecule must not be mixed with strengths scaled by the model -- objects therefore keep raw
