@@ -195,9 +195,12 @@ int grt_dev_is_host_memory(void const *p)
     return 0;
 }
 
+/* The reference-shaped calls that only queue work return without waiting (stream order does the rest) -- unless the
+   result lives in host memory, which the caller reads itself, or lanes other than 0 are in use: then the next call may be
+   queued on another lane's stream, which nothing orders behind this one, so the call finishes its work as it always did */
 int grt_dev_sync_if_host_memory(Device_t device, void const *p, void *stream)
 {
-    if (grt_dev_is_host_memory(p))
+    if ((device >= 0 && device < GRT_MAX_DEVICES && g_lanes_used[device]) || grt_dev_is_host_memory(p))
     {
         GRT_TRY(grt_dev_sync(device, stream));
     }

@@ -217,6 +217,7 @@ EXTERN int add_optics(Optics_t const * const * const optics, int const num_optic
         }
         rc = grt_dev_check(grt_launch_add_optics(s, n, num_optics, &in, result->tau, result->omega, result->g),
                            "add_optics kernel");
+        if (rc == GRTCODE_SUCCESS) rc = grt_dev_sync_if_host_memory(first->device, result->tau, s);    /* (lanes in use: waits) */
     }
     else
     {
