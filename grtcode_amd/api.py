@@ -138,7 +138,7 @@ create_solar_flux destroy_solar_flux disort_shortwave
 grt_tips_load grt_tips_reset grt_tips_is_table grt_tips_source grt_sizeof grt_add_molecule_lines grt_gas_optics_tune grt_gas_optics_last_launch grt_hitran_index_stats
 grt_optical_depth_batch grt_pipeline_create grt_pipeline_create_ex grt_pipeline_destroy grt_pipeline_run grt_pipeline_sync
 grt_pipeline_stream grt_pipeline_views grt_device_malloc grt_device_free grt_device_to_host
-grt_host_to_device grt_debug_line_prep grt_debug_partition_functions grt_debug_voigt grt_debug_line_strengths grt_profile_enable grt_profile_read
+grt_host_to_device grt_debug_line_prep grt_debug_partition_functions grt_debug_tile_items grt_debug_voigt grt_debug_line_strengths grt_profile_enable grt_profile_read
 grt_set_deterministic grt_deterministic grt_gas_optics_probe grt_optics_cache_flush grt_device_use_lane grt_device_synchronize
 grt_multi_shard grt_multi_create grt_multi_destroy grt_multi_gather_fluxes grt_multi_broadcast grt_multi_max
 grt_err_begin grt_err_frame grt_log grt_gmalloc grt_gfree grt_gmemset grt_gmemcpy
@@ -320,6 +320,17 @@ class GasOpticsObject:
         info = (C.c_longlong * 8)()
         check(self.lib.grt_gas_optics_last_launch(C.byref(self.c), info))
         return dict(zip(("fast", "tile", "nslice", "tree_levels", "halo", "moment_bytes", "moments"), info))
+
+    def tile_items(self):
+        """(items [n][4], ranges [tiles][2]) of the last two-pass launch table: grt_debug_tile_items (include/grt_ext.h)."""
+        n, tiles = C.c_uint32(), C.c_uint64()
+        check(self.lib.grt_debug_tile_items(C.byref(self.c), C.byref(n), None, C.byref(tiles), None))
+        items = np.zeros((n.value, 4), dtype=np.uint32)
+        ranges = np.zeros((tiles.value, 2), dtype=np.uint32)
+        if n.value and tiles.value:
+            check(self.lib.grt_debug_tile_items(C.byref(self.c), C.byref(n), items.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                C.byref(tiles), ranges.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return items, ranges
 
     def calculate_optical_depth(self, p_mb, t, optics):
         p_mb, t = _f64(p_mb).copy(), _f64(t).copy()

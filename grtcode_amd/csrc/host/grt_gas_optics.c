@@ -742,6 +742,9 @@ static int free_store(GasOptics_t *go)
     im->tile_ranges_d = NULL;
     GRT_TRY(grt_dev_free(go->device, im->tile_items_d));
     im->tile_items_d = NULL;
+    free(im->tile_items_h);
+    free(im->tile_ranges_h);
+    im->tile_items_h = im->tile_ranges_h = NULL;
     im->n_items = 0;
     im->tr_tile = 0;
     return GRTCODE_SUCCESS;
@@ -1740,8 +1743,10 @@ static int tile_ranges(GasOptics_t *go, int ncol, GrtGasOpticsArgs *a)
             if (rc == GRTCODE_SUCCESS) rc = grt_dev_upload(go->device, im->tile_items_d, items, sizeof(uint32_t)*4*(size_t)n_items, s);
         }
         if (rc == GRTCODE_SUCCESS) rc = grt_dev_sync(go->device, s);
-        free(host);
-        free(items);
+        free(im->tile_ranges_h);
+        free(im->tile_items_h);
+        im->tile_ranges_h = host;           /* (kept: grt_debug_tile_items) */
+        im->tile_items_h = items;
         GRT_TRY(rc);
         im->n_items = im->tile_items_d != NULL ? n_items : 0;
         im->items_cut = cut;
@@ -2172,6 +2177,28 @@ EXTERN int grt_debug_line_prep(GasOptics_t *gas_optics, fp_t *pressure, fp_t *te
     if (rc == GRTCODE_SUCCESS) rc = grt_dev_sync(dev, s);
     grt_dev_free(dev, d);
     GRT_TRY(rc);
+    return GRTCODE_SUCCESS;
+}
+
+EXTERN int grt_debug_tile_items(GasOptics_t *gas_optics, uint32_t *num_items, uint32_t *items, uint64_t *num_tiles,
+                                uint32_t *ranges)
+{
+    GRT_REQUIRE_PTR(gas_optics);
+    GRT_REQUIRE_PTR(gas_optics->impl);
+    GRT_REQUIRE_PTR(num_items);
+    GRT_REQUIRE_PTR(num_tiles);
+    GrtGasOpticsImpl const *im = impl_of(gas_optics);
+    int const have = im->tile_ranges_d != NULL && im->tile_ranges_h != NULL && im->tile_items_h != NULL;
+    *num_items = have ? im->n_items : 0;
+    *num_tiles = have ? im->tr_tiles : 0;
+    if (have && items != NULL)
+    {
+        memcpy(items, im->tile_items_h, sizeof(uint32_t)*4*(size_t)im->n_items);
+    }
+    if (have && ranges != NULL)
+    {
+        memcpy(ranges, im->tile_ranges_h, sizeof(uint32_t)*2*(size_t)im->tr_tiles);
+    }
     return GRTCODE_SUCCESS;
 }
 

@@ -91,6 +91,7 @@ typedef struct GrtGasOpticsImpl
     uint64_t tr_tiles;
     double tr_pbound;
     uint32_t *tile_items_d;        /* device [n_items][4], see GrtGasOpticsArgs.tile_items; built with tile_ranges_d */
+    uint32_t *tile_items_h, *tile_ranges_h;   /* host copies of both tables (grt_debug_tile_items) */
     uint32_t n_items;
     int items_cut;                 /* the largest number of pieces a tile appears in (1: none is cut) */
     /* sweep methods only: one store per molecule (each sorted by centre), prep/sort scratch, bin arrays */

@@ -243,4 +243,11 @@ EXTERN int grt_debug_voigt(Device_t device, int fast, fp_t w, uint64_t num_wpoin
  * zero beyond a molecule's isotopologue count. */
 EXTERN int grt_debug_partition_functions(GasOptics_t *gas_optics, fp_t *pressure, fp_t *temperature, double *q_out);
 
+/* ---- test hook: the work list of the object's last two-pass launch table (GrtGasOpticsArgs.tile_items: a launch of few
+ * workgroups cuts crowded tiles by line count) and the per-tile candidate ranges it was cut from, as the host built them.
+ * *num_items / *num_tiles: counts (0 before the first launch of the two-pass form); items: host [num_items][4] = {tile,
+ * first line, one past the last, ordinal}, ranges: host [num_tiles][2]; either may be NULL to ask for the counts only. */
+EXTERN int grt_debug_tile_items(GasOptics_t *gas_optics, uint32_t *num_items, uint32_t *items, uint64_t *num_tiles,
+                                uint32_t *ranges);
+
 #endif

@@ -102,6 +102,18 @@ def test_lone_column_of_a_crowded_band_is_cut_by_line_count(tmp_path, oracle, li
         info = go.last_launch()
         if label == "items" and not api.load_library().grt_deterministic():
             assert info["tile"] == 256 and info["nslice"] == 6, info       # 60 000 lines in tile 0: six pieces
+            # the list itself (grt_debug_tile_items): every tile's pieces are its candidate range cut without gaps or
+            # overlaps, in order; only crowded tiles are cut, into pieces of about 10 000 lines
+            items, ranges = go.tile_items()
+            assert ranges.shape[0] == 7 and items.shape[0] == 6 + 6
+            for t in range(ranges.shape[0]):
+                mine = items[items[:, 0] == t]
+                assert list(mine[:, 3]) == list(range(len(mine)))
+                assert mine[0, 1] == ranges[t, 0] and mine[-1, 2] == ranges[t, 1]
+                assert np.array_equal(mine[1:, 1], mine[:-1, 2])
+                count = int(ranges[t, 1]) - int(ranges[t, 0])
+                assert len(mine) == (1 if count <= 16000 else (count + 5000) // 10000)
+            assert int(ranges[0, 1]) - int(ranges[0, 0]) == 60000
         opt.destroy()
         go.destroy()
     assert tau_close(taus["items"], want) < FAST_TOL
