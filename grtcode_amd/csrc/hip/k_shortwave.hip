@@ -126,11 +126,17 @@ struct LayerProps { double Rdir, Tdir, Tpure, Rdif, Tdif; };
 __device__ __forceinline__ LayerProps layer_props(double omega, double g, double tau,
                                                   double mu_dir, double mu_dif)
 {
-    // shortwave.c:86-89
-    double const gs = g/(g + 1.);
-    double const f = g*g;
-    double const os = (1. - f)*omega/(1. - omega*f);
-    double const ts = tau*(1. - omega*f);
+    // shortwave.c:86-89.  With g = 0 exactly -- every clear-sky layer: Rayleigh scattering and absorbing gases -- the
+    // scaling is the identity in floating point too (g/(g + 1) = 0, f = 0, (1 - 0) omega/(1 - omega 0) = omega/1,
+    // tau (1 - 0) = tau: each step exact), so the two divisions are skipped and the same doubles go on
+    double gs = g, os = omega, ts = tau;
+    if (g != 0. || !(omega*0. == 0.))           // (an infinite or NaN omega takes the expressions as written)
+    {
+        gs = g/(g + 1.);
+        double const f = g*g;
+        os = (1. - f)*omega/(1. - omega*f);
+        ts = tau*(1. - omega*f);
+    }
     ExpKt shared = {0., 0., 0., false};
     LayerRT const d = eddington<true>(os, ts, mu_dir, gs, shared);
     LayerRT const s = eddington<false>(os, ts, mu_dif, gs, shared);
