@@ -21,12 +21,12 @@ SO = os.path.join(LIB, "libgrtcode_hip.so")
 HOST_SRC = ["grt_error.c", "grt_util.c", "grt_grid.c", "grt_device.c", "grt_optics.c", "grt_tips.c",
             "grt_gas_optics.c", "grt_solvers.c", "grt_pipeline.c", "grt_multi.c", "grt_clouds.c"]
 NOT_IN_SO = {"grt_clouds"}      # libclouds.a only: a maintainer links the reference's own libclouds.a in its place
-HIP_SRC = ["k_gas_optics.hip", "k_gas_optics_mp.hip", "k_gas_optics_sweep.hip", "k_optics.hip", "k_longwave.hip", "k_shortwave.hip"]
+HIP_SRC = ["k_gas_optics.hip", "k_gas_optics_mp.hip", "k_gas_optics_lean.hip", "k_gas_optics_sweep.hip", "k_optics.hip", "k_longwave.hip", "k_shortwave.hip"]
 
 # the reference's archive names (*/src/Makefile.am): which objects go where
 ARCHIVES = {
     "libgrtcode_utilities.a": ["grt_error", "grt_util", "grt_grid", "grt_device", "grt_optics", "k_optics"],
-    "libgas_optics.a": ["grt_tips", "grt_gas_optics", "k_gas_optics", "k_gas_optics_mp", "k_gas_optics_sweep"],
+    "libgas_optics.a": ["grt_tips", "grt_gas_optics", "k_gas_optics", "k_gas_optics_mp", "k_gas_optics_lean", "k_gas_optics_sweep"],
     "liblongwave.a": ["k_longwave"],
     "libshortwave.a": ["k_shortwave"],
     # solvers' host entry points and the batched pipeline reference both bands
@@ -60,40 +60,49 @@ def _run(cmd):
     return r.stdout
 
 
+def _flags_stamp():
+    import hashlib
+    return os.path.join(OBJ, "flags.sha256"), hashlib.sha256("\0".join(CFLAGS + ["|"] + HIPFLAGS).encode()).hexdigest()
+
+
 def _flags_changed():
     """The flags the objects in lib/obj were built with are kept next to them: a build under other flags (GRT_HIPFLAGS_EXTRA
-    set or dropped, a new default) rebuilds everything instead of silently reusing objects of the other configuration."""
-    import hashlib
-    stamp = os.path.join(OBJ, "flags.sha256")
-    want = hashlib.sha256("\0".join(CFLAGS + ["|"] + HIPFLAGS).encode()).hexdigest()
+    set or dropped, a new default) rebuilds everything instead of silently reusing objects of the other configuration.
+    The stamp is removed here and written again only after the link succeeded (build()), so a build that fails half way
+    cannot leave objects of two configurations under a stamp that matches."""
+    stamp, want = _flags_stamp()
     have = open(stamp).read().strip() if os.path.exists(stamp) else None
     if have != want:
-        with open(stamp, "w") as f:
-            f.write(want + "\n")
+        if os.path.exists(stamp):
+            os.remove(stamp)
         return have is not None or any(n.endswith(".o") for n in os.listdir(OBJ))
     return False
 
 
 def build(force=False, verbose=False):
+    from concurrent.futures import ThreadPoolExecutor
     os.makedirs(OBJ, exist_ok=True)
     force = force or _flags_changed()
     headers = [os.path.join(ROOT, "include", h) for h in ("grtcode_hip_api.h", "grt_ext.h")]
-    headers += [os.path.join(CSRC, "grt_kernels.h"), os.path.join(CSRC, "hip", "gas_optics_dev.h"), os.path.join(CSRC, "host", "grt_internal.h"),
-                os.path.join(CSRC, "host", "grt_molecule_table.h")]
-    objs = []
+    headers += [os.path.join(CSRC, "grt_kernels.h"), os.path.join(CSRC, "hip", "gas_optics_dev.h"), os.path.join(CSRC, "hip", "gas_optics_mp_dev.h"),
+                os.path.join(CSRC, "hip", "optics_dev.h"), os.path.join(CSRC, "host", "grt_internal.h"), os.path.join(CSRC, "host", "grt_molecule_table.h")]
+    objs, jobs = [], []
     for f in HOST_SRC:
         src, obj = os.path.join(CSRC, "host", f), os.path.join(OBJ, f[:-2] + ".o")
         if force or _newer(src, obj, headers):
-            out = _run(["gcc"] + CFLAGS + ["-c", src, "-o", obj])
-            if verbose and out:
-                print(out)
+            jobs.append(["gcc"] + CFLAGS + ["-c", src, "-o", obj])
         objs.append(obj)
     for f in HIP_SRC:
         src, obj = os.path.join(CSRC, "hip", f), os.path.join(OBJ, f[:-4] + ".o")
         if force or _newer(src, obj, headers):
-            _run(["hipcc"] + HIPFLAGS + ["-c", src, "-o", obj])
+            jobs.append(["hipcc"] + HIPFLAGS + ["-c", src, "-o", obj])
         objs.append(obj)
-    if force or any(_newer(o, SO) for o in objs):
+    # (the translation units are independent: compiled side by side, four at a time -- the container has 8 CPUs)
+    with ThreadPoolExecutor(max_workers=int(os.environ.get("GRT_BUILD_JOBS", "4"))) as pool:
+        for out in pool.map(_run, jobs):
+            if verbose and out:
+                print(out)
+    if force or jobs or any(_newer(o, SO) for o in objs):
         _run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] +
              [o for o in objs if os.path.basename(o)[:-2] not in NOT_IN_SO] +
              [f"-L{ROCM}/lib", "-lamdhip64", "-lm", "-ldl", f"-Wl,-rpath,{ROCM}/lib"])
@@ -102,6 +111,9 @@ def build(force=False, verbose=False):
             if os.path.exists(path):
                 os.remove(path)
             _run(["ar", "rcs", path] + [os.path.join(OBJ, m + ".o") for m in members])
+    stamp, want = _flags_stamp()
+    with open(stamp, "w") as f:
+        f.write(want + "\n")
     return SO
 
 
