@@ -392,7 +392,11 @@ EXTERN int grt_gmemset(void *ptr, int value, size_t bytes, Device_t loc)
         return GRTCODE_SUCCESS;
     }
     GRT_TRY(grt_dev_require(loc));
-    GRT_TRY(grt_dev_check((int)hipMemset(ptr, value, bytes), "hipMemset"));
+    /* on the library's stream, behind whatever the queued calls still have to do with this memory, and finished on return
+       (the library stream is non-blocking: a hipMemset on the null stream would not be ordered behind it) */
+    void *s = grt_dev_stream(loc);
+    GRT_TRY(grt_dev_check((int)hipMemsetAsync(ptr, value, bytes, (hipStream_t)s), "hipMemsetAsync"));
+    GRT_TRY(grt_dev_sync(loc, s));
     return GRTCODE_SUCCESS;
 }
 

@@ -218,6 +218,16 @@ EXTERN int add_optics(Optics_t const * const * const optics, int const num_optic
         rc = grt_dev_check(grt_launch_add_optics(s, n, num_optics, &in, result->tau, result->omega, result->g),
                            "add_optics kernel");
         if (rc == GRTCODE_SUCCESS) rc = grt_dev_sync_if_host_memory(first->device, result->tau, s);    /* (lanes in use: waits) */
+        /* an INPUT the caller can write from the host (GRT_OPTICS_HOST_VISIBLE objects, as driver.c:507-525 fills its
+           cloud and aerosol optics) must have been read before this call returns: the caller may fill it again at once */
+        for (int j = 0; j < num_optics && rc == GRTCODE_SUCCESS; ++j)
+        {
+            if (grt_dev_is_host_memory(optics[j]->tau))
+            {
+                rc = grt_dev_sync(first->device, s);
+                break;
+            }
+        }
     }
     else
     {

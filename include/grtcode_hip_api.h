@@ -338,6 +338,11 @@ EXTERN int add_cia(GasOptics_t * const gas_optics, int const species1, int const
                    char const * const filepath);
 EXTERN int set_cia_ppmv(GasOptics_t * const gas_optics, int const cia_id,
                         fp_t const * const ppmv);
+/* Asynchronous on a GPU device: calculate_optical_depth, rayleigh_scattering and add_optics queue
+   their kernels on the library's stream and return; the next call that uses the result is ordered behind them, the
+   solvers' calls wait for the fluxes.  They DO wait where the host could see the difference: a result or an input in
+   host-visible memory (GRT_OPTICS_HOST_VISIBLE=1), or a lane other than 0 in use (grt_ext.h: grt_device_use_lane).
+   grt_device_synchronize() waits for everything queued. */
 EXTERN int calculate_optical_depth(GasOptics_t * const gas_optics, fp_t * const pressure,
                                    fp_t * const temperature, Optics_t * const optics);
 EXTERN int get_num_molecules(GasOptics_t const * const gas_optics, int * const n);
