@@ -192,16 +192,17 @@ __device__ __forceinline__ float row_sum_two_groups(float const (&g0)[8], float 
 // line is not the lean form's at all (no Lorentz width, strength outside the scaled fp32 range, centre within 1e-5 of
 // halfway between two grid points, exponent not tabulated): the core kernel takes it whole through the general block.
 constexpr unsigned kCoreExc = 0x80u;
-// lines with core points wait here, per wave, until there are 64 of them (core kernel); blocks with handed-over lines are
-// listed (block start, lanes per half)
-constexpr int kCoreCap = 128;
-constexpr int kLeanListCap = 12;
+// lines with core points wait here, per wave (a scan step lists up to four per lane; a batch of 64 leaves when there are that
+// many); handed-over lines are listed per scan step and byte position (first line counted from the scan's start, lanes:
+// lane l stands for line first + 4 l)
+constexpr int kCoreCap = 64 + 256;
+constexpr int kLeanListCap = 16;
 struct CoreLines
 {
-    unsigned long long xl_mask[kWaves][kLeanListCap][2];
+    unsigned long long xl_mask[kWaves][kLeanListCap];
     unsigned xl_base[kWaves][kLeanListCap];
     unsigned j[kWaves][kCoreCap];            // the line (index into the store)
-    unsigned pk[kWaves][kCoreCap];           // bits 0-6: its core points | (centre index - A0) << 8
+    unsigned pk[kWaves][kCoreCap];           // bits 0-6: its core points
 };
 // The lean loop's per-layer tables sit at FIXED distances from one LDS address (room for kLeanSlots molecule slots, whatever
 // the object has: a launch with more slots takes the general loop), so that one address register per index serves all the
@@ -275,8 +276,17 @@ __device__ __forceinline__ unsigned lean_stim_flags(GrtGasOpticsArgs const &a, d
 __device__ __forceinline__ bool lean_tile_ok(GrtGasOpticsArgs const &a, bool use_moments, int R, int F0, int F1, int nw_i,
                                              int fsteps, int halo)
 {
+#ifdef GRT_LEAN_FORCE    // (timing only: wrong results)
+    (void)F0; (void)F1; (void)nw_i; (void)R;
+    return a.lean != 0 && use_moments && fsteps >= 8 && halo >= 8 && a.lines.lean_a != nullptr && a.core_mask != nullptr;
+#elif defined(GRT_LEAN_EDGES)
+    (void)F0; (void)F1; (void)nw_i;
+    return a.lean != 0 && use_moments && R == 3 && fsteps >= 8 && halo >= 8
+           && a.lines.lean_a != nullptr && a.core_mask != nullptr;
+#else
     return a.lean != 0 && use_moments && R == 3 && F0 >= 8 && F1 + 8 <= nw_i && fsteps >= 8 && halo >= 8
            && a.lines.lean_a != nullptr && a.core_mask != nullptr;
+#endif
 }
 
 // Near-centre points (Humlicek regions 1-4 inside XLIM1) wait in per-wave LDS queues, one queue per
@@ -377,7 +387,10 @@ __device__ int near_radius(GrtGasOpticsArgs const &a, double const *lay, double 
     {
         *zmax = sqrt(0.25 + eta*eta);       // every line of the layer has |z| = |delta + i eta| below this
     }
-    int const r_mp = (int)ceil(moment_separation(a.mom_terms)*sqrt(0.25 + eta*eta)) - 1;
+    int r_mp = (int)ceil(moment_separation(a.mom_terms)*sqrt(0.25 + eta*eta)) - 1;
+#ifdef GRT_SEVEN_ETA
+    if (a.tree_levels == 0 && r_mp == 4 && eta <= 0.3) r_mp = 3;
+#endif
     int const r_lo = r_mp < 3 ? 3 : r_mp;
     double const w_hi = a.w0 + (double)(F1l + fsteps)*a.wres;
     double const alpha_max = 0.83255461115*w_hi*dop;

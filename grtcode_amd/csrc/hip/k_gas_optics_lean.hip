@@ -606,7 +606,11 @@ __device__ __forceinline__ void lean_kernel_body(GrtGasOpticsArgs const &a, long
         }
     };
 
+#ifdef GRT_LEAN_ABL_NOLOOP      // (timing experiments only: prologue and epilogue alone)
+    if (walk_first == 0xffffffffu)
+#else
     if (walk_first < nrel)
+#endif
     {
         lean_fetch(walk_first);
         for (unsigned brel = walk_first; brel < nrel; brel += walk_stride)

@@ -1055,19 +1055,22 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
     //     changes by 2 x^2 times a relative change of x, and region 4's sums cancel so that only the reference's own
     //     sequence of fp32 roundings reproduces its value (gas_optics_dev.h): x AND y have to be the reference's fp32
     //     numbers to the bit -- its fp64 expressions from the line's fp64 centre and its two broadening coefficients
-    //     (general_block's; ONE 16-byte load per line, GrtLineStore.lean_x), REPWID rounded to fp32 as the reference has
-    //     it.  Lines with core points are compacted per wave (LDS, 8 bytes a line), prepared exactly ONCE PER LINE with
-    //     all lanes busy (rounds 3-4 prepared per point: 1.6 points per line at 49 000 cm-1), and their points sorted into
-    //     the class queues, which are evaluated in full batches of one formula each.
-    // Two lines per lane and step here too (the lean kernel's pairs: a lane reads its two lines' bytes in one load).
+    //     (general_block's; ONE 16-byte load per line, GrtLineStore.lean_x), REPWID rounded to fp32 as the reference has it.
+    // How: the waves stream over the bytes of the tile's candidate lines (four lines per lane and step, the next step's
+    // bytes requested a step ahead); lines with core points are compacted into a per-wave list (LDS, 8 bytes a line); 64
+    // listed lines at a time have their records requested (what the exact preparation and the lean kernel's own fp32
+    // strength need: eight scattered loads, L2 hits -- every (layer, column) workgroup of the tile reads the same lines)
+    // and are worked on one batch LATER, when the loads have long landed: prepared exactly ONCE PER LINE with all lanes busy
+    // (rounds 3-4 prepared per point: 1.6 points per line at 49 000 cm-1), their points sorted into the class queues, which
+    // are evaluated in full batches of one formula each.  A listed line that turns out to belong to the neighbouring
+    // tile (the candidate ranges overlap by a cell or two; the centre index is formed as the lean kernel forms it) is dropped.
     // ---------------------------------------------------------------------------------------------------------
-    constexpr int kLinesPerLane = CORE ? 2 : 1;
     auto uniform_flag = [](bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; };
     [[maybe_unused]] bool lean_ok = false;
     [[maybe_unused]] LeanTables *lt = nullptr;
     [[maybe_unused]] CoreLines *cq = nullptr;
     [[maybe_unused]] int lcount = 0;                // wave-uniform: lines waiting in the wave's list
-    [[maybe_unused]] int xcount = 0;                // wave-uniform: blocks with handed-over lines, listed
+    [[maybe_unused]] int xcount = 0;                // wave-uniform: handed-over lines' list entries
     [[maybe_unused]] LeanLayer ll = {0.f, 0.f, 0.f, 0.f, 0.f};
     [[maybe_unused]] unsigned stimf = 0u;
     if constexpr (CORE)
@@ -1076,6 +1079,12 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         lt = reinterpret_cast<LeanTables *>(smem + lean_off);
         cq = reinterpret_cast<CoreLines *>(lt + 1);
         lean_ok = uniform_flag(lean_tile_ok(a, use_moments, R, F0, F1, nw_i, fsteps, halo));
+#ifdef GRT_CORE_DEBUG_PRINT
+        if (!lean_ok && tid == 0 && col == 0 && slice == 0)
+        {
+            printf("NONLEAN nw %d tile %d layer %d R %d mom %d corr %d lean %d\n", nw_i, tile_idx, layer, R, (int)use_moments, (int)corrected, a.lean);
+        }
+#endif
         if (lean_ok)
         {
             lean_fill_tables(lt, ms_l, q_l, ptab, a.lay.num_slots, tid);
@@ -1085,57 +1094,88 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         }
     }
 
-    // (blocks of a lean tile start on even line indices -- a pair of the packed records; a line before jbeg in the first
-    // block is masked)
-    uint64_t const jal = lean_ok ? (jbeg & ~(uint64_t)1) : jbeg;
-    uint64_t const walk_first = a.deterministic ? (wave == 0 ? jal : jend) : jal + (uint64_t)wave*64*kLinesPerLane;
-    unsigned const walk_stride = (a.deterministic ? 64u : (unsigned)kBlock)*kLinesPerLane;
-    // (a lean tile's lines are counted from jal, in 32 bits -- the store has fewer than 2^32 lines where the lean form runs)
+    uint64_t const walk_first = line_walk_first(a, jbeg, jend, wave);
+    unsigned const walk_stride = line_walk_stride(a);
+    // (a lean tile's bytes are read four lines per lane from a four-aligned start; counted from there, in 32 bits -- the
+    // store has fewer than 2^32 lines where the lean form runs)
+    [[maybe_unused]] uint64_t const jal = jbeg & ~(uint64_t)3;
     [[maybe_unused]] unsigned const nrel = (unsigned)(jend - jal);          // the range ends at jal + nrel
-    [[maybe_unused]] unsigned const lo_first = (unsigned)(jbeg - jal);      // 0, or 1: the range begins on an odd index
+    [[maybe_unused]] unsigned const lo_first = (unsigned)(jbeg - jal);      // 0 .. 3: the range begins here
+    [[maybe_unused]] unsigned const scan_stride = a.deterministic ? 256u : (unsigned)kBlock*4u;
+    [[maybe_unused]] unsigned sb = a.deterministic ? (wave == 0 ? 0u : 0xfffffff0u) : (unsigned)wave*256u;      // the wave's next scan step
     [[maybe_unused]] uint8_t const *mrow = nullptr;
+    [[maybe_unused]] unsigned next_m = 0u;
+    [[maybe_unused]] auto scan_fetch = [&](unsigned const at)
+    {
+        unsigned const off = at + 4u*(unsigned)lane;
+        next_m = (at < nrel && off < nrel) ? *reinterpret_cast<unsigned const *>(mrow + off) : 0u;
+    };
     if constexpr (CORE)
     {
         if (lean_ok)
         {
             mrow = a.core_mask + ((uint64_t)col*a.lay.num_layers + layer)*a.core_mask_stride + jal;
+            scan_fetch(sb);
         }
     }
 
-    // 64 (or, at the end, fewer) listed lines, one per lane: S(T) N_s in the lean kernel's own fp32 expressions (the same
-    // numbers: k_gas_optics_lean.hip), x and y of general_block, then the line's core points one per pass into the class queues.
-    [[maybe_unused]] auto drain_lines = [&](int const first, int const count)
+    // A batch of listed lines, one per lane: the loads of what its preparation needs (issued when the batch is taken off
+    // the list, used one batch later)
+    [[maybe_unused]] int pend_n = 0;                // wave-uniform: lines of the batch in flight (0: none)
+    [[maybe_unused]] unsigned p_j = 0u, p_bits = 0u, p_rc = 0u;
+    [[maybe_unused]] float p_d0 = 0.f, p_v0f = 0.f, p_ss = 0.f, p_en = 0.f, p_dsh = 0.f;
+    [[maybe_unused]] int p_ci = 0;
+    [[maybe_unused]] double2 p_lx = make_double2(0., 0.);
+    [[maybe_unused]] auto fetch_lines = [&](int const first, int const count)
     {
         if constexpr (CORE)
         {
             bool const on = lane < count;
             int const i = first + (on ? lane : 0);
-            unsigned const j = cq->j[wave][i];
-            unsigned const pk = cq->pk[wave][i];
-            unsigned bits = on ? (pk & 0x7fu) : 0u;
-            int const c = (int)(pk >> 8) + A0;              // the lean kernel's centre index (exact there, or the line is not here)
-            unsigned const q = j >> 1, h = j & 1u;
+            p_j = cq->j[wave][i];
+            p_bits = on ? (cq->pk[wave][i] & 0x7fu) : 0u;
+            unsigned const q = p_j >> 1, h = p_j & 1u;
+            float const *pa0 = a.lines.lean_a + 4*(uint64_t)q;
             float const *pa1 = a.lines.lean_a + 4*((uint64_t)a.lines.lean_npair + q);
             float const *pb1 = a.lines.lean_b + 4*((uint64_t)a.lines.lean_npair + q);
-            float const v0f = pa1[h], ss = pa1[2u + h], en = pb1[h], dsh = pb1[2u + h];
-            unsigned const rc = a.lines.lean_c[2*(uint64_t)q + h];
+            p_d0 = pa0[h];
+            p_ci = __float_as_int(pa0[2u + h]);
+            p_v0f = pa1[h];
+            p_ss = pa1[2u + h];
+            p_en = pb1[h];
+            p_dsh = pb1[2u + h];
+            p_rc = a.lines.lean_c[2*(uint64_t)q + h];
             // (the line's fp64 centre and its two broadening coefficients: one 16-byte load)
-            double2 const lx = reinterpret_cast<double2 const *>(a.lines.lean_x)[j];
-            float const yair = __int_as_float(__double2loint(lx.y)), yself = __int_as_float(__double2hiint(lx.y));
+            p_lx = reinterpret_cast<double2 const *>(a.lines.lean_x)[p_j];
+            pend_n = count;
+        }
+    };
+    // ... and its work: S(T) N_s in the lean kernel's own fp32 expressions (the same numbers: k_gas_optics_lean.hip), x and y
+    // as general_block has them, then the line's core points one per pass into the class queues.
+    [[maybe_unused]] auto process_lines = [&]()
+    {
+        if constexpr (CORE)
+        {
+            float const yair = __int_as_float(__double2loint(p_lx.y)), yself = __int_as_float(__double2hiint(p_lx.y));
+            // centre index (kernels.c:44, :431-432) in the lean kernel's fp32 expressions: the same integer (it is exact
+            // there, or the line would have been handed over)
+            float const u = fmaf(p_dsh, ll.pw, p_d0);
+            int const c = p_ci + (int)floorf(u + 0.5f);
+            unsigned bits = ((unsigned)(c - F0) < (unsigned)(F1 - F0)) ? p_bits : 0u;      // (a neighbour's line: not ours)
             // ---- S(T) N_s (kernels.c:83-85, :459), as the lean kernel has it ----
-            float const nz = rintf(en*ll.kh);
-            float const rz = fmaf(en, ll.kl, fmaf(en, ll.kh, -nz));
-            unsigned const qi = (rc >> 14) & 1023u;
-            float amp = (ss*lt->qn_m[qi])*__builtin_amdgcn_exp2f(rz);
+            float const nz = rintf(p_en*ll.kh);
+            float const rz = fmaf(p_en, ll.kl, fmaf(p_en, ll.kh, -nz));
+            unsigned const qi = (p_rc >> 14) & 1023u;
+            float amp = (p_ss*lt->qn_m[qi])*__builtin_amdgcn_exp2f(rz);
             amp = ldexpf(amp, (int)(lt->qn_e[qi] + nz));
             if (stimf & 1u)
             {
-                float const n2 = rintf(v0f*ll.kh);
-                float const r2 = fmaf(v0f, ll.kl, fmaf(v0f, ll.kh, -n2));
+                float const n2 = rintf(p_v0f*ll.kh);
+                float const r2 = fmaf(p_v0f, ll.kl, fmaf(p_v0f, ll.kh, -n2));
                 float stim = 1.f - ldexpf(__builtin_amdgcn_exp2f(r2), (int)n2);
                 if (stimf & 2u)
                 {
-                    float const x2 = v0f*ll.c2t;
+                    float const x2 = p_v0f*ll.c2t;
                     float ps = 2.50521084e-08f;
                     ps = fmaf(ps, x2, 2.75573192e-07f);
                     ps = fmaf(ps, x2, 2.75573192e-06f);
@@ -1152,10 +1192,10 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                 amp *= stim;
             }
             // ---- x and y in the reference's expressions (general_block) ----
-            double const *ms = ms_l + ((rc >> 8) & 63u)*4;
-            double const wnoadj = lx.x + (double)dsh*lay[0];                               // kernels.c:44
+            double const *ms = ms_l + ((p_rc >> 8) & 63u)*4;
+            double const wnoadj = p_lx.x + (double)p_dsh*lay[0];                           // kernels.c:44
             int const s = c - fsteps < 0 ? 0 : c - fsteps;                                 // kernels.c:435
-            double const gamma = ptab[rc & 127u]*((double)yair*ms[1] + (double)yself*ms[0]);    // kernels.c:105-106
+            double const gamma = ptab[p_rc & 127u]*((double)yair*ms[1] + (double)yself*ms[0]);  // kernels.c:105-106
             double const alpha = ((double)0.83255461115f*wnoadj)*ms[3];                    // kernels.c:127
             double const r0 = (double)__builtin_amdgcn_rcpf((float)alpha);
             float const repwid = (float)((double)kSqrln2*(r0*fma(-alpha, r0, 2.0)));       // RFM_voigt.c:94
@@ -1163,6 +1203,9 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
             double const dwno = (double)s*a.wres + a.w0;                                   // kernels.c:438
             // (RFM_voigt.c:278; the product of two fp32 numbers rounded once, as the general form's fp64 product rounded to fp32)
             float const ampq = amp*(kRsqrpi*repwid);
+#if defined(GRT_CORE_ABL) && GRT_CORE_ABL == 3      // (scan, loads and per-line preparation; no points)
+            if (ampq + y == 123.456f)
+#endif
             while (ballot_b(bits != 0u) != 0ull)
             {
                 bool const push = bits != 0u;
@@ -1173,54 +1216,41 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                 int const cls = push ? voigt_class<true, kSplit>(xr, y) : -1;
                 queue_push(cls, ampq, xr, y, (unsigned short)(f - A0));
             }
+            pend_n = 0;
         }
     };
 
-    // One step of a lean tile's walk: lane l reads the bytes of the pair of lines base + 2 l, base + 2 l + 1 (base even,
-    // counted from jal).  Handed-over lines are listed block by block (cq->xl_*) for general_block; lines with core points
-    // that this tile OWNS (centre index in [F0, F1): formed as the lean kernel forms it -- the bytes of lines of the
-    // neighbouring tiles are in the candidate range too) join the wave's list.
-    [[maybe_unused]] auto core_block = [&](unsigned const base)
+    // One step of a lean tile's scan: lane l has the bytes of the four lines at + 4 l .. + 3 (counted from jal).  Handed-over
+    // lines are listed byte position by byte position (cq->xl_*: first line, lanes) for general_block; lines with core
+    // points join the wave's list.
+    [[maybe_unused]] auto core_scan = [&](unsigned const at)
     {
         if constexpr (CORE)
         {
-            int const lo = base == 0u ? (int)lo_first : 0;
-            int const hi = nrel - base < 128u ? (int)(nrel - base) : 128;
-            bool const have[2] = {2*lane >= lo && 2*lane < hi, 2*lane + 1 < hi};
-            bool const any = have[0] | have[1];
-            unsigned const off = any ? base + 2u*(unsigned)lane : base;
-            unsigned const m16 = *reinterpret_cast<unsigned short const *>(mrow + off);
-            unsigned const mb[2] = {have[0] ? (m16 & 0xffu) : 0u, have[1] ? (m16 >> 8) : 0u};
-            if (ballot_b((mb[0] | mb[1]) != 0u) == 0ull)
+            unsigned const m = next_m;
+            scan_fetch(at + scan_stride);
+            if (ballot_b(m != 0u) == 0ull)
             {
                 return;
             }
-            unsigned long long const handed0 = ballot_b((mb[0] & kCoreExc) != 0u), handed1 = ballot_b((mb[1] & kCoreExc) != 0u);
-            if ((handed0 | handed1) != 0ull)
-            {
-                if (lane == 0)
-                {
-                    cq->xl_base[wave][xcount] = base;
-                    cq->xl_mask[wave][xcount][0] = handed0;
-                    cq->xl_mask[wave][xcount][1] = handed1;
-                }
-                ++xcount;
-            }
-            unsigned core[2] = {(mb[0] & kCoreExc) ? 0u : (mb[0] & 0x7fu), (mb[1] & kCoreExc) ? 0u : (mb[1] & 0x7fu)};
-            if (ballot_b((core[0] | core[1]) != 0u) == 0ull)
-            {
-                return;
-            }
-            // centre index (kernels.c:44, :431-432) in the lean kernel's fp32 expressions: the same integer
-            uint64_t const q0 = (jal >> 1) + (off >> 1);
-            float4 const ra0 = reinterpret_cast<float4 const *>(a.lines.lean_a)[q0];
-            float4 const rb1 = reinterpret_cast<float4 const *>(a.lines.lean_b)[a.lines.lean_npair + q0];
-            float const u0 = fmaf(rb1.z, ll.pw, ra0.x), u1 = fmaf(rb1.w, ll.pw, ra0.y);
-            int const c[2] = {__float_as_int(ra0.z) + (int)floorf(u0 + 0.5f), __float_as_int(ra0.w) + (int)floorf(u1 + 0.5f)};
+            unsigned const rel0 = at + 4u*(unsigned)lane;
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (unsigned b = 0; b < 4u; ++b)
             {
-                bool const push = (core[h] != 0u) & ((unsigned)(c[h] - F0) < (unsigned)(F1 - F0));
+                unsigned const byte = (m >> (8u*b)) & 0xffu;
+                unsigned const rel = rel0 + b;
+                bool const ok = (byte != 0u) & (rel >= lo_first) & (rel < nrel);
+                unsigned long long const handed = ballot_b(ok & ((byte & kCoreExc) != 0u));
+                if (handed != 0ull)
+                {
+                    if (lane == 0)
+                    {
+                        cq->xl_base[wave][xcount] = at + b;
+                        cq->xl_mask[wave][xcount] = handed;
+                    }
+                    ++xcount;
+                }
+                bool const push = ok & ((byte & kCoreExc) == 0u);
                 unsigned long long const mk = ballot_b(push);
                 if (mk == 0ull)
                 {
@@ -1229,98 +1259,90 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                 if (push)
                 {
                     int const pos = lcount + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-                    cq->j[wave][pos] = (unsigned)jal + off + (unsigned)h;
-                    cq->pk[wave][pos] = core[h] | ((unsigned)(c[h] - A0) << 8);
+                    cq->j[wave][pos] = (unsigned)jal + rel;
+                    cq->pk[wave][pos] = byte;
                 }
                 lcount += __popcll(mk);
-                if (lcount >= 64)
-                {
-                    lcount -= 64;
-                    drain_lines(lcount, 64);
-                }
             }
         }
     };
 
-    // The workgroup's lines.  A lean tile: its bytes, block by block, until the list of handed-over blocks is full or the
-    // range ends; then the listed blocks through general_block; and so on.  Any other tile: every block through general_block.
+    // The workgroup's lines.  A lean tile: its bytes, step by step, until 64 lines are listed (a batch: its loads go out, the
+    // batch before it is worked on), the list of handed-over lines is full, or the range ends; then the handed-over lines
+    // through general_block; and so on.  Any other tile: every block through general_block.
     uint64_t base = walk_first;
-    [[maybe_unused]] unsigned brel = lean_ok ? (unsigned)((walk_first < jend ? walk_first : jend) - jal) : 0u;
     for (;;)
     {
+        [[maybe_unused]] bool scan_done = true;
         if constexpr (CORE)
         {
             if (lean_ok)
             {
-                for (; brel < nrel && xcount < kLeanListCap; brel += walk_stride)
+                for (;;)
                 {
-                    core_block(brel);
-                }
-                if (brel >= nrel && lcount > 0)
-                {
-                    drain_lines(0, lcount);
-                    lcount = 0;
+#if defined(GRT_CORE_ABL) && (GRT_CORE_ABL == 1 || GRT_CORE_ABL == 5)      // (timing experiments only: no scan at all)
+                    sb = nrel;
+#endif
+                    while (lcount < 64 && sb < nrel && xcount + 4 <= kLeanListCap)
+                    {
+                        core_scan(sb);
+                        sb += scan_stride;
+#if defined(GRT_CORE_ABL) && GRT_CORE_ABL == 2      // (the scan alone: listed lines are dropped)
+                        lcount = 0;
+#endif
+                    }
+                    scan_done = !(sb < nrel);
+                    bool const list_full = !(xcount + 4 <= kLeanListCap);
+                    int const n = lcount >= 64 ? 64 : ((scan_done || list_full) ? lcount : 0);
+                    if (pend_n > 0)
+                    {
+                        process_lines();
+                    }
+                    if (n > 0)
+                    {
+                        lcount -= n;
+                        fetch_lines(lcount, n);
+                    }
+                    if ((scan_done || list_full) && lcount == 0 && pend_n == 0)
+                    {
+                        break;
+                    }
                 }
             }
         }
         for (int x = 0;;)
         {
             bool listed = false;
-            uint64_t bj = 0;
+            uint64_t j = 0;
+            bool hv = false;
             if constexpr (CORE)
             {
                 if (x < xcount)
                 {
+                    // (lines the lean form handed over: flagged ones, and centres too close to halfway between two grid points)
                     listed = true;
-                    bj = jal + cq->xl_base[wave][x];
+                    j = jal + cq->xl_base[wave][x] + 4u*(unsigned)lane;
+                    hv = ((cq->xl_mask[wave][x] >> lane) & 1ull) != 0ull;
+                    ++x;
                 }
             }
             if (!listed)
             {
+#if defined(GRT_CORE_ABL) && GRT_CORE_ABL == 5      // (timing experiments only: tiles the lean form does not take are skipped)
+                if (CORE) break;
+#endif
                 if (lean_ok || base >= jend)
                 {
                     break;
                 }
-                bj = base;
+                j = base + lane;
+                hv = j < jend;
                 base += walk_stride;
             }
-            for (int p = 0; p < kLinesPerLane; ++p)
-            {
-                uint64_t j;
-                bool hv;
-                if (listed)
-                {
-                    // (lines the lean form handed over: flagged ones, and centres too close to halfway between two grid points)
-                    unsigned long long mk = 0ull;
-                    if constexpr (CORE)
-                    {
-                        mk = cq->xl_mask[wave][x][p];
-                    }
-                    if (mk == 0ull)
-                    {
-                        continue;
-                    }
-                    j = bj + (uint64_t)(kLinesPerLane*lane + p);
-                    hv = ((mk >> lane) & 1ull) != 0ull;
-                }
-                else
-                {
-                    if (bj + (uint64_t)p*64 >= jend)
-                    {
-                        continue;
-                    }
-                    j = bj + (uint64_t)p*64 + lane;
-                    hv = j < jend;
-                }
-                general_block(j, hv);
-            }
-            if (listed)
-            {
-                ++x;
-            }
+            general_block(j, hv);
         }
         xcount = 0;
-        if (!lean_ok || brel >= nrel)
+        if (!lean_ok || scan_done)
         {
             break;
         }

@@ -1894,7 +1894,7 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
                    (column, layer, line) for the core-point kernel behind it (k_gas_optics_lean.hip) */
                 if (a->tree_levels == 0 && im->store.lean_a != NULL && im->store.lean_npair > 0)
                 {
-                    uint64_t const row = (2*im->store.lean_npair + 15) & ~(uint64_t)15;
+                    uint64_t const row = ((2*im->store.lean_npair + 15) & ~(uint64_t)15) + 16;    /* (the core kernel reads dwords: a few bytes past the last line) */
                     size_t const mask_need = (size_t)row*(size_t)go->num_layers*(size_t)ncol;
                     if (mask_need > im->core_mask_bytes)
                     {
