@@ -621,7 +621,7 @@ def main():
             dist.destroy_process_group()
         return
     if rank == 0:
-        ms = {tag: api.profile_read(tag) for tag in (1, 2, 3, 4, 5, 6, 7, 11, 12)}
+        ms = {tag: api.profile_read(tag) for tag in (1, 2, 3, 4, 5, 6, 7)}
         L, V = W.NUM_LEVELS - 1, W.NUM_LEVELS
         n_lw, n_sw = wl.grid_lw.n, wl.grid_sw.n
         S = wl.total_lines
@@ -710,7 +710,6 @@ def main():
                               "instructions_per_64_lines": (sq["SQ_INSTS_VALU"] / (cols_launch * L * S["sw"] / 64.0)) if sq.get("SQ_INSTS_VALU") else None,
                               "utilisation_source": traffic_src},
             "kernel_ms_per_step": {"gas_optics_lw": ms[1][0] / args.steps, "gas_optics_sw": ms[2][0] / args.steps,
-                                   "core_points_lw": ms[11][0] / args.steps, "core_points_sw": ms[12][0] / args.steps,
                                    "far_field_lw": ms[6][0] / args.steps, "far_field_sw": ms[7][0] / args.steps,
                                    "lw_solver": ms[3][0] / args.steps, "sw_solver": ms[4][0] / args.steps,
                                    "clear_sky_optics": ms[5][0] / args.steps},

@@ -144,12 +144,6 @@ typedef struct GrtGasOpticsArgs
                                  do, would otherwise be a few hundred long workgroups and thousands of short ones).  nslice is
                                  then 1 when no tile is cut and 2 when any is (moments and tau are added with atomics) */
     uint32_t n_items;
-    uint8_t *core_mask;       /* two-pass form with the lean first pass, or NULL: [ncol][L] rows of core_mask_stride bytes, one
-                                 byte per line of the store.  The lean kernel (k_gas_optics_lean.hip) writes, for every line it
-                                 owns, which of the line's seven near-field points are Humlicek core points (bits 0-6: left out
-                                 of its sums) and whether the line is not the lean form's at all (bit 7); the core kernel that
-                                 follows (k_gas_optics_mp.hip) reads them.  Scratch of one launch. */
-    uint64_t core_mask_stride;
 } GrtGasOpticsArgs;
 
 int grt_launch_gas_optics(void *stream, GrtGasOpticsArgs const *a);

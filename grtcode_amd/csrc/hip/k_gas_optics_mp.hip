@@ -27,15 +27,355 @@
 // Humlicek region 1 (XLIM1 <= |x| < XLIM0) is evaluated inside the ring whenever it lies within R (or travels
 // with the moments: near_radius); regions 2-4 go through per-wave queues, one per class of formula, and those
 // points are skipped by the ring, whose tokens are fp32 sums of at most 16 lines' values (fp64 from there on).
-#include "gas_optics_mp_dev.h"
-
-// k_gas_optics_lean.hip
-extern "C" size_t grt_lean_lds_bytes(int nacc, int ncell, int num_slots);
-extern "C" int grt_launch_gas_optics_lean(void *stream, GrtGasOpticsArgs const *b, long long fsteps, unsigned long long blocks,
-                                          unsigned long long ngroups, int ncell, int nacc, int halo);
+#include <type_traits>
+#include "gas_optics_dev.h"
 
 namespace {
 
+constexpr int kMom = 8;         // moments per cell
+#ifndef GRT_FAR_GRADED_MIN
+#define GRT_FAR_GRADED_MIN 64   // single-level gather: windows wider than this many points a side take fewer terms for far cells
+#endif
+constexpr int kMomWide = 12;    // ... of the tree form on sparse lines (args.mom_terms)
+
+// The series is geometric in |z|/r: K terms leave (|z|/r)^K.  Near field out to r = sep |z|max keeps that at 7e-8.
+__host__ __device__ inline double moment_separation(int terms)
+{
+    return terms == kMomWide ? 3.95 : 7.8;        // 3.95^-12 = 7e-8 = 7.8^-8
+}
+// LDS a workgroup of these kernels may ask for.  gfx950 would let one workgroup declare 160 KB (opt-in per kernel), but every
+// form here lives on several workgroups per CU (five of 27 KB for the 1 cm-1 first pass, four of 38 KB for the 0.001 cm-1
+// one): a form that does not fit 64 KB hands over to the next one -- single level -> cell hierarchy at windows of 200
+// points a side, eight moments in LDS -> twelve straight to global memory -- and those crossovers were MEASURED earlier than
+// the cap would force them, so the cap only guards odd hand-made tilings (tests, grt_gas_optics_tune).
+constexpr size_t kLdsPerWorkgroup = 64*1024;
+constexpr int kRcap = 12;       // widest near field taken for the sake of region 1 unless the host says otherwise (args.rcap)
+constexpr int kPowTable = 128;  // tabulated temperature exponents n = k/100 (kernels.c:105)
+constexpr int kCellLoop = 3;    // passes of the in-register moment reduction before falling back to per-lane adds
+
+// (old = 0 with bound_ctrl: every control used here -- rotations, mirrors, quad permutations -- has a source lane for every
+// lane, so the value is the same as with old = v, and in this form the compiler folds the move into the instruction that
+// uses it: one v_add_f32_dpp instead of v_mov_b32_dpp + v_add_f32)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v)
+{
+    int const b = __float_as_int(v);
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, b, CTRL, 0xf, 0xf, true));
+}
+
+// row_ror:1 (DPP control 0x121): rotation by one lane inside each row of 16 lanes
+__device__ __forceinline__ double row_pass(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x121, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x121, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+
+// Wave-wide integer max as a scalar: rotations inside the rows of 16 lanes (every lane of a row
+// ends up with the row's extreme, whatever the direction of row_ror), then the four rows on the
+// scalar unit.
+__device__ __forceinline__ int wave_max_s(int v)
+{
+    v = max(v, dpp_i<0x121>(v));
+    v = max(v, dpp_i<0x122>(v));
+    v = max(v, dpp_i<0x124>(v));
+    v = max(v, dpp_i<0x128>(v));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+// a + (a of the lane's partner under CTRL) where the lane's bit is clear, b + (b of the partner) where it is set -- the bit
+// being one that splits a row of 16 lanes into whole banks of four (8: row_mirror partner, lanes 8-15 = banks 2, 3;
+// 4: row_half_mirror partner, lanes 4-7 and 12-15 = banks 1, 3).  A DPP instruction writes only the banks its bank_mask
+// names, so two adds do what two selects and an add did.  (Inline assembly: the compiler's DPP folding takes full masks
+// only.  s_nop: a DPP operand may not be read within two wait states of its write, and the hazard recogniser does not
+// look into assembly.)
+template <int BIT>
+__device__ __forceinline__ float dpp_add_by_bit(float a, float b)
+{
+    static_assert(BIT == 8 || BIT == 4, "");
+    float w;
+    if constexpr (BIT == 8)
+    {
+        asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %0, %2, %2 row_mirror row_mask:0xf bank_mask:0xc" : "=&v"(w) : "v"(a), "v"(b));
+    }
+    else
+    {
+        asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa" : "=&v"(w) : "v"(a), "v"(b));
+    }
+    return w;
+}
+
+// Row sums of eight values per lane, transposed: on return lane l holds the sum over its row of 16
+// lanes of m[4 b3 + 2 b2 + b1] (b_i = bits of l & 15).  Three halving exchanges (partner = lane ^ 15,
+// lane ^ 7, lane ^ 3: row_mirror, row_half_mirror, reversed quad), each lane keeping the half of the
+// values its bit selects and adding the partner's copy of that half, then one exchange with lane ^ 1.
+// 14 selects + 8 DPP adds instead of 8 x 4 DPP adds.
+__device__ __forceinline__ float row_sum_transposed(float const (&m)[8], bool b3, bool b2, bool b1)
+{
+    (void)b3; (void)b2;
+    float w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+    {
+        w[i] = dpp_add_by_bit<8>(m[i], m[i + 4]);       // b3 clear: m[i] + partner's m[i]; set: m[i + 4] + partner's (row_mirror)
+    }
+    float x[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+    {
+        x[i] = dpp_add_by_bit<4>(w[i], w[i + 2]);       // likewise by b2 (row_half_mirror)
+    }
+    float const keep = b1 ? x[1] : x[0];
+    float const send = b1 ? x[0] : x[1];
+    float const y = keep + dpp_f<0x1B>(send);           // quad_perm:[3,2,1,0]
+    return y + dpp_f<0xB1>(y);                          // quad_perm:[1,0,3,2]
+}
+
+// Row sums of eight values per lane for TWO groups of lanes at once: every lane hands in its eight values and says
+// whether it belongs to group 0, group 1 or neither.  On return lane l of the row holds, for group b3 (bit 3 of l & 15),
+// the sum over the group's lanes of m[l & 7]: sixteen sums in sixteen lanes, none twice.  The first exchange
+// (partner = lane ^ 15) sends each half of the row the other group's values; the three halving exchanges of
+// row_sum_transposed follow inside the halves.  15 DPP adds + 30 selects, where two calls of row_sum_transposed take
+// 18 + 28 + 16 for the masks -- and one chain of dependent exchanges instead of two.
+__device__ __forceinline__ float row_sum_transposed_pair(float const (&m)[8], bool in0, bool in1, bool b3, bool b2, bool b1, bool b0)
+{
+    bool const keep_mine = b3 ? in1 : in0, send_mine = b3 ? in0 : in1;
+    float w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+    {
+        float const keep = keep_mine ? m[i] : 0.f;
+        float const send = send_mine ? m[i] : 0.f;
+        w[i] = keep + dpp_f<0x140>(send);               // row_mirror: the partner is in the other half
+    }
+    float x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+    {
+        float const keep = b2 ? w[i + 4] : w[i];
+        float const send = b2 ? w[i] : w[i + 4];
+        x[i] = keep + dpp_f<0x141>(send);               // row_half_mirror: lane ^ 7, other b2
+    }
+    float y[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+    {
+        float const keep = b1 ? x[i + 2] : x[i];
+        float const send = b1 ? x[i] : x[i + 2];
+        y[i] = keep + dpp_f<0x1B>(send);                // quad_perm:[3,2,1,0]: lane ^ 3, other b1
+    }
+    float const keep = b0 ? y[1] : y[0];
+    float const send = b0 ? y[0] : y[1];
+    return keep + dpp_f<0xB1>(send);                    // quad_perm:[1,0,3,2]: lane ^ 1, other b0
+}
+
+// The same for two groups whose contributions every lane holds in two arrays (the lean line loop: a lane's lines of the
+// row's first cell in g0, of the next cell in g1).  On return lane l of the row holds, for group b3, the row's sum of
+// value l & 7.
+__device__ __forceinline__ float row_sum_two_groups(float const (&g0)[8], float const (&g1)[8], bool b3, bool b2, bool b1, bool b0)
+{
+    (void)b3; (void)b2;
+    float w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+    {
+        w[i] = dpp_add_by_bit<8>(g0[i], g1[i]);         // row_mirror: the partner is in the other half
+    }
+    float x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+    {
+        x[i] = dpp_add_by_bit<4>(w[i], w[i + 4]);       // row_half_mirror
+    }
+    float y[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+    {
+        float const keep = b1 ? x[i + 2] : x[i];
+        float const send = b1 ? x[i] : x[i + 2];
+        y[i] = keep + dpp_f<0x1B>(send);                // quad_perm:[3,2,1,0]
+    }
+    float const keep = b0 ? y[1] : y[0];
+    float const send = b0 ? y[0] : y[1];
+    return keep + dpp_f<0xB1>(send);                    // quad_perm:[1,0,3,2]
+}
+
+// The lean line loop's near-centre points wait here until a wave has 64 of them (line, strength S(T) N_s, accumulator index)
+// ... and the blocks with lines the lean loop hands over to the general one are listed here (block start, lanes per p)
+constexpr int kRawCap = 128;
+constexpr int kLeanListCap = 12;
+constexpr int kLeanMaxP = 4;
+// The lean loop's per-layer tables sit at FIXED distances from one LDS address (room for kLeanSlots molecule slots, whatever
+// the object has: a launch with more slots takes the general loop), so that one address register per index serves all the
+// tables that index reads -- the distances go into the ds_read's offset field instead of a vector add per table.
+constexpr int kLeanSlots = 16;
+struct LeanTables
+{
+    float ps[kLeanSlots], p_ps[kLeanSlots], dop[kLeanSlots];          // per slot: ps | p - ps | sqrt(ln 2) x doppler factor
+    float qn_m[kLeanSlots*GRT_MAX_ISO], qn_e[kLeanSlots*GRT_MAX_ISO]; // per (slot, isotopologue): N_s/Q as mantissa | exponent
+    float ptab[kPowTable];                                            // (296/T)^(k/100)
+};
+struct LeanRaw
+{
+    unsigned long long xl_mask[kWaves][kLeanListCap][kLeanMaxP];
+    unsigned j[kWaves][kRawCap];             // the line
+    float amp[kWaves][kRawCap];              // S(T) N_s
+    float delta[kWaves][kRawCap];            // its pressure shift coefficient
+    unsigned idx[kWaves][kRawCap];           // accumulator index f - A0 | the point's k << 12 | the line's molecule slot << 16
+                                             // | the index of its temperature exponent << 22
+    unsigned xl_base[kWaves][kLeanListCap];
+};
+
+// Near-centre points (Humlicek regions 1-4 inside XLIM1) wait in per-wave LDS queues, one queue per
+// class of formula (voigt_class), so that a batch of 64 points runs ONE formula with all lanes busy:
+// evaluated unsorted, a batch pays for every formula present in it (~4x the work of the usual mix).
+// Four classes: regions 1-2 | region 4 inner sums | region 4 outer sums | region 3.  Region 3 used to share class 0: a
+// batch then ran both formulas whenever one lane wanted region 3 -- ten polynomials of y for a handful of points
+// (1 cm-1 shortwave launch 14.8 -> 14.4 ms).  Entries are 14 bytes so that four queues fit where three of 22 did.
+constexpr int kClasses = 3;
+constexpr int kClassesSplit = 4;
+// entries per (class, wave): batches of 64 leave at most 63 behind, so 64 is the least a queue can have.  At four
+// workgroups per CU 80 ... 96 measured the same (104 cost the fourth workgroup: 14.4 -> 16.6 ms); at five (see
+// gas_optics_mp_kernel_w5) the LDS they take is what decides: 64 entries.  The tree form's first pass is short of LDS
+// anyway (0.001 cm-1: four workgroups per CU instead of three, 42 -> 39 ms) and its pushes mostly come as full batches
+#ifndef GRT_MP_QUEUE
+#define GRT_MP_QUEUE 64
+#endif
+constexpr int kMpQueue = GRT_MP_QUEUE;
+constexpr int kMpQueueTree = 64;
+
+template <int CAP, int NCLS>
+struct MpQueue
+{
+    static constexpr int capacity = CAP;
+    static constexpr int classes = NCLS;
+    float amp[NCLS][kWaves][CAP];      // S(T)*N_s of the line times RSQRPI*REPWID (RFM_voigt.c:278), rounded to fp32 once
+    float xi[NCLS][kWaves][CAP];
+    float y[NCLS][kWaves][CAP];
+    unsigned short idx[NCLS][kWaves][CAP];   // accumulator index f - F0 (< 2^15); top bit: beyond the near field, where the
+                                             // moments supply the Lorentzian -- to be taken back
+};
+using MpQueueFlat = MpQueue<kMpQueue, kClassesSplit>;
+using MpQueueTree = MpQueue<kMpQueueTree, kClassesSplit>;
+
+// (a call, not inline code: the lines that need it -- exponents that are not hundredths -- are rare, and its registers
+// would count against every wave)
+__device__ __attribute__((noinline)) double exp_fp64_call(double x)
+{
+    return exp_fp64(x);
+}
+
+constexpr int binomial(int n, int k)
+{
+    int r = 1;
+    for (int i = 1; i <= k; ++i)
+    {
+        r = r*(n - k + i)/i;
+    }
+    return r;
+}
+
+// a Voigt line with a region 1 at all (RFM_voigt.c:97,122-126)
+__device__ __forceinline__ bool voigt_reg1(float y, bool lorentz)
+{
+    return !lorentz & (y > 0.000001f);
+}
+
+// Near-field radius R of a (cell tile, layer), the same for every line of the tile.
+// moment series: every line has |z| <= sqrt(1/4 + eta_max^2), eta_max from the largest half-width any
+// line of the store can have in this layer (kernels.c:105-106: per molecule, the largest air- and
+// self-broadening coefficients times this layer's partial pressures); ratio |z|/(R+1) <= 0.128 keeps the
+// 8-term remainder below 1e-7 of the far-wing value (0.253 with 12 terms: moment_separation).  If that asks
+// for more than the window, the whole window is "near" (R = fsteps) and no moments are formed.
+// ms_l: this layer's [slot][4] block in LDS.
+//
+// Humlicek region 1 (XLIM1 <= |x| < XLIM0 <= 123.4 Doppler widths) differs from the Lorentzian the moments carry,
+//     K1 - K0 = cl [ 1.5/q^2 + (1.25 - 5 Y)/q^3 + (10.5 Y^2 - 8.75 Y + 0.875)/q^4 + ... ],   q = x^2, Y = y^2
+// (RFM_voigt.c:172-183 against :103, both expanded in 1/q).  Where every line of the (tile, layer) has y <= 4 the
+// three terms are FOLDED INTO THE MOMENTS (`corrected`: with x = (r - delta) wr they are multiples of
+// (r - delta)^-4, ^-6, ^-8, expanded about the cell centre like the Lorentzian), so the near field only has to
+// reach where that series is good -- X1 = max(13, 8 y_max) Doppler widths, which also covers XLIM1 <= 12.85 --
+// instead of all of region 1.  Cost: the series goes on beyond a line's XLIM0, where the reference has switched
+// back to the Lorentzian: 1.5 cl/x^4 there, 1e-4 of the line's value at XLIM0 and falling as x^-4 -- 1e-7 of the
+// line's own peak at y = 4 (3e-8 at y = 2); against a layer maximum that is itself a wing value see kFoldWrMax.
+// Elsewhere (some line of the tile may have y > 4: low wavenumbers, high pressures) region 1 is evaluated inside
+// the ring where it lies within rcap grid steps (a performance choice: region-1 points beyond R are picked up
+// line by line in pre-pass 2; shrinking R below that was measured slower).
+// [F0l, F1l): the cells of the tile (one-pass form: including the fsteps cells either side it prepares).
+constexpr double kCorrectedYmax = 4.;
+constexpr double kEtaSevenPoints = 0.3;  // Lorentz widths up to this many grid steps keep the seven-point near field (near_radius)
+constexpr float kFoldWrMax = 25.f;      // region 1 is folded for lines within kFoldWrMax/2 Doppler widths of their grid point (see the kernel)
+__device__ int near_radius(GrtGasOpticsArgs const &a, double const *lay, double const *ms_l, long long F0l, long long F1l,
+                           int fsteps, bool *use_moments, bool *corrected, double *zmax = nullptr)
+{
+    // max over slots of yair_max (P - Ps) + yself_max Ps (Lorentz width at 296 K); of the Doppler factor; of their
+    // quotient, molecule by molecule (y = gamma/(nu dop))
+    double gmax = 0., dop = 0., gd_max = 0.;
+    for (int sl = 0; sl < a.lay.num_slots; ++sl)
+    {
+        double const g = (double)a.lines.yair_max[sl]*fabs(ms_l[sl*4 + 1]) + (double)a.lines.yself_max[sl]*fabs(ms_l[sl*4]);
+        gmax = fmax(gmax, g);
+        dop = fmax(dop, ms_l[sl*4 + 3]);
+        gd_max = fmax(gd_max, ms_l[sl*4 + 3] > 0. ? g/ms_l[sl*4 + 3] : 1e300);
+    }
+    double const tfac = exp(a.lines.nmax*fabs(lay[3]));
+    double const gamma_max = gmax*tfac;
+    double const eta = gamma_max/a.wres;
+    if (zmax != nullptr)
+    {
+        *zmax = sqrt(0.25 + eta*eta);       // every line of the layer has |z| = |delta + i eta| below this
+    }
+    int r_mp = (int)ceil(moment_separation(a.mom_terms)*sqrt(0.25 + eta*eta)) - 1;
+    // Seven points serve wider lines than the |z| bound says (round 5).  What the series leaves out is the line's
+    // A Im(z^9)/eta r^-10 and beyond, and for |delta| <= 1/2 that is LARGEST for a narrow line half-way between two grid
+    // points (9 x 0.5^8 = 0.035, against |z|^9 sin(9 theta)/eta = 0.016 at eta = 0.24): with R = 3 the worst single-line
+    // remainder is the same 6e-7 of the line's far-wing value for every eta up to 0.3 as for eta -> 0
+    // (tests/test_moment_series.py).  The bound alone had the twelve lowest layers of a 1 013 mb atmosphere at R = 4
+    // -- O2's self-broadened lines, 0.5 cm-1/atm x 0.209 -- and with that a fifth of the 1 cm-1 grids' (tile, layer)s on
+    // the general line loop at six times the lean loop's cost per line.
+    if (a.tree_levels == 0 && r_mp == 4 && eta <= kEtaSevenPoints)
+    {
+        r_mp = 3;
+    }
+    int const r_lo = r_mp < 3 ? 3 : r_mp;
+    double const w_hi = a.w0 + (double)(F1l + fsteps)*a.wres;
+    double const alpha_max = 0.83255461115*w_hi*dop;
+    double const reach = 123.4*alpha_max/(0.832554611*a.wres) + 0.51;
+    int const rcap = a.rcap > 0 ? a.rcap : kRcap;
+    int const r_reg1 = reach < (double)rcap ? (int)reach : rcap;
+    int R = r_lo > r_reg1 ? r_lo : r_reg1;
+    *corrected = false;
+    // largest y = sqrt(ln 2) gamma/alpha = gamma/(nu dop) any line of the tile can have in this layer, molecule by
+    // molecule (kernels.c:105-106,127)
+    double const w_lo = a.w0 + ((double)F0l - 1.)*a.wres;
+    double const y_num = 1.001*gd_max*tfac;
+    if (w_lo > 0. && y_num <= kCorrectedYmax*w_lo)
+    {
+        double const y_max = y_num/w_lo;
+        double const x1 = fmax(13., 8.*y_max);
+        double const reach_c = x1*alpha_max/(0.832554611*a.wres) + 1.51;
+        int const rc = reach_c < 1e9 ? (int)reach_c : 1000000000;
+        int const Rc = r_lo > rc ? r_lo : rc;
+        if (Rc + 4 <= fsteps && (Rc < R || reach >= (double)(rcap + 1)))
+        {
+            *corrected = true;
+            R = Rc;
+        }
+    }
+    *use_moments = (R + 4 <= fsteps);
+    *corrected = *corrected && *use_moments;
+    return *use_moments ? R : fsteps;
+}
 
 // ---- the cell hierarchy of the tree form (described above gas_optics_tree_kernel): sizes, offsets, the shift of
 // a child's moments to its parent's centre ----
@@ -120,7 +460,7 @@ __device__ __forceinline__ void drain_class(double *acc, Queue const *q, int wav
 // PROBE: the instrumented instance (GrtGasOpticsArgs.probe): per-workgroup clocks and event counts, for the cost
 // analysis of scripts/line_cost_by_wavenumber.py; the production instances carry none of it.
 constexpr int kProbeWords = 24;
-template <bool TWO_PASS, bool TREE, int K, bool LEAN = false, bool PROBE = false, bool CORE = false>
+template <bool TWO_PASS, bool TREE, int K, bool LEAN = false, bool PROBE = false, int LEANP = 0>
 __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long long fsteps_ll, unsigned ngroups,
                                                unsigned perm_stride, int ncell, int nacc, int halo)
 {
@@ -680,7 +1020,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                     // nothing to put through fp32 partial sums); beyond it the moments supply the
                     // Lorentzian there (to ~1e-8), to be taken back when the entry is evaluated (top bit)
                     queue_push(cls, (float)(amp*(double)(kRsqrpi*repwid)), xr, y,
-                               (unsigned short)((f - A0) | (((f >= near_lo) & (f <= near_hi)) ? 0 : 0x8000)));
+                               (unsigned short)((f - A0) | ((f >= near_lo) & (f <= near_hi) ? 0 : 0x8000)));
                 }
             }
         }
@@ -1046,305 +1386,738 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         phase_mark(4);
     };
     // ---------------------------------------------------------------------------------------------------------
-    // CORE: this launch FOLLOWS the lean first pass (k_gas_optics_lean.hip) and does what that kernel leaves: a (tile,
-    // layer, column) the lean form does not take (lean_tile_ok: near fields wider than seven points, tiles at the grid's
-    // ends) goes through general_block as in any other instance; one it does take has had all of its lines' moments and
-    // near fields done already BUT, as the lean kernel's byte per line says (GrtGasOpticsArgs.core_mask),
-    //   * the lines it cannot take (bit 7) -- they go through general_block here, whole;
-    //   * the core points of its lines (bits 0-6: |x| < XLIM1, Humlicek regions 2-4, RFM_voigt.c:174-281).  K(x, y) there
-    //     changes by 2 x^2 times a relative change of x, and region 4's sums cancel so that only the reference's own
-    //     sequence of fp32 roundings reproduces its value (gas_optics_dev.h): x AND y have to be the reference's fp32
-    //     numbers to the bit -- its fp64 expressions from the line's fp64 centre and its two broadening coefficients
-    //     (general_block's; ONE 16-byte load per line, GrtLineStore.lean_x), REPWID rounded to fp32 as the reference has it.
-    // How: the waves stream over the bytes of the tile's candidate lines (four lines per lane and step, the next step's
-    // bytes requested a step ahead); lines with core points are compacted into a per-wave list (LDS, 8 bytes a line); 64
-    // listed lines at a time have their records requested (what the exact preparation and the lean kernel's own fp32
-    // strength need: eight scattered loads, L2 hits -- every (layer, column) workgroup of the tile reads the same lines)
-    // and are worked on one batch LATER, when the loads have long landed: prepared exactly ONCE PER LINE with all lanes busy
-    // (rounds 3-4 prepared per point: 1.6 points per line at 49 000 cm-1), their points sorted into the class queues, which
-    // are evaluated in full batches of one formula each.  A listed line that turns out to belong to the neighbouring
-    // tile (the candidate ranges overlap by a cell or two; the centre index is formed as the lean kernel forms it) is dropped.
+    // The LEAN form of the line loop (LEANP > 0: that many lines per lane; first pass of the two-pass form with the
+    // single-level gather).  Round 4's measurements (scripts/valu_mix*.hip, profiles/r4_*): the general loop above is not
+    // waiting on latencies, it fills the vector pipe -- with instructions that run at half rate on this chip (everything
+    // fp64, every conversion, compare, select, DPP move, min/max/floor; 4.5 cycles per wave against 2.4 for an fp32
+    // fma/mul/add) or at a quarter (rcp, exp, sqrt: 9.5), plus a scalar instruction stream that costs issue slots of its own.
+    // So this form does the per-line work in fp32 from packed records (GrtLineStore.lean_*), keeps compares and selects
+    // out of the per-point code, reduces TWO lines per lane with one pass of DPP exchanges, and leaves to the general
+    // code only what needs its fp64:
+    //   * centre index (kernels.c:431-432, bit-exact): nearest grid point and offset of the unshifted centre come with
+    //     the record; the pressure shift (kernels.c:44) is added to the offset in fp32, and a line whose sum comes within
+    //     1e-5 of the halfway mark goes through general_block, which forms the reference's fp64 expression;
+    //   * strength S(T) N (kernels.c:83-85, :459): exponent of e^(c2 E/T) split off exactly (two-float product), strength and
+    //     1/Q N as mantissa/exponent pairs -- relative error ~2e-7, the class of the fp32 line shape it multiplies;
+    //   * the Lorentzian of every point that sees one, A/((r - delta)^2 + eta^2), needs no Doppler width at all;
+    //   * near-centre points (|x| < XLIM1: Humlicek regions 2-4) need the reference's fp64 x and its y bit for bit (see
+    //     the file header): they wait in a raw per-wave queue (line, strength, grid point) and are prepared exactly, 64
+    //     at a time with all lanes busy, then sorted into the class queues as before;
+    //   * anything unusual (no Lorentz width, exponent not tabulated, strength outside the scaled range) is flagged and goes
+    //     through general_block whole.
+    // A workgroup takes this form if its near fields are seven points wide (R = 3: near_radius); otherwise every block of
+    // lines goes through general_block as before.
     // ---------------------------------------------------------------------------------------------------------
-    auto uniform_flag = [](bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; };
+    static_assert(LEANP == 0 || LEANP == 2, "the lean loop keeps the two lines of a lane in the halves of packed registers");
+    constexpr int kLinesPerLane = LEANP > 0 ? LEANP : 1;
     [[maybe_unused]] bool lean_ok = false;
+    // (per-slot and per-isotopologue tables, one array per quantity: a line's look-up then lands in its half of a register pair)
     [[maybe_unused]] LeanTables *lt = nullptr;
-    [[maybe_unused]] CoreLines *cq = nullptr;
-    [[maybe_unused]] int lcount = 0;                // wave-uniform: lines waiting in the wave's list
-    [[maybe_unused]] int xcount = 0;                // wave-uniform: handed-over lines' list entries
-    [[maybe_unused]] LeanLayer ll = {0.f, 0.f, 0.f, 0.f, 0.f};
-    [[maybe_unused]] unsigned stimf = 0u;
-    if constexpr (CORE)
+    [[maybe_unused]] LeanRaw *raw = nullptr;
+    [[maybe_unused]] int rawcount = 0;              // wave-uniform: entries waiting in the raw queue
+    [[maybe_unused]] int xcount = 0;                // wave-uniform: blocks with lines handed over to general_block
+    // (uniform per workgroup, but kept in VECTOR registers: an fp32 multiply or fma with a scalar operand runs at half rate)
+    [[maybe_unused]] float kh = 0.f, kl = 0.f, c2t = 0.f, pw = 0.f, pavg_f = 0.f, a_norm = 0.f, wres_v = 0.f, inv_wres_v = 0.f;
+    // what the near field of this (tile, layer) is made of, from bounds on its lines' Doppler widths -- decided once per
+    // workgroup (each per-wave vote cost a compare, two scalar instructions and the expressions it tested), kept as bits of
+    // ONE scalar word (a flag as a lane mask of its own is two scalar registers, and the loop is short of those):
+    //   stim / farir the stimulated-emission factor is not 1 to fp32 / needs its series
+    //   corrected    region 1 beyond the near field is folded into the moments
+    //   lreg         only a line's own grid point can be anything but Lorentzian (half a grid step >= XLIM0 Doppler units)
+    //   v1           all seven points of every line lie in Humlicek region 1
+    //   nc_one       only a line's own grid point can be a near-centre point (|x| < XLIM1); nc_three: or its two neighbours
+    [[maybe_unused]] unsigned tflags = 0u;
+    enum : unsigned { kTfStim = 1u, kTfFarir = 2u, kTfCorrected = 4u, kTfLreg = 8u, kTfV1 = 16u, kTfNcOne = 32u, kTfNcThree = 64u };
+    auto uniform_flag = [](bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; };
+    if constexpr (LEANP > 0)
     {
         size_t const lean_off = ((size_t)(reinterpret_cast<unsigned char *>(invr + 1) - smem) + 15) & ~(size_t)15;
         lt = reinterpret_cast<LeanTables *>(smem + lean_off);
-        cq = reinterpret_cast<CoreLines *>(lt + 1);
-        lean_ok = uniform_flag(lean_tile_ok(a, use_moments, R, F0, F1, nw_i, fsteps, halo));
-#ifdef GRT_CORE_DEBUG_PRINT
-        if (!lean_ok && tid == 0 && col == 0 && slice == 0)
-        {
-            printf("NONLEAN nw %d tile %d layer %d R %d mom %d corr %d lean %d\n", nw_i, tile_idx, layer, R, (int)use_moments, (int)corrected, a.lean);
-        }
-#endif
+        raw = reinterpret_cast<LeanRaw *>(lt + 1);
+        // (round 5: the tiles at the grid's ends too.  The accumulator spans `halo` >= 8 points either side of the tile
+        // whatever the grid, points outside [0, nw) are dropped when it is flushed, a line whose centre index is off the
+        // grid belongs to no tile (kernels.c:433), and the far-field gather clips the windows as before -- the full-size
+        // parity tests pass with them; on the G1 longwave band, 51 tiles of 64 cells, the two end tiles on the general
+        // loop were 4 ms of a 30 ms launch, all of it on the two XCDs they are dealt to.)
+        lean_ok = uniform_flag(a.lean != 0 && use_moments && R == 3 && fsteps >= 8 && halo >= 8
+                               && a.lines.lean_a != nullptr);
         if (lean_ok)
         {
-            lean_fill_tables(lt, ms_l, q_l, ptab, a.lay.num_slots, tid);
+            for (int i = tid; i < a.lay.num_slots; i += kBlock)
+            {
+                // (third entry: alpha of kernels.c:127 over the line centre, divided by RFM_voigt.c:94's sqrt(ln 2) -- 1/REPWID per cm-1)
+                lt->ps[i] = (float)ms_l[4*i];
+                lt->p_ps[i] = (float)ms_l[4*i + 1];
+                lt->dop[i] = (float)(((double)0.83255461115f/(double)kSqrln2)*ms_l[4*i + 3]);
+            }
+            for (int i = tid; i < a.lay.num_slots*GRT_MAX_ISO; i += kBlock)
+            {
+                double const v = q_l[i]*ms_l[(i/GRT_MAX_ISO)*4 + 2];                 // N_s/Q(T): kernels.c:85, :459
+                int e = 0;
+                double const m = frexp(v, &e);                                      // v = m 2^e, 1/2 <= m < 1
+                bool const ok = v > 0. && v < 1e300;
+                lt->qn_m[i] = ok ? (float)(2.*m) : 0.f;
+                lt->qn_e[i] = ok ? (float)(e - 1 - GRT_LEAN_S0_SHIFT) : 0.f;
+            }
+            for (int i = tid; i < kPowTable; i += kBlock)
+            {
+                lt->ptab[i] = (float)ptab[i];
+            }
             __syncthreads();
-            ll = lean_layer(lay, inv_wres);
-            stimf = (unsigned)__builtin_amdgcn_readfirstlane((int)lean_stim_flags(a, lay, F0));
+            double const kTd = ((double)(-1.4387686f)*1.4426950408889634)*lay[2];  // c2 log2(e)/T (kernels.c:75)
+            kh = (float)kTd;
+            kl = (float)(kTd - (double)kh);
+            c2t = (float)((double)(-1.4387686f)*lay[2]);
+            pw = (float)(lay[0]*inv_wres);
+            pavg_f = (float)lay[0];
+            a_norm = (float)(1./(3.14159265358979323846*a.wres));
+            wres_v = wres_f;
+            inv_wres_v = inv_wres_f;
+#ifndef GRT_LEAN_NOPIN
+            asm volatile("" : "+v"(kh), "+v"(kl), "+v"(c2t), "+v"(pw), "+v"(pavg_f), "+v"(a_norm), "+v"(wres_v), "+v"(inv_wres_v));
+#endif
+            // stimulated emission 1 - exp(c2 v0/T) (kernels.c:84): 1 to fp32 and beyond below exp(-20); the tile's lowest
+            // wavenumber decides for the whole workgroup (sorted store, shifts of a fraction of a grid step)
+            double const x2_tile = ((double)(-1.4387686f)*lay[2])*(a.w0 + ((double)F0 - 2.)*a.wres - 1.);
+            unsigned tf = (x2_tile > -21. ? kTfStim : 0u) | (x2_tile > -1.1 ? kTfFarir : 0u) | (corrected ? kTfCorrected : 0u);
+            {
+                double dop_hi = 0., dop_lo = 1e300;
+                for (int sl = 0; sl < a.lay.num_slots; ++sl)
+                {
+                    double const d = ((double)0.83255461115f/(double)kSqrln2)*ms_l[sl*4 + 3];
+                    dop_hi = fmax(dop_hi, d);
+                    dop_lo = d > 0. ? fmin(dop_lo, d) : dop_lo;
+                }
+                // grid step in Doppler units, wr = wres REPWID = wres/(centre x doppler factor), over the tile's lines (one cell
+                // and the largest shift of margin either side)
+                double const nu_lo = fmax(a.w0 + ((double)F0 - 1.5)*a.wres - a.lines.dmax*fabs(lay[0]), 1e-3);
+                double const nu_hi = a.w0 + ((double)F1 + 0.5)*a.wres + a.lines.dmax*fabs(lay[0]);
+                double const wr_min = dop_hi > 0. ? a.wres/(nu_hi*dop_hi) : 0.;
+                double const wr_max = dop_lo < 1e300 ? a.wres/(nu_lo*dop_lo) : 1e300;
+                // XLIM0^2 = 15100 + y (40 - 3.6 y) <= 15211.2 (y = 5.56), >= 15100 for y <= 4; XLIM1^2 <= 164 (RFM_voigt.c:109-118)
+                tf |= (0.25*wr_min*wr_min >= 1.003*15211.2 ? kTfLreg : 0u) | ((corrected && 12.25*wr_max*wr_max < 0.999*15100.) ? kTfV1 : 0u)
+                      | (0.25*wr_min*wr_min >= 164.1 ? kTfNcOne : 0u) | (2.25*wr_min*wr_min >= 164.1 ? kTfNcThree : 0u);
+            }
+            tflags = (unsigned)__builtin_amdgcn_readfirstlane((int)tf);
         }
     }
 
-    uint64_t const walk_first = line_walk_first(a, jbeg, jend, wave);
-    unsigned const walk_stride = line_walk_stride(a);
-    // (a lean tile's bytes are read four lines per lane from a four-aligned start; counted from there, in 32 bits -- the
-    // store has fewer than 2^32 lines where the lean form runs)
-    [[maybe_unused]] uint64_t const jal = jbeg & ~(uint64_t)3;
-    [[maybe_unused]] unsigned const nrel = (unsigned)(jend - jal);          // the range ends at jal + nrel
-    [[maybe_unused]] unsigned const lo_first = (unsigned)(jbeg - jal);      // 0 .. 3: the range begins here
-    [[maybe_unused]] unsigned const scan_stride = a.deterministic ? 256u : (unsigned)kBlock*4u;
-    [[maybe_unused]] unsigned sb = a.deterministic ? (wave == 0 ? 0u : 0xfffffff0u) : (unsigned)wave*256u;      // the wave's next scan step
-    [[maybe_unused]] uint8_t const *mrow = nullptr;
-    [[maybe_unused]] unsigned next_m = 0u;
-    [[maybe_unused]] auto scan_fetch = [&](unsigned const at)
-    {
-        unsigned const off = at + 4u*(unsigned)lane;
-        next_m = (at < nrel && off < nrel) ? *reinterpret_cast<unsigned const *>(mrow + off) : 0u;
-    };
-    if constexpr (CORE)
-    {
-        if (lean_ok)
-        {
-            mrow = a.core_mask + ((uint64_t)col*a.lay.num_layers + layer)*a.core_mask_stride + jal;
-            scan_fetch(sb);
-        }
-    }
+    // (lean blocks start on even line indices -- a pair of the packed records; a line before jbeg in the first block is masked)
+    uint64_t const jal = lean_ok ? (jbeg & ~(uint64_t)1) : jbeg;
+    uint64_t const walk_first = a.deterministic ? (wave == 0 ? jal : jend) : jal + (uint64_t)wave*64*kLinesPerLane;
+    unsigned const walk_stride = (a.deterministic ? 64u : (unsigned)kBlock)*kLinesPerLane;
 
-    // A batch of listed lines, one per lane: the loads of what its preparation needs (issued when the batch is taken off
-    // the list, used one batch later)
-    [[maybe_unused]] int pend_n = 0;                // wave-uniform: lines of the batch in flight (0: none)
-    [[maybe_unused]] unsigned p_j = 0u, p_bits = 0u, p_rc = 0u;
-    [[maybe_unused]] float p_d0 = 0.f, p_v0f = 0.f, p_ss = 0.f, p_en = 0.f, p_dsh = 0.f;
-    [[maybe_unused]] int p_ci = 0;
-    [[maybe_unused]] double2 p_lx = make_double2(0., 0.);
-    [[maybe_unused]] auto fetch_lines = [&](int const first, int const count)
+    // The raw queue's entries -- core points (|x| < XLIM1: Humlicek regions 2-4) -- get the reference's x and y, 64 at a time
+    // with all lanes busy, and are sorted into the class queues.  K(x, y) there changes by 2 x^2 times a relative change of
+    // x, and region 4's sums cancel so that only the reference's own sequence of fp32 roundings reproduces its value
+    // (gas_optics_dev.h): x AND y have to be the reference's fp32 numbers to the bit -- its fp64 expressions from the line's
+    // fp64 centre and its two broadening coefficients (general_block's; ONE 16-byte load per point, GrtLineStore.lean_x:
+    // everything else the entry brings along or LDS holds), REPWID rounded to fp32 as the reference has it.  (The loop's own fp32 y, 1e-7 off, made
+    // the shortwave launch 3 % shorter and three of 600 soak cases 2e-6 to 4e-6 wrong.)
+    [[maybe_unused]] auto drain_raw = [&](int const first, int const count)
     {
-        if constexpr (CORE)
+        if constexpr (LEANP > 0)
         {
             bool const on = lane < count;
             int const i = first + (on ? lane : 0);
-            p_j = cq->j[wave][i];
-            p_bits = on ? (cq->pk[wave][i] & 0x7fu) : 0u;
-            unsigned const q = p_j >> 1, h = p_j & 1u;
-            float const *pa0 = a.lines.lean_a + 4*(uint64_t)q;
-            float const *pa1 = a.lines.lean_a + 4*((uint64_t)a.lines.lean_npair + q);
-            float const *pb1 = a.lines.lean_b + 4*((uint64_t)a.lines.lean_npair + q);
-            p_d0 = pa0[h];
-            p_ci = __float_as_int(pa0[2u + h]);
-            p_v0f = pa1[h];
-            p_ss = pa1[2u + h];
-            p_en = pb1[h];
-            p_dsh = pb1[2u + h];
-            p_rc = a.lines.lean_c[2*(uint64_t)q + h];
+            unsigned const packed = raw->idx[wave][i];
+            unsigned const j = raw->j[wave][i];
+            int const idx = (int)(packed & 4095u);                                      // f - A0
+            // the centre index is the lean loop's (it is exact there, or the line would not be here): the point is its
+            // grid point c + k - 3
+            int const c = idx + A0 - ((int)((packed >> 12) & 15u) - 3);
             // (the line's fp64 centre and its two broadening coefficients: one 16-byte load)
-            p_lx = reinterpret_cast<double2 const *>(a.lines.lean_x)[p_j];
-            pend_n = count;
-        }
-    };
-    // ... and its work: S(T) N_s in the lean kernel's own fp32 expressions (the same numbers: k_gas_optics_lean.hip), x and y
-    // as general_block has them, then the line's core points one per pass into the class queues.
-    [[maybe_unused]] auto process_lines = [&]()
-    {
-        if constexpr (CORE)
-        {
-            float const yair = __int_as_float(__double2loint(p_lx.y)), yself = __int_as_float(__double2hiint(p_lx.y));
-            // centre index (kernels.c:44, :431-432) in the lean kernel's fp32 expressions: the same integer (it is exact
-            // there, or the line would have been handed over)
-            float const u = fmaf(p_dsh, ll.pw, p_d0);
-            int const c = p_ci + (int)floorf(u + 0.5f);
-            unsigned bits = ((unsigned)(c - F0) < (unsigned)(F1 - F0)) ? p_bits : 0u;      // (a neighbour's line: not ours)
-            // ---- S(T) N_s (kernels.c:83-85, :459), as the lean kernel has it ----
-            float const nz = rintf(p_en*ll.kh);
-            float const rz = fmaf(p_en, ll.kl, fmaf(p_en, ll.kh, -nz));
-            unsigned const qi = (p_rc >> 14) & 1023u;
-            float amp = (p_ss*lt->qn_m[qi])*__builtin_amdgcn_exp2f(rz);
-            amp = ldexpf(amp, (int)(lt->qn_e[qi] + nz));
-            if (stimf & 1u)
-            {
-                float const n2 = rintf(p_v0f*ll.kh);
-                float const r2 = fmaf(p_v0f, ll.kl, fmaf(p_v0f, ll.kh, -n2));
-                float stim = 1.f - ldexpf(__builtin_amdgcn_exp2f(r2), (int)n2);
-                if (stimf & 2u)
-                {
-                    float const x2 = p_v0f*ll.c2t;
-                    float ps = 2.50521084e-08f;
-                    ps = fmaf(ps, x2, 2.75573192e-07f);
-                    ps = fmaf(ps, x2, 2.75573192e-06f);
-                    ps = fmaf(ps, x2, 2.48015873e-05f);
-                    ps = fmaf(ps, x2, 1.98412698e-04f);
-                    ps = fmaf(ps, x2, 1.38888889e-03f);
-                    ps = fmaf(ps, x2, 8.33333333e-03f);
-                    ps = fmaf(ps, x2, 4.16666667e-02f);
-                    ps = fmaf(ps, x2, 1.66666667e-01f);
-                    ps = fmaf(ps, x2, 0.5f);
-                    ps = fmaf(ps, x2, 1.0f);
-                    stim = x2 > -1.f ? (-x2)*ps : stim;
-                }
-                amp *= stim;
-            }
-            // ---- x and y in the reference's expressions (general_block) ----
-            double const *ms = ms_l + ((p_rc >> 8) & 63u)*4;
-            double const wnoadj = p_lx.x + (double)p_dsh*lay[0];                           // kernels.c:44
-            int const s = c - fsteps < 0 ? 0 : c - fsteps;                                 // kernels.c:435
-            double const gamma = ptab[p_rc & 127u]*((double)yair*ms[1] + (double)yself*ms[0]);  // kernels.c:105-106
-            double const alpha = ((double)0.83255461115f*wnoadj)*ms[3];                    // kernels.c:127
+            double2 const lx = reinterpret_cast<double2 const *>(a.lines.lean_x)[j];
+            float const yair = __int_as_float(__double2loint(lx.y)), yself = __int_as_float(__double2hiint(lx.y));
+            double const *ms = ms_l + ((packed >> 16) & 63u)*4;
+            double const wnoadj = lx.x + (double)raw->delta[wave][i]*lay[0];           // kernels.c:44
+            int const s = c - fsteps < 0 ? 0 : c - fsteps;                             // kernels.c:435
+            double const gamma = ptab[(packed >> 22) & 127u]*((double)yair*ms[1] + (double)yself*ms[0]);    // kernels.c:105-106
+            double const alpha = ((double)0.83255461115f*wnoadj)*ms[3];                // kernels.c:127
             double const r0 = (double)__builtin_amdgcn_rcpf((float)alpha);
-            float const repwid = (float)((double)kSqrln2*(r0*fma(-alpha, r0, 2.0)));       // RFM_voigt.c:94
-            float const y = (float)((double)repwid*gamma);                                 // RFM_voigt.c:95
-            double const dwno = (double)s*a.wres + a.w0;                                   // kernels.c:438
+            float const repwid = (float)((double)kSqrln2*(r0*fma(-alpha, r0, 2.0)));   // RFM_voigt.c:94
+            float const y = (float)((double)repwid*gamma);                             // RFM_voigt.c:95
+            double const dwno = (double)s*a.wres + a.w0;                               // kernels.c:438
+            float const xr = voigt_x(dwno, idx + A0 - s, a.wres, wnoadj, repwid);      // the reference's x
+            int const cls = on ? voigt_class<true, kSplit>(xr, y) : -1;
             // (RFM_voigt.c:278; the product of two fp32 numbers rounded once, as the general form's fp64 product rounded to fp32)
-            float const ampq = amp*(kRsqrpi*repwid);
-#if defined(GRT_CORE_ABL) && GRT_CORE_ABL == 3      // (scan, loads and per-line preparation; no points)
-            if (ampq + y == 123.456f)
-#endif
-            while (ballot_b(bits != 0u) != 0ull)
-            {
-                bool const push = bits != 0u;
-                int const k = push ? __builtin_ctz(bits) : 3;
-                bits &= bits - 1u;
-                int const f = c - 3 + k;
-                float const xr = voigt_x(dwno, f - s, a.wres, wnoadj, repwid);             // the reference's x
-                int const cls = push ? voigt_class<true, kSplit>(xr, y) : -1;
-                queue_push(cls, ampq, xr, y, (unsigned short)(f - A0));
-            }
-            pend_n = 0;
+            queue_push(cls, raw->amp[wave][i]*(kRsqrpi*repwid), xr, y, (unsigned short)idx);
         }
     };
 
-    // One step of a lean tile's scan: lane l has the bytes of the four lines at + 4 l .. + 3 (counted from jal).  Handed-over
-    // lines are listed byte position by byte position (cq->xl_*: first line, lanes) for general_block; lines with core
-    // points join the wave's list.
-    [[maybe_unused]] auto core_scan = [&](unsigned const at)
+    // The packed records of the pair of lines b + 2 lane, b + 2 lane + 1 (b even; past the end of the workgroup's range:
+    // its last pair) -- requested one block ahead of their use.
+    [[maybe_unused]] float4 next_a0 = make_float4(0.f, 0.f, 0.f, 0.f), next_a1 = next_a0, next_b0 = next_a0, next_b1 = next_a0;
+    [[maybe_unused]] uint2 next_c = make_uint2(0u, 0u);
+    // (the lean loop counts its lines from jal, in 32 bits -- the store has fewer than 2^32 lines where this loop runs: its
+    // range tests are scalar compares then; 64-bit ones are vector instructions on this chip)
+    [[maybe_unused]] unsigned const nrel = (unsigned)(jend - jal);          // the range ends at jal + nrel
+    [[maybe_unused]] unsigned const lo_first = (unsigned)(jbeg - jal);      // 0, or 1: the range begins on an odd index
+    [[maybe_unused]] auto lean_fetch = [&](unsigned const b)
     {
-        if constexpr (CORE)
+        if constexpr (LEANP > 0)
         {
-            unsigned const m = next_m;
-            scan_fetch(at + scan_stride);
-            if (ballot_b(m != 0u) == 0ull)
+            unsigned const qlast = (nrel - 1u) >> 1;
+            unsigned const qb = b < nrel ? (b >> 1) : qlast;
+            unsigned const room = qlast - qb;
+            unsigned const off = (unsigned)lane < room ? (unsigned)lane : room;
+            // (byte offsets in 32 bits: scalar base + vector offset addressing instead of 64-bit vector address arithmetic)
+            uint64_t const q0 = (jal >> 1) + qb;
+            float4 const *pa = reinterpret_cast<float4 const *>(a.lines.lean_a) + q0;
+            float4 const *pb = reinterpret_cast<float4 const *>(a.lines.lean_b) + q0;
+            uint2 const *pc = reinterpret_cast<uint2 const *>(a.lines.lean_c) + q0;
+            next_a0 = *reinterpret_cast<float4 const *>(reinterpret_cast<char const *>(pa) + (off << 4));
+            next_a1 = *reinterpret_cast<float4 const *>(reinterpret_cast<char const *>(pa + a.lines.lean_npair) + (off << 4));
+            next_b0 = *reinterpret_cast<float4 const *>(reinterpret_cast<char const *>(pb) + (off << 4));
+            next_b1 = *reinterpret_cast<float4 const *>(reinterpret_cast<char const *>(pb + a.lines.lean_npair) + (off << 4));
+            next_c = *reinterpret_cast<uint2 const *>(reinterpret_cast<char const *>(pc) + (off << 3));
+        }
+    };
+
+    // One lean block: lane l takes the pair of lines base + 2 l (half 0 of every packed value below) and base + 2 l + 1
+    // (half 1); base is even.  What depends on one line only and has a packed instruction -- fp32 multiply, add, fma -- is
+    // done for both lines at once; compares, selects, conversions, transcendentals and table look-ups come per half.  The
+    // operations and their order are those of a line on its own, so the halves hold what two passes over single lines
+    // would.  Lines that have to go through general_block instead are recorded, block by block, in the wave's list
+    // (raw->xl_*).
+    [[maybe_unused]] auto lean_block = [&](unsigned const base)      // (base: counted from jal)
+    {
+        if constexpr (LEANP > 0)
+        {
+            // lines of this block: base + lo .. base + hi - 1 (lo = 1: the workgroup's range begins on an odd index)
+            int const lo = base == 0u ? (int)lo_first : 0;
+            int const hi = nrel - base < 128u ? (int)(nrel - base) : 128;
+            float4 const ra0 = next_a0, ra1 = next_a1, rb0 = next_b0, rb1 = next_b1;
+            uint2 const rcc = next_c;
+            lean_fetch(base + walk_stride);
+            // (the tile's flags, tested where they are used: hoisted out of the loop, each test became a lane mask in two
+            // scalar registers, spilled to a vector register's lanes and read back with v_readlane at every use)
+            unsigned tfl = tflags;
+            asm volatile("" : "+s"(tfl));
+            bool const have[2] = {2*lane >= lo && 2*lane < hi, 2*lane + 1 < hi};
+            unsigned const rc[2] = {rcc.x, rcc.y};
+            v2f const d0 = {ra0.x, ra0.y};
+            int const ci[2] = {__float_as_int(ra0.z), __float_as_int(ra0.w)};
+            v2f const v0f = {ra1.x, ra1.y};
+            v2f const ss = {ra1.z, ra1.w};
+            v2f const yair = {rb0.x, rb0.y}, yself = {rb0.z, rb0.w}, en = {rb1.x, rb1.y}, dsh = {rb1.z, rb1.w};
+            v2f const kh2 = splat2(kh), kl2 = splat2(kl), inv_wres2 = splat2(inv_wres_v);
+            // ---- centre index and offset (kernels.c:44, :431-432) ----
+            v2f const u = pk_fma(dsh, splat2(pw), d0);
+            v2f const t = u + 0.5f;
+            v2f const kf = {floorf(t.x), floorf(t.y)};
+            v2f const dl = u - kf;                              // offset of the shifted centre from grid point c, [-1/2, 1/2)
+            v2f const gd = (t - kf) - 0.5f;
+            int const c[2] = {ci[0] + (int)kf.x, ci[1] + (int)kf.y};
+            bool const guard[2] = {fabsf(gd.x) > 0.49999f, fabsf(gd.y) > 0.49999f};
+            bool const in_tile[2] = {(unsigned)(c[0] - F0) < (unsigned)(F1 - F0), (unsigned)(c[1] - F0) < (unsigned)(F1 - F0)};
+            v2f const wn = pk_fma(dsh, splat2(pavg_f), v0f);    // shifted centre [cm-1]
+            // ---- S(T) N_s (kernels.c:83-85, :459) ----
+            v2f const nz = rint2(en*kh2);
+            v2f const rz = pk_fma(en, kl2, pk_fma(en, kh2, -nz));       // en c2 log2(e)/T - nz, to ~1e-8
+            unsigned const qi[2] = {(rc[0] >> 14) & 1023u, (rc[1] >> 14) & 1023u};
+            v2f amp = (ss*(v2f){lt->qn_m[qi[0]], lt->qn_m[qi[1]]})*exp2_2(rz);
             {
-                return;
+                v2f const ex = (v2f){lt->qn_e[qi[0]], lt->qn_e[qi[1]]} + nz;
+                amp = (v2f){ldexpf(amp.x, (int)ex.x), ldexpf(amp.y, (int)ex.y)};
             }
-            unsigned const rel0 = at + 4u*(unsigned)lane;
-#pragma unroll
-            for (unsigned b = 0; b < 4u; ++b)
+            if (tfl & kTfStim)
             {
-                unsigned const byte = (m >> (8u*b)) & 0xffu;
-                unsigned const rel = rel0 + b;
-                bool const ok = (byte != 0u) & (rel >= lo_first) & (rel < nrel);
-                unsigned long long const handed = ballot_b(ok & ((byte & kCoreExc) != 0u));
-                if (handed != 0ull)
+                // (kernels.c:84 with the UNSHIFTED centre: launch.c:119 hands calc_line_strengths the line list's v0)
+                v2f const n2 = rint2(v0f*kh2);
+                v2f const r2 = pk_fma(v0f, kl2, pk_fma(v0f, kh2, -n2));
+                v2f const e2 = exp2_2(r2);
+                v2f stim = 1.f - (v2f){ldexpf(e2.x, (int)n2.x), ldexpf(e2.y, (int)n2.y)};
+                if (tfl & kTfFarir)
+                {
+                    // nu < ~0.7 T: 1 - e^x cancels; -expm1(x) by its series on [-1, 0] (eleven terms: 2e-9)
+                    v2f const x2 = v0f*splat2(c2t);
+                    v2f ps = splat2(2.50521084e-08f);                           // 1/11!
+                    ps = pk_fma(ps, x2, splat2(2.75573192e-07f));
+                    ps = pk_fma(ps, x2, splat2(2.75573192e-06f));
+                    ps = pk_fma(ps, x2, splat2(2.48015873e-05f));
+                    ps = pk_fma(ps, x2, splat2(1.98412698e-04f));
+                    ps = pk_fma(ps, x2, splat2(1.38888889e-03f));
+                    ps = pk_fma(ps, x2, splat2(8.33333333e-03f));
+                    ps = pk_fma(ps, x2, splat2(4.16666667e-02f));
+                    ps = pk_fma(ps, x2, splat2(1.66666667e-01f));
+                    ps = pk_fma(ps, x2, splat2(0.5f));
+                    ps = pk_fma(ps, x2, splat2(1.0f));
+                    stim = sel2(x2.x > -1.f, x2.y > -1.f, (-x2)*ps, stim);
+                }
+                amp *= stim;
+            }
+            // ---- widths (kernels.c:105-106, :127; RFM_voigt.c:94-95) ----
+            unsigned const si[2] = {(rc[0] >> 8) & 63u, (rc[1] >> 8) & 63u};
+            v2f const ptv = {lt->ptab[rc[0] & 127u], lt->ptab[rc[1] & 127u]};
+            v2f const gam = ptv*pk_fma(yair, (v2f){lt->p_ps[si[0]], lt->p_ps[si[1]]}, yself*(v2f){lt->ps[si[0]], lt->ps[si[1]]});
+            v2f const ad = wn*(v2f){lt->dop[si[0]], lt->dop[si[1]]};                              // alpha/sqrt(ln 2) (kernels.c:127, RFM_voigt.c:94)
+            v2f const r0 = rcp2(ad);
+            v2f const rep = pk_fma(pk_fma(-ad, r0, splat2(1.f)), r0, r0);       // REPWID (one Newton step: the far wings scale with it)
+            v2f y = rep*gam;
+            // (flagged by the loader: strength zeroed; RFM_voigt.c:122-126: no Lorentz width -- all of that is general_block's)
+            bool const exc[2] = {bool(!(ss.x > 0.f) | guard[0] | !(y.x > 0.000001f)), bool(!(ss.y > 0.f) | guard[1] | !(y.y > 0.000001f))};
+            bool const valid[2] = {bool(have[0] & in_tile[0] & !exc[0]), bool(have[1] & in_tile[1] & !exc[1])};
+            {
+                unsigned long long const handed0 = ballot_b(have[0] & exc[0]), handed1 = ballot_b(have[1] & exc[1]);
+                if ((handed0 | handed1) != 0ull)
                 {
                     if (lane == 0)
                     {
-                        cq->xl_base[wave][xcount] = at + b;
-                        cq->xl_mask[wave][xcount] = handed;
+                        raw->xl_base[wave][xcount] = base;
+                        raw->xl_mask[wave][xcount][0] = handed0;
+                        raw->xl_mask[wave][xcount][1] = handed1;
                     }
                     ++xcount;
                 }
-                bool const push = ok & ((byte & kCoreExc) == 0u);
+            }
+            // a lane without a line of its own here works on a harmless one (no infinities: 0 x inf would poison the sums)
+            amp = sel2(valid[0], valid[1], amp, splat2(0.f));
+            y = sel2(valid[0], valid[1], y, splat2(1.f));
+            v2f const eta = sel2(valid[0], valid[1], gam*inv_wres2, splat2(1.f));
+            v2f const eta2 = eta*eta;
+            v2f const wr = splat2(wres_v)*rep;
+            // ---- which cell of its row: cr or cr + 1; anything else (sparse lines) is added lane by lane ----
+            // (cr: the row's reference cell -- its lines sit in cells cr, cr + 1: sorted store)
+            int cr;
+            {
+                int const c_first = dpp_i<0x150>(c[0]);                             // row_newbcast:0 -- the row's first lane
+                cr = c_first < F0 ? F0 : (c_first > F1 - 1 ? F1 - 1 : c_first);
+            }
+            // (a lane without a valid line has amp = 0 and adds nothing wherever it is put: it is put in cell cr, and from here
+            // on nothing asks about validity -- its XLIM0 and XLIM1 below are zero, so it has no region 1 and no core point)
+            int const o[2] = {valid[0] ? c[0] - cr : 0, valid[1] ? c[1] - cr : 0};
+            bool const odd[2] = {(unsigned)o[0] > 1u, (unsigned)o[1] > 1u};
+            // (the longwave band's usual case, 308 lines per cell: no second cell, no weights; the shortwave instance, 30
+            // lines per cell, does not ask)
+            bool const single = LEAN && ballot_b((o[0] | o[1]) != 0) == 0ull;
+            v2f const W0 = {o[0] == 0 ? 1.f : 0.f, o[1] == 0 ? 1.f : 0.f};
+            v2f const W1 = {o[0] == 1 ? 1.f : 0.f, o[1] == 1 ? 1.f : 0.f};
+            // ---- moments of the Lorentzian about the cell centre (see general_block) ----
+            v2f const A = (amp*eta)*splat2(a_norm);                             // K(r) = A/((r - dl)^2 + eta^2)
+            v2f m[kMom];
+#ifdef GRT_ABL_NOMOM     // (timing experiments only, scripts/lean_ablation.sh: results are wrong by construction)
+            for (int k = 0; k < kMom; ++k) m[k] = splat2(0.f);
+#else
+            {
+                v2f uu = A, pk = splat2(0.f);
+#pragma unroll
+                for (int k = 0; k < kMom; ++k)
+                {
+                    v2f const un = pk_fma(dl, uu, (-eta2)*pk);
+                    pk = pk_fma(dl, pk, uu);
+                    uu = un;
+                    m[k] = pk;
+                }
+            }
+#endif
+            // Voigt constants (RFM_voigt.c:97-126, :177-179); a pure Lorentz line (y >= 70.55) has no region 1
+            v2f const yq = y*y;
+            v2f const x0q = sel2(!valid[0] | (y.x >= 70.55f), !valid[1] | (y.y >= 70.55f), splat2(0.f), pk_fma(y, pk_fma(y, splat2(-3.6f), splat2(40.0f)), splat2(15100.0f)));   // XLIM0^2
+            v2f const xq_near = sel2(!valid[0] | (y.x >= 8.425f), !valid[1] | (y.y >= 8.425f), splat2(0.f), 164.0f - y*pk_fma(y, splat2(1.8f), splat2(4.3f)));              // XLIM1^2
+            v2f const a0 = yq + 0.5f;
+            v2f const d0r = a0*a0;
+            v2f const d2r = (yq + yq) - 1.0f;
+            v2f const cl = (rep*y)*0.318309886f;
+            v2f const adl = {fabsf(dl.x), fabsf(dl.y)};
+            v2f const ndcr = (-dl)*wr;                          // x of the line's own grid point
+            bool pre2[2] = {false, false};
+            if (tfl & kTfCorrected)
+            {
+                // region 1 beyond the near field: folded into the moments, or (pre-pass 2 of general_block) point by point
+                v2f const e4 = (4.f - adl)*wr;
+                v2f const e4q = e4*e4, aw = adl*wr;
+                bool const reg1_far[2] = {e4q.x < x0q.x, e4q.y < x0q.y};
+                bool const fold[2] = {bool(reg1_far[0] & (aw.x <= 0.5f*kFoldWrMax)), bool(reg1_far[1] & (aw.y <= 0.5f*kFoldWrMax))};
+                pre2[0] = reg1_far[0] & !fold[0];
+                pre2[1] = reg1_far[1] & !fold[1];
+                // (below ~15 000 cm-1 region 1 ends inside the near field: no line of the wave has anything to fold)
+                if (ballot_b(fold[0] | fold[1]) != 0ull)
+                {
+                    v2f const rwr = ad*inv_wres2;                                   // 1/wr
+                    v2f const rw2 = rwr*rwr;
+                    v2f const t4 = sel2(fold[0], fold[1], A*rw2, splat2(0.f));
+                    v2f const t6 = t4*rw2;
+                    v2f d4 = 1.5f*t4;
+                    v2f d6 = pk_fma(splat2(-5.f), yq, splat2(1.25f))*t6;
+                    v2f d8 = pk_fma(yq, pk_fma(splat2(10.5f), yq, splat2(-8.75f)), splat2(0.875f))*(t6*rw2);
+#pragma unroll
+                    for (int i = 2; i < kMom; ++i)
+                    {
+                        m[i] = pk_fma(splat2((float)binomial(i + 1, 3)), d4, m[i]);
+                        d4 *= dl;
+                        if (i >= 4)
+                        {
+                            m[i] = pk_fma(splat2((float)binomial(i + 1, 5)), d6, m[i]);
+                            d6 *= dl;
+                        }
+                        if (i >= 6)
+                        {
+                            m[i] = pk_fma(splat2((float)binomial(i + 1, 7)), d8, m[i]);
+                            d8 *= dl;
+                        }
+                    }
+                }
+            }
+            // ---- the row's moment sums: eight per cell end in sixteen lanes (one cell: in eight) ----
+#ifdef GRT_ABL_NOREDUCE
+            if (hi < 0)
+#else
+            if (single)
+#endif
+            {
+                float g0[kMom];
+#pragma unroll
+                for (int k = 0; k < kMom; ++k)
+                {
+                    g0[k] = m[k].x + m[k].y;        // (a lane without a valid line has A = 0: nothing)
+                }
+                float tsum = row_sum_transposed(g0, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0);       // value (lane >> 1) & 7, twice
+                tsum = (lane & 1) == 0 ? tsum : 0.f;
+#ifdef GRT_ABL_NOLDSADD
+                if ((tsum == 123.456f) & (cr < F1))
+#else
+                if ((tsum != 0.f) & (cr < F1))
+#endif
+                {
+                    mom_add((lane >> 1) & 7, cr, tsum);
+                }
+            }
+#ifdef GRT_ABL_NOREDUCE
+            else if (hi < 0)
+#else
+            else
+#endif
+            {
+                float g0[kMom], g1[kMom];
+#pragma unroll
+                for (int k = 0; k < kMom; ++k)
+                {
+                    v2f const t0 = W0*m[k], t1 = W1*m[k];
+                    g0[k] = t0.x + t0.y;
+                    g1[k] = t1.x + t1.y;
+                }
+                float const tsum = row_sum_two_groups(g0, g1, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0, (lane & 1) != 0);
+                int const cell = cr + ((lane >> 3) & 1);
+#ifdef GRT_ABL_NOLDSADD
+                if ((tsum == 123.456f) & (cell < F1))
+#else
+                if ((tsum != 0.f) & (cell < F1))
+#endif
+                {
+                    mom_add(lane & 7, cell, tsum);
+                }
+            }
+            bool const any_odd = (!single || (tfl & kTfCorrected) != 0u) && ballot_b(odd[0] | odd[1] | pre2[0] | pre2[1]) != 0ull;
+            // (rare: a line in neither of its row's cells adds lane by lane)
+            if (any_odd)
+            {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                {
+                    if (odd[h])
+                    {
+#pragma unroll
+                        for (int k = 0; k < kMom; ++k)
+                        {
+                            mom_add(k, c[h], m[k][h]);
+                        }
+                    }
+                }
+            }
+            // ---- near field: the lines' seven points r = -3 .. 3 (v[r + 3]; x = r wr + ndcr, the general form's canonical
+            // x), by what the wave's lines have there: only Lorentzians but for a line's own point | region 1 throughout
+            // | the point's region picks the formula.  Near-centre points (|x| < XLIM1) are left out and noted in ncm. ----
+            v2f v[7];
+            unsigned ncm[2] = {0u, 0u};
+#ifdef GRT_ABL_NOSLOTS
+            for (int k = 0; k < 7; ++k) v[k] = splat2(0.f);
+            if (hi < 0)
+#else
+            if (tfl & kTfLreg)
+#endif
+            {
+                // every point but the line's own: the Lorentzian, A/(rel^2 + eta^2) (RFM_voigt.c:103,170,278)
+#pragma unroll
+                for (int k = 0; k < 7; ++k)
+                {
+                    if (k != 3)
+                    {
+                        v2f const rel = (float)(k - 3) - dl;
+                        v[k] = A*rcp2(pk_fma(rel, rel, eta2));
+                    }
+                }
+                // the line's own grid point: region 1, the Lorentzian, or a near-centre point (the queues')
+                v2f const xq0 = ndcr*ndcr;
+                bool const nc[2] = {xq0.x < xq_near.x, xq0.y < xq_near.y};
+                bool const reg1[2] = {xq0.x < x0q.x, xq0.y < x0q.y};
+                v2f const den = sel2(reg1[0], reg1[1], pk_fma(xq0, d2r + xq0, d0r), xq0 + yq);
+                v2f const num = sel2(reg1[0], reg1[1], cl*(a0 + xq0), cl);
+                v[3] = sel2(nc[0], nc[1], splat2(0.f), (amp*num)*rcp2(den));
+                ncm[0] = nc[0] ? 8u : 0u;
+                ncm[1] = nc[1] ? 8u : 0u;
+            }
+#ifdef GRT_ABL_NOSLOTS
+            else if (hi < 0)
+#else
+            else
+#endif
+            {
+                v2f const acl = amp*cl;
+                v2f xq[7];
+#pragma unroll
+                for (int k = 0; k < 7; ++k)
+                {
+                    v2f const x = pk_fma(splat2((float)(k - 3)), wr, ndcr);
+                    xq[k] = x*x;
+                }
+                if (tfl & kTfV1)
+                {
+                    // region 1 throughout: K = cl (A0 + XQ)/(D0 + XQ (D2 + XQ)) (RFM_voigt.c:172-183)
+#pragma unroll
+                    for (int k = 0; k < 7; ++k)
+                    {
+                        v[k] = (acl*(a0 + xq[k]))*rcp2(pk_fma(xq[k], d2r + xq[k], d0r));
+                    }
+                }
+                else
+                {
+                    // ... and the Lorentzian in the same form, cl (A0 + XQ)/((XQ + YQ)(XQ + A0)): the point's region picks (D0, D2)
+                    v2f const d0l = yq*a0, d2l = yq + a0;
+#pragma unroll
+                    for (int k = 0; k < 7; ++k)
+                    {
+                        bool const r1x = xq[k].x < x0q.x, r1y = xq[k].y < x0q.y;
+                        v2f const D2 = sel2(r1x, r1y, d2r, d2l);
+                        v2f const D0 = sel2(r1x, r1y, d0r, d0l);
+                        v[k] = (acl*(a0 + xq[k]))*rcp2(pk_fma(xq[k], D2 + xq[k], D0));
+                    }
+                }
+                if (tfl & kTfNcOne)
+                {
+                    v2f const xq0 = ndcr*ndcr;
+                    bool const nc[2] = {xq0.x < xq_near.x, xq0.y < xq_near.y};
+                    v[3] = sel2(nc[0], nc[1], splat2(0.f), v[3]);
+                    ncm[0] = nc[0] ? 8u : 0u;
+                    ncm[1] = nc[1] ? 8u : 0u;
+                }
+                else if (tfl & kTfNcThree)
+                {
+                    // (grid steps of 8.6 Doppler widths and more: the own point and its two neighbours)
+#pragma unroll
+                    for (int k = 2; k <= 4; ++k)
+                    {
+                        bool const nc[2] = {xq[k].x < xq_near.x, xq[k].y < xq_near.y};
+                        v[k] = sel2(nc[0], nc[1], splat2(0.f), v[k]);
+                        ncm[0] |= nc[0] ? (1u << k) : 0u;
+                        ncm[1] |= nc[1] ? (1u << k) : 0u;
+                    }
+                }
+                else
+                {
+#pragma unroll
+                    for (int k = 0; k < 7; ++k)
+                    {
+                        bool const nc[2] = {xq[k].x < xq_near.x, xq[k].y < xq_near.y};
+                        v[k] = sel2(nc[0], nc[1], splat2(0.f), v[k]);
+                        ncm[0] |= nc[0] ? (1u << k) : 0u;
+                        ncm[1] |= nc[1] ? (1u << k) : 0u;
+                    }
+                }
+            }
+            // into the row's eight slots (grid points cr - 3 .. cr + 4): a line of cell cr + o has its points in slots o .. 6 + o
+#ifdef GRT_ABL_NOREDUCE
+            if (hi < 0)
+#endif
+            {
+                float nvs[8];
+                if (single)
+                {
+#pragma unroll
+                    for (int sl = 0; sl < 7; ++sl)
+                    {
+                        nvs[sl] = v[sl].x + v[sl].y;
+                    }
+                    nvs[7] = 0.f;
+                }
+                else
+                {
+#pragma unroll
+                    for (int sl = 0; sl < 8; ++sl)
+                    {
+                        v2f tt = splat2(0.f);
+                        if (sl <= 6) tt = W0*v[sl];
+                        if (sl >= 1) tt = pk_fma(W1, v[sl - 1], tt);
+                        nvs[sl] = tt.x + tt.y;
+                    }
+                }
+                float const s8 = row_sum_transposed(nvs, (lane & 8) != 0, (lane & 4) != 0, (lane & 2) != 0);
+#ifdef GRT_ABL_NOLDSADD
+                if (((lane & 1) == 0) & (s8 == 123.456f))
+#else
+                if (((lane & 1) == 0) & (s8 != 0.f))
+#endif
+                {
+                    GRT_ACC_ADD(&acc[cr - 3 + ((lane >> 1) & 7) - A0], (double)s8);
+                }
+            }
+            // ---- rare: a line in neither of its row's cells adds lane by lane; region-1 points beyond the near field of
+            // lines that are not folded (pre-pass 2 of general_block): such a line has |dl| wr > 12.5, so region 1
+            // (|x| < XLIM0 <= 123.4) ends within five grid steps ----
+            // (a wave whose lines all sit in their row's first cell has no such lane)
+            if (any_odd)
+            {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                {
+                    if (odd[h])
+                    {
+#pragma unroll
+                        for (int k = 0; k < 7; ++k)
+                        {
+                            if (v[k][h] != 0.f)
+                            {
+                                GRT_ACC_ADD(&acc[c[h] - 3 + k - A0], (double)v[k][h]);
+                            }
+                        }
+                    }
+                    if (ballot_b(pre2[h]) != 0ull)
+                    {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                        {
+                            int const r = q == 0 ? -5 : (q == 1 ? -4 : (q == 2 ? 4 : 5));
+                            float const x = fmaf((float)r, wr[h], ndcr[h]);
+                            float const xq = x*x;
+                            float const den = fmaf(xq, d2r[h] + xq, d0r[h])*(xq + yq[h]);
+                            float const corr = (amp[h]*cl[h])*fmaf(1.5f, xq, -0.5f*a0[h])*__builtin_amdgcn_rcpf(den);
+                            if (pre2[h] & (xq < x0q[h]))
+                            {
+                                GRT_ACC_ADD(&acc[c[h] + r - A0], (double)corr);
+                            }
+                        }
+                    }
+                }
+            }
+            // ---- core points (|x| < XLIM1: Humlicek regions 2-4) -> raw queue (line, strength, shift coefficient, grid point,
+            // molecule slot and exponent index); full batches are given the reference's x and y (drain_raw).
+            // Bits 0-6: points of the lane's first line, 7-13: of its second ----
+            unsigned nc2 = ncm[0] | (ncm[1] << 7);
+#ifdef GRT_ABL_NORAW
+            nc2 = 0u;
+#endif
+            // (the wave's last lean block also empties the raw queue: ONE place in the code prepares entries, so the kernel
+            // carries one copy less of that and of the four evaluation formulas behind it)
+            bool const flush = base + walk_stride >= nrel || xcount == kLeanListCap;
+            for (;;)
+            {
+                bool const more = ballot_b(nc2 != 0u) != 0ull;
+                if (rawcount >= 64 || (flush && !more && rawcount > 0))
+                {
+                    int const n = rawcount < 64 ? rawcount : 64;
+                    rawcount -= n;
+                    drain_raw(rawcount, n);
+                    continue;
+                }
+                if (!more)
+                {
+                    break;
+                }
+                bool const push = nc2 != 0u;
+                int const kb = push ? __builtin_ctz(nc2) : 0;
+                nc2 &= nc2 - 1u;
+                bool const second = kb >= 7;
+                int const k = second ? kb - 7 : kb;
                 unsigned long long const mk = ballot_b(push);
+                if (push)
+                {
+                    int const pos = rawcount + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+                    raw->j[wave][pos] = ((unsigned)jal + base) + 2u*(unsigned)lane + (second ? 1u : 0u);
+                    raw->amp[wave][pos] = second ? amp.y : amp.x;
+                    raw->delta[wave][pos] = second ? dsh.y : dsh.x;
+                    raw->idx[wave][pos] = (unsigned)((second ? c[1] : c[0]) - 3 + k - A0) | ((unsigned)k << 12) | ((second ? si[1] : si[0]) << 16)
+                                         | (((second ? rc[1] : rc[0]) & 127u) << 22);
+                }
+                rawcount += __popcll(mk);
+            }
+        }
+    };
+
+    // The workgroup's lines: lean blocks while that form applies and its list of handed-over lines has room; then the
+    // general form for the listed lines and for every block the lean loop did not take.
+    uint64_t base = walk_first;
+    if constexpr (LEANP > 0)
+    {
+        if (lean_ok && walk_first < jend)
+        {
+            unsigned brel = (unsigned)(walk_first - jal);
+            lean_fetch(brel);
+            for (; brel < nrel; brel += walk_stride)
+            {
+                lean_block(brel);
+                if (xcount == kLeanListCap)
+                {
+                    brel += walk_stride;
+                    break;
+                }
+            }
+            base = jal + brel;
+        }
+    }
+    for (int x = 0;;)
+    {
+        bool listed = false;
+        uint64_t bj = 0;
+        if constexpr (LEANP > 0)
+        {
+            if (x < xcount)
+            {
+                listed = true;
+                bj = jal + raw->xl_base[wave][x];
+            }
+        }
+        if (!listed)
+        {
+            if (base >= jend)
+            {
+                break;
+            }
+            bj = base;
+            base += walk_stride;
+        }
+        for (int p = 0; p < kLinesPerLane; ++p)
+        {
+            uint64_t j;
+            bool hv;
+            if (listed)
+            {
+                // (lines the lean form handed over: flagged ones, and centres too close to halfway between two grid points)
+                unsigned long long mk = 0ull;
+                if constexpr (LEANP > 0)
+                {
+                    mk = raw->xl_mask[wave][x][p];
+                }
                 if (mk == 0ull)
                 {
                     continue;
                 }
-                if (push)
-                {
-                    int const pos = lcount + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-                    cq->j[wave][pos] = (unsigned)jal + rel;
-                    cq->pk[wave][pos] = byte;
-                }
-                lcount += __popcll(mk);
+                j = bj + (uint64_t)(kLinesPerLane*lane + p);
+                hv = ((mk >> lane) & 1ull) != 0ull;
             }
-        }
-    };
-
-    // The workgroup's lines.  A lean tile: its bytes, step by step, until 64 lines are listed (a batch: its loads go out, the
-    // batch before it is worked on), the list of handed-over lines is full, or the range ends; then the handed-over lines
-    // through general_block; and so on.  Any other tile: every block through general_block.
-    uint64_t base = walk_first;
-    for (;;)
-    {
-        [[maybe_unused]] bool scan_done = true;
-        if constexpr (CORE)
-        {
-            if (lean_ok)
+            else
             {
-                for (;;)
+                if (bj + (uint64_t)p*64 >= jend)
                 {
-#if defined(GRT_CORE_ABL) && (GRT_CORE_ABL == 1 || GRT_CORE_ABL == 5)      // (timing experiments only: no scan at all)
-                    sb = nrel;
-#endif
-                    while (lcount < 64 && sb < nrel && xcount + 4 <= kLeanListCap)
-                    {
-                        core_scan(sb);
-                        sb += scan_stride;
-#if defined(GRT_CORE_ABL) && GRT_CORE_ABL == 2      // (the scan alone: listed lines are dropped)
-                        lcount = 0;
-#endif
-                    }
-                    scan_done = !(sb < nrel);
-                    bool const list_full = !(xcount + 4 <= kLeanListCap);
-                    int const n = lcount >= 64 ? 64 : ((scan_done || list_full) ? lcount : 0);
-                    if (pend_n > 0)
-                    {
-                        process_lines();
-                    }
-                    if (n > 0)
-                    {
-                        lcount -= n;
-                        fetch_lines(lcount, n);
-                    }
-                    if ((scan_done || list_full) && lcount == 0 && pend_n == 0)
-                    {
-                        break;
-                    }
+                    continue;
                 }
-            }
-        }
-        for (int x = 0;;)
-        {
-            bool listed = false;
-            uint64_t j = 0;
-            bool hv = false;
-            if constexpr (CORE)
-            {
-                if (x < xcount)
-                {
-                    // (lines the lean form handed over: flagged ones, and centres too close to halfway between two grid points)
-                    listed = true;
-                    j = jal + cq->xl_base[wave][x] + 4u*(unsigned)lane;
-                    hv = ((cq->xl_mask[wave][x] >> lane) & 1ull) != 0ull;
-                    ++x;
-                }
-            }
-            if (!listed)
-            {
-#if defined(GRT_CORE_ABL) && GRT_CORE_ABL == 5      // (timing experiments only: tiles the lean form does not take are skipped)
-                if (CORE) break;
-#endif
-                if (lean_ok || base >= jend)
-                {
-                    break;
-                }
-                j = base + lane;
+                j = bj + (uint64_t)p*64 + lane;
                 hv = j < jend;
-                base += walk_stride;
             }
             general_block(j, hv);
         }
-        xcount = 0;
-        if (!lean_ok || scan_done)
+        if (listed)
         {
-            break;
+            ++x;
         }
     }
 #pragma unroll
@@ -1380,15 +2153,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         for (int i = tid; i < kMom*(F1 - F0) && !direct; i += kBlock)
         {
             int const cidx = i >> 3, k = i & 7;
-            if (CORE && lean_ok)
-            {
-                // (the lean kernel has stored this tile's moments: what the handed-over lines contribute is added)
-                if (mom[k*ncell + cidx] != 0.f)
-                {
-                    unsafeAtomicAdd(&gm[i], mom[k*ncell + cidx]);
-                }
-            }
-            else if (a.nslice == 1)
+            if (a.nslice == 1)
             {
                 gm[i] = mom[k*ncell + cidx];
             }
@@ -1543,14 +2308,19 @@ void gas_optics_mp_kernel_w5(GrtGasOpticsArgs a, long long fsteps_ll, unsigned n
     mp_kernel_body<TWO_PASS, TREE, K, LEAN>(a, fsteps_ll, ngroups, perm_stride, ncell, nacc, halo);
 }
 
-// The kernel that FOLLOWS the lean first pass (k_gas_optics_lean.hip; see mp_kernel_body<..., CORE>): core points and
-// handed-over lines of the tiles the lean form takes, everything of the tiles it does not.
-template <bool LEAN>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void gas_optics_core_kernel(GrtGasOpticsArgs a, long long fsteps_ll, unsigned ngroups, unsigned perm_stride, int ncell,
+// First pass of the two-pass form with the LEAN line loop (see mp_kernel_body): LEANP lines per lane.
+#ifndef GRT_LEAN_WAVES
+#define GRT_LEAN_WAVES 4
+#endif
+#ifndef GRT_LEAN_P
+#define GRT_LEAN_P 2
+#endif
+template <bool LEAN, int LEANP>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(GRT_LEAN_WAVES, GRT_LEAN_WAVES)))
+void gas_optics_lean_kernel(GrtGasOpticsArgs a, long long fsteps_ll, unsigned ngroups, unsigned perm_stride, int ncell,
                             int nacc, int halo)
 {
-    mp_kernel_body<true, false, kMom, LEAN, false, true>(a, fsteps_ll, ngroups, perm_stride, ncell, nacc, halo);
+    mp_kernel_body<true, false, kMom, LEAN, false, LEANP>(a, fsteps_ll, ngroups, perm_stride, ncell, nacc, halo);
 }
 
 // The instrumented instance of the tree form on sparse lines (twelve moments), see mp_kernel_body<..., PROBE>.
@@ -2360,7 +3130,7 @@ void launch_tree(hipStream_t s, GrtGasOpticsArgs const &b, long long fsteps, int
 size_t lean_lds_bytes(int num_slots)
 {
     (void)num_slots;
-    return 16 + sizeof(LeanTables) + sizeof(CoreLines);
+    return 16 + sizeof(LeanTables) + sizeof(LeanRaw);
 }
 
 size_t mp_lds_bytes(int nacc, int ncell, int fsteps, int num_slots, bool tree = false, int subtree_tile = 0)
@@ -2528,8 +3298,6 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
         b.lean = !tree && a->probe == NULL && lean_wanted() && a->lines.lean_a != NULL && a->lines.lean_b != NULL
                  && a->lines.lean_c != NULL && a->lines.lean_x != NULL && a->lay.num_slots <= kLeanSlots && a->lines.lean_w0 == a->w0 && a->lines.lean_wres == a->wres
                  && a->lines.n < 0xffffffffull && halo >= 8 && nacc <= 4096
-                 && a->core_mask != NULL && a->core_mask_stride >= 2*a->lines.lean_npair && (a->core_mask_stride & 1u) == 0
-                 && ncell > 0 && grt_lean_lds_bytes(nacc, ncell, a->lay.num_slots) <= kLdsPerWorkgroup
                  && lds + lean_lds_bytes(a->lay.num_slots) <= kLdsPerWorkgroup;
         if (b.lean)
         {
@@ -2580,35 +3348,15 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
                                            fsteps, (unsigned)ngroups, golden_stride(ngroups), ncell, nacc, halo);
                     }
                 }
+                else if (b.lean && a->w0 + (double)a->nw*a->wres <= 4000.)
+                {
+                    hipLaunchKernelGGL((gas_optics_lean_kernel<true, GRT_LEAN_P>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
+                                       fsteps, (unsigned)ngroups, golden_stride(ngroups), ncell, nacc, halo);
+                }
                 else if (b.lean)
                 {
-                    // the lean first pass, then the kernel that takes what it leaves (core points, handed-over lines, the
-                    // tiles it does not apply to): both add to tau; the second adds to the first's cell moments
-                    int const rc = grt_launch_gas_optics_lean(stream, &b, fsteps, blocks, ngroups, ncell, nacc, halo);
-                    if (rc != 0)
-                    {
-                        return rc;
-                    }
-                    if (a->profile_tag)         // (the core kernel is timed under tag + 10)
-                    {
-                        grt_profile_end(stream, slot);
-                        slot = grt_profile_begin(stream, a->profile_tag + 10);
-                    }
-                    if (a->w0 + (double)a->nw*a->wres <= 4000.)
-                    {
-                        hipLaunchKernelGGL((gas_optics_core_kernel<true>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
-                                           fsteps, (unsigned)ngroups, golden_stride(ngroups), ncell, nacc, halo);
-                    }
-                    else
-                    {
-                        hipLaunchKernelGGL((gas_optics_core_kernel<false>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
-                                           fsteps, (unsigned)ngroups, golden_stride(ngroups), ncell, nacc, halo);
-                    }
-                    if (a->profile_tag && phase + 1 < nphase)
-                    {
-                        grt_profile_end(stream, slot);
-                        slot = grt_profile_begin(stream, a->profile_tag);
-                    }
+                    hipLaunchKernelGGL((gas_optics_lean_kernel<false, GRT_LEAN_P>), dim3((unsigned)blocks), dim3(kBlock), lds, s, b,
+                                       fsteps, (unsigned)ngroups, golden_stride(ngroups), ncell, nacc, halo);
                 }
                 else if (a->w0 + (double)a->nw*a->wres <= 4000.)
                 {

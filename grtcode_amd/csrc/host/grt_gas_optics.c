@@ -763,7 +763,6 @@ EXTERN int destroy_gas_optics(GasOptics_t * const gas_optics)
         GRT_TRY(free_store(gas_optics));
         GRT_TRY(grt_dev_free(gas_optics->device, im->bins_block));
         GRT_TRY(grt_dev_free(gas_optics->device, im->gmom));
-        GRT_TRY(grt_dev_free(gas_optics->device, im->core_mask));
         GRT_TRY(grt_dev_free(gas_optics->device, im->h2o_tables));
         GRT_TRY(grt_dev_free(gas_optics->device, im->lin_tables));
         GRT_TRY(grt_dev_free(gas_optics->device, im->colstate_d));
@@ -1890,23 +1889,6 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
                     im->gmom_bytes = need;
                 }
                 a->gmom = im->gmom;
-                /* the lean first pass (single-level gather, packed records built for this grid) leaves one byte per
-                   (column, layer, line) for the core-point kernel behind it (k_gas_optics_lean.hip) */
-                if (a->tree_levels == 0 && im->store.lean_a != NULL && im->store.lean_npair > 0)
-                {
-                    uint64_t const row = ((2*im->store.lean_npair + 15) & ~(uint64_t)15) + 16;    /* (the core kernel reads dwords: a few bytes past the last line) */
-                    size_t const mask_need = (size_t)row*(size_t)go->num_layers*(size_t)ncol;
-                    if (mask_need > im->core_mask_bytes)
-                    {
-                        GRT_TRY(grt_dev_free(go->device, im->core_mask));
-                        im->core_mask = NULL;
-                        im->core_mask_bytes = 0;
-                        GRT_TRY(grt_dev_alloc(go->device, (void **)&im->core_mask, mask_need));
-                        im->core_mask_bytes = mask_need;
-                    }
-                    a->core_mask = im->core_mask;
-                    a->core_mask_stride = row;
-                }
             }
             else
             {

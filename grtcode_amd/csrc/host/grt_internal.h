@@ -101,8 +101,6 @@ typedef struct GrtGasOpticsImpl
     void *bins_block;              /* device allocation backing bins.w / bins.l / bins.r / bins.tau */
     float *gmom;                   /* two-pass moment kernel: [ncol][L][8][n] cell moments */
     size_t gmom_bytes;
-    uint8_t *core_mask;            /* ... with the lean first pass: [ncol][L] rows of one byte per line (GrtGasOpticsArgs.core_mask) */
-    size_t core_mask_bytes;
     long long last_launch[8];    /* grt_gas_optics_last_launch */
     /* spectral tables on device, each [n]: */
     double *h2o_tables;            /* [4][n] F296,S296,CKDF,CKDS or NULL */

@@ -175,8 +175,7 @@ EXTERN int grt_multi_max(GrtMulti_t *multi, double *value);    /* barrier + maxi
  * Tags: 1 = line-by-line kernel on a grid of <= 10 000 points (longwave band at 1 cm-1),
  * 2 = line-by-line kernel on a larger grid (shortwave band), 3 = LW solver, 4 = SW solver,
  * 5 = clear-sky optics combine, 6 / 7 = far-field gather kernel of the two-pass line kernel (longwave /
- * shortwave band; tags 1 / 2 then cover its first pass), 11 / 12 = the core-point kernel that follows the lean first
- * pass (tags 1 / 2 then cover the lean kernel alone).  Read after grt_pipeline_sync(). */
+ * shortwave band; tags 1 / 2 then cover its first pass).  Read after grt_pipeline_sync(). */
 EXTERN int grt_profile_enable(int on);
 EXTERN int grt_profile_read(int tag, double *total_ms, int *launches, int reset);
 
