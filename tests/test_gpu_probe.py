@@ -33,7 +33,16 @@ def test_instrumented_instance_same_tau_and_one_record_per_workgroup(tmp_path, d
     go.tune(fast=3)
     col = syn.profile(2, V)
     band.set_column(go, col)
-    plain = optical_depth(go, grid, device, col)
+    # (the instrumented instance is one of the GENERAL line loop: it is compared with that loop -- GRT_LEAN is read at every
+    # launch -- not with the lean form, which agrees with it to LEAN_TOL only and which this band's tiles, at the ends of
+    # its short grid, take since round 5)
+    import os
+    os.environ["GRT_LEAN"] = "0"
+    production = optical_depth(go, grid, device, col)
+    try:
+        plain = optical_depth(go, grid, device, col)
+    finally:
+        del os.environ["GRT_LEAN"]
     info = go.last_launch()
     assert info["fast"] == 3 and (info["tree_levels"] > 0) == (case != "single_level_1cm"), info
     if case != "single_level_1cm":
@@ -64,7 +73,7 @@ def test_instrumented_instance_same_tau_and_one_record_per_workgroup(tmp_path, d
     api.check(lib.grt_host_to_device(device, buf.ptr, zeros.ctypes.data_as(C.c_void_p), zeros.nbytes))
     api.check(lib.grt_gas_optics_probe(C.byref(go.c), buf.ptr, C.c_uint64(WORDS * nrec - 1)))
     again = optical_depth(go, grid, device, col)
-    assert np.max(np.abs(again - plain) / peak) < RUN_TO_RUN_FUSED
+    assert np.max(np.abs(again - production) / peak) < RUN_TO_RUN_FUSED
     assert not buf.to_host((WORDS * nrec,), dtype=np.uint64).any()
     api.check(lib.grt_gas_optics_probe(C.byref(go.c), None, C.c_uint64(0)))
     buf.free()
