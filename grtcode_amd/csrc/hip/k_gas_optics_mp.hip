@@ -398,6 +398,28 @@ __host__ __device__ inline uint64_t level_offset(uint64_t nw, int l, int terms, 
     return (p2 - (p2 >> l))*terms;
 }
 
+// Layout of a (column, layer) block of the hierarchy.  A cell's number counts the cells of the levels before its own
+// (level l begins at cell level_offset(nw, l, 1, levels)).  Eight moments per cell: [cell][8].  TWELVE (sparse lines, the
+// 0.001 cm-1 class of grids; round 5): TWO PLANES -- the first four moments of every cell, [cell][4], then the other
+// eight, [cell][8].  The gather's lanes take only four terms from the cells at the far ends of their windows (one
+// 16-byte load each), and with 48-byte cells those loads still drew every line of the level-0 and level-1 cells through
+// the memory system once per side: 56 of the 100 GB that a 0.001 cm-1 column moved (profiles/traffic_latest.json, r4).
+template <int K>
+struct CellStore
+{
+    float *a, *b;
+    __host__ __device__ CellStore(float *blk, uint64_t total_cells)
+        : a(blk), b(K == kMomWide ? blk + total_cells*4 : blk + 4) {}
+    __host__ __device__ float *lo(uint64_t cell) const { return a + cell*(K == kMomWide ? 4 : K); }      // moments 1-4
+    __host__ __device__ float *hi(uint64_t cell) const { return b + cell*(K == kMomWide ? 8 : K); }      // moments 5 ..
+    __host__ __device__ float *moment(uint64_t cell, int k) const { return k < 4 ? lo(cell) + k : hi(cell) + (k - 4); }
+};
+// cells of all the levels of a block (levels 0 .. `levels`)
+__host__ __device__ inline uint64_t hierarchy_cells(uint64_t nw, int levels)
+{
+    return level_offset(nw, levels + 1, 1, levels);
+}
+
 // |C(k, j) (1/4)^(k-j) (1/2)^j|: the parent's m_k from a child's m_j (1-based, j <= k); the lower child's takes the
 // sign (-1)^(k-j), the upper child's is positive
 constexpr float shift_coef(int k, int j)
@@ -648,14 +670,15 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                 }
             }
             __syncthreads();
-            float4 *z = reinterpret_cast<float4 *>(a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*a.gmom_stride + (uint64_t)F0*K);
+            CellStore<K> const zs(a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*a.gmom_stride, hierarchy_cells(a.nw, a.tree_levels));
             for (int i = tid; i < (F1 - F0)*(K/4); i += kBlock)
             {
-                int const cell = i/(K/4);
+                int const cell = i/(K/4), piece = i - cell*(K/4);
                 unsigned const bit = 1u << (cell & 31);
                 if (!(occ_any[cell >> 5] & bit) || (occ_many[cell >> 5] & bit))
                 {
-                    z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    float *z = piece == 0 ? zs.lo((uint64_t)(F0 + cell)) : zs.hi((uint64_t)(F0 + cell)) + 4*(piece - 1);
+                    *reinterpret_cast<float4 *>(z) = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
             __syncthreads();        // (orders the clearing stores before other waves' adds)
@@ -669,12 +692,13 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
     // moments go to the tile's LDS block, or (tree form: ncell == 0, sparse lines, wide tiles) straight to the
     // zeroed level-0 block in global memory
     bool const direct = TREE && K == kMomWide && ncell == 0;     // (twelve moments <=> straight to global memory)
-    float *gcell = TWO_PASS ? a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*a.gmom_stride : nullptr;      // [cell][8]
+    float *gcell = TWO_PASS ? a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*a.gmom_stride : nullptr;      // (CellStore)
+    CellStore<K> const cells(gcell, TREE ? hierarchy_cells(a.nw, a.tree_levels) : 0);
     auto mom_add = [&](int k, int cell, float v)
     {
         if (direct)
         {
-            unsafeAtomicAdd(&gcell[(size_t)cell*K + k], v);
+            unsafeAtomicAdd(cells.moment((uint64_t)cell, k), v);
         }
         else
         {
@@ -971,11 +995,11 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                 if (!shared)
                 {
                     // the cell's only line: its moments ARE the cell
-                    float4 *dst = reinterpret_cast<float4 *>(gcell + (size_t)c*K);
+                    *reinterpret_cast<float4 *>(cells.lo((uint64_t)c)) = make_float4(m[0], m[1], m[2], m[3]);
 #pragma unroll
-                    for (int q = 0; q < K/4; ++q)
+                    for (int q = 1; q < K/4; ++q)
                     {
-                        dst[q] = make_float4(m[4*q], m[4*q + 1], m[4*q + 2], m[4*q + 3]);
+                        reinterpret_cast<float4 *>(cells.hi((uint64_t)c))[q - 1] = make_float4(m[4*q], m[4*q + 1], m[4*q + 2], m[4*q + 3]);
                     }
                 }
                 else
@@ -2218,32 +2242,36 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                 {
                     float *dst = (l & 1) ? buf_odd : buf_even;
                     float const *src = (l & 1) ? buf_even : buf_odd;
-                    float *parent = gcell + level_offset(a.nw, l, K, a.tree_levels);
+                    uint64_t const parent0 = level_offset(a.nw, l, 1, a.tree_levels);           // the level's first cell
                     int const c0 = F0 >> (l - 1), c1 = (F1 + (1 << (l - 1)) - 1) >> (l - 1);    // the tile's cells one level down
                     int const p0 = F0 >> l, p1 = (F1 + (1 << l) - 1) >> l;
                     for (int j = p0 + tid; j < p1; j += kBlock)
                     {
-                        float4 const *ch = l == 1 ? reinterpret_cast<float4 const *>(gcell + (size_t)(2*j)*K)
-                                                  : reinterpret_cast<float4 const *>(src + (size_t)(2*j - c0)*K);
                         bool const two = 2*j + 1 < c1;
                         float lo[K], hi[K];
+                        // (level 1: the children are the level-0 cells in global memory, two planes; further up: the LDS
+                        // copy of the level before, [cell][K])
 #pragma unroll
                         for (int q = 0; q < K/4; ++q)
                         {
-                            float4 const x = ch[q];
-                            float4 const y = two ? ch[K/4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+                            float4 const *c_lo = l == 1 ? reinterpret_cast<float4 const *>(q == 0 ? cells.lo((uint64_t)(2*j)) : cells.hi((uint64_t)(2*j)) + 4*(q - 1))
+                                                        : reinterpret_cast<float4 const *>(src + (size_t)(2*j - c0)*K) + q;
+                            float4 const *c_hi = l == 1 ? reinterpret_cast<float4 const *>(q == 0 ? cells.lo((uint64_t)(2*j + 1)) : cells.hi((uint64_t)(2*j + 1)) + 4*(q - 1))
+                                                        : reinterpret_cast<float4 const *>(src + (size_t)(2*j + 1 - c0)*K) + q;
+                            float4 const x = *c_lo;
+                            float4 const y = two ? *c_hi : make_float4(0.f, 0.f, 0.f, 0.f);
                             lo[4*q] = x.x; lo[4*q + 1] = x.y; lo[4*q + 2] = x.z; lo[4*q + 3] = x.w;
                             hi[4*q] = y.x; hi[4*q + 1] = y.y; hi[4*q + 2] = y.z; hi[4*q + 3] = y.w;
                         }
                         float m[K];
                         shift_pair<K>(lo, hi, m);
-                        float4 *out4 = reinterpret_cast<float4 *>(parent + (size_t)j*K);
                         float4 *lds4 = reinterpret_cast<float4 *>(dst + (size_t)(j - p0)*K);
 #pragma unroll
                         for (int q = 0; q < K/4; ++q)
                         {
                             float4 const v = make_float4(m[4*q], m[4*q + 1], m[4*q + 2], m[4*q + 3]);
-                            out4[q] = v;
+                            float *o = q == 0 ? cells.lo(parent0 + (uint64_t)j) : cells.hi(parent0 + (uint64_t)j) + 4*(q - 1);
+                            *reinterpret_cast<float4 *>(o) = v;
                             lds4[q] = v;
                         }
                     }
@@ -2566,32 +2594,34 @@ __global__ __launch_bounds__(kBlock) void gas_optics_far_kernel(GrtGasOpticsArgs
 // ---------------------------------------------------------------------------------------------------------
 template <int K>
 __global__ __launch_bounds__(kBlock) void moment_up_kernel(float *gmom, uint64_t stride, uint64_t off_child, uint64_t n_child,
-                                                            uint64_t off_parent, uint64_t n_parent)
+                                                            uint64_t off_parent, uint64_t n_parent, uint64_t total_cells)
 {
     uint64_t const j = (uint64_t)blockIdx.x*kBlock + threadIdx.x;
     if (j >= n_parent)
     {
         return;
     }
-    float *blk = gmom + ((uint64_t)blockIdx.z*gridDim.y + blockIdx.y)*stride;      // block of (column z, layer y)
-    float4 const *ch = reinterpret_cast<float4 const *>(blk + off_child + 2*j*K);
+    // (off_child, off_parent: the levels' first cells; total_cells: of the whole block -- CellStore)
+    CellStore<K> const cells(gmom + ((uint64_t)blockIdx.z*gridDim.y + blockIdx.y)*stride, total_cells);      // block of (column z, layer y)
     bool const two = 2*j + 1 < n_child;
     float lo[K], hi[K];
 #pragma unroll
     for (int q = 0; q < K/4; ++q)
     {
-        float4 const a = ch[q];
-        float4 const b = two ? ch[K/4 + q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float const *pa = q == 0 ? cells.lo(off_child + 2*j) : cells.hi(off_child + 2*j) + 4*(q - 1);
+        float const *pb = q == 0 ? cells.lo(off_child + 2*j + 1) : cells.hi(off_child + 2*j + 1) + 4*(q - 1);
+        float4 const a = *reinterpret_cast<float4 const *>(pa);
+        float4 const b = two ? *reinterpret_cast<float4 const *>(pb) : make_float4(0.f, 0.f, 0.f, 0.f);
         lo[4*q] = a.x; lo[4*q + 1] = a.y; lo[4*q + 2] = a.z; lo[4*q + 3] = a.w;
         hi[4*q] = b.x; hi[4*q + 1] = b.y; hi[4*q + 2] = b.z; hi[4*q + 3] = b.w;
     }
     float m[K];
     shift_pair<K>(lo, hi, m);
-    float4 *out = reinterpret_cast<float4 *>(blk + off_parent + j*K);
 #pragma unroll
     for (int q = 0; q < K/4; ++q)
     {
-        out[q] = make_float4(m[4*q], m[4*q + 1], m[4*q + 2], m[4*q + 3]);
+        float *o = q == 0 ? cells.lo(off_parent + j) : cells.hi(off_parent + j) + 4*(q - 1);
+        *reinterpret_cast<float4 *>(o) = make_float4(m[4*q], m[4*q + 1], m[4*q + 2], m[4*q + 3]);
     }
 }
 
@@ -2608,6 +2638,31 @@ __device__ __forceinline__ float cell_series(float const *cell, float u)
         v = c4[q];
         p = fmaf(p, u, v.w); p = fmaf(p, u, v.z); p = fmaf(p, u, v.y); p = fmaf(p, u, v.x);
     }
+    return p*(u*u);
+}
+
+// ... of cell number `cell` of a block (CellStore): TERMS = K, or 4 -- the first plane alone
+template <int K, int TERMS>
+__device__ __forceinline__ float cell_series_at(CellStore<K> const &cs, uint64_t cell, float u)
+{
+    float4 const lo = *reinterpret_cast<float4 const *>(cs.lo(cell));
+    float p = 0.f;
+    if constexpr (TERMS > 4)
+    {
+        float4 const *h4 = reinterpret_cast<float4 const *>(cs.hi(cell));
+#pragma unroll
+        for (int q = K/4 - 2; q >= 0; --q)
+        {
+            float4 const v = h4[q];
+            p = fmaf(p, u, v.w); p = fmaf(p, u, v.z); p = fmaf(p, u, v.y); p = fmaf(p, u, v.x);
+        }
+        p = fmaf(p, u, lo.w);
+    }
+    else
+    {
+        p = lo.w;
+    }
+    p = fmaf(p, u, lo.z); p = fmaf(p, u, lo.y); p = fmaf(p, u, lo.x);
     return p*(u*u);
 }
 
@@ -2648,7 +2703,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_lane_kernel(GrtGasOpti
     double *ms_l = acc + a.tile;                                                  // [num_slots][4]
     double *q_l = ms_l + 4*a.lay.num_slots;                                       // [num_slots][GRT_MAX_ISO] (unused here)
     int *rtab = reinterpret_cast<int *>(q_l + GRT_MAX_ISO*a.lay.num_slots);       // [ntab]
-    unsigned *loff = reinterpret_cast<unsigned *>(rtab + ntab);                   // [kMaxLevels + 1] level offsets (floats)
+    unsigned *loff = reinterpret_cast<unsigned *>(rtab + ntab);                   // [kMaxLevels + 1] level offsets (cells)
     int const tid = threadIdx.x;
     int const layer = blockIdx.y, col = blockIdx.z;
     int const nw = (int)a.nw;
@@ -2657,7 +2712,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_lane_kernel(GrtGasOpti
     double const *cs = a.colstate + (uint64_t)col*a.lay.stride;
     double const *lay = cs + a.lay.off_lay + (uint64_t)layer*4;
     double *out = a.tau + (uint64_t)col*a.tau_col_stride + (uint64_t)layer*a.nw;
-    float const *gm = a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*a.gmom_stride;
+    CellStore<K> const gm(a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*a.gmom_stride, hierarchy_cells(a.nw, a.tree_levels));
     stage_column_state(a, cs, layer, ms_l, q_l, tid);
     for (int i = tid; i < F1 - F0; i += kBlock)
     {
@@ -2665,7 +2720,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_lane_kernel(GrtGasOpti
     }
     if (tid <= a.tree_levels)
     {
-        loff[tid] = (unsigned)level_offset(a.nw, tid, K, a.tree_levels);
+        loff[tid] = (unsigned)level_offset(a.nw, tid, 1, a.tree_levels);       // the levels' first cells
     }
     __syncthreads();
     // near-field radii of the cell tiles within `halo` of this tile (level-0 cells further away are far for sure)
@@ -2709,7 +2764,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_lane_kernel(GrtGasOpti
                 if (D > rtab[(x >> cell_shift) - t0])
                 {
                     float const u = -__builtin_amdgcn_rcpf((float)D);
-                    sum += (double)cell_series<K>(gm + (size_t)x*K, u);
+                    sum += (double)cell_series_at<K, K>(gm, (uint64_t)x, u);
                 }
             }
             while (x <= e)
@@ -2720,7 +2775,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_lane_kernel(GrtGasOpti
                 float const h = __int_as_float((127 + l) << 23), rh = __int_as_float((127 - l) << 23);
                 float const d = ((float)D - 0.5f) + 0.5f*h;                     // C - f
                 float const u = -h*__builtin_amdgcn_rcpf(d);
-                sum += (double)(cell_series<K>(gm + loff[l] + (size_t)(x >> l)*K, u)*rh);
+                sum += (double)(cell_series_at<K, K>(gm, (uint64_t)loff[l] + (uint64_t)(x >> l), u)*rh);
                 x += 1 << l;
             }
         }
@@ -2735,7 +2790,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_lane_kernel(GrtGasOpti
                 if (D > rtab[(x >> cell_shift) - t0])
                 {
                     float const u = __builtin_amdgcn_rcpf((float)D);
-                    sum += (double)cell_series<K>(gm + (size_t)x*K, u);
+                    sum += (double)cell_series_at<K, K>(gm, (uint64_t)x, u);
                 }
             }
             while (x >= s)
@@ -2746,7 +2801,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_lane_kernel(GrtGasOpti
                 float const h = __int_as_float((127 + l) << 23), rh = __int_as_float((127 - l) << 23);
                 float const d = ((float)D - 0.5f) + 0.5f*h;                     // f - C
                 float const u = h*__builtin_amdgcn_rcpf(d);
-                sum += (double)(cell_series<K>(gm + loff[l] + (size_t)(x >> l)*K, u)*rh);
+                sum += (double)(cell_series_at<K, K>(gm, (uint64_t)loff[l] + (uint64_t)(x >> l), u)*rh);
                 x -= 1 << l;
             }
         }
@@ -2760,19 +2815,21 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_lane_kernel(GrtGasOpti
 // wait there is is for all of them; the operands of scalar_wait tie the values to it).
 typedef float sfloat4 __attribute__((ext_vector_type(4)));
 
+// (lo: the cell's first four moments, hi: the others -- CellStore; eight moments: one 32-byte record, hi = lo + 4)
 template <int K>
-__device__ __forceinline__ void scalar_load_cell(float const *cell, sfloat4 (&c)[K/4])
+__device__ __forceinline__ void scalar_load_cell(float const *lo, float const *hi, sfloat4 (&c)[K/4])
 {
     static_assert(K == 8 || K == 12, "two or three 16-byte pieces");
     if constexpr (K == 12)
     {
-        asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x10\n\ts_load_dwordx4 %2, %3, 0x20"
-                     : "=&s"(c[0]), "=&s"(c[1]), "=&s"(c[2]) : "s"(cell) : "memory");
+        asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %4, 0x0\n\ts_load_dwordx4 %2, %4, 0x10"
+                     : "=&s"(c[0]), "=&s"(c[1]), "=&s"(c[2]) : "s"(lo), "s"(hi) : "memory");
     }
     else
     {
+        (void)hi;
         asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x10"
-                     : "=&s"(c[0]), "=&s"(c[1]) : "s"(cell) : "memory");
+                     : "=&s"(c[0]), "=&s"(c[1]) : "s"(lo) : "memory");
     }
 }
 
@@ -2839,7 +2896,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArg
     double const *cs = a.colstate + (uint64_t)col*a.lay.stride;
     double const *lay = cs + a.lay.off_lay + (uint64_t)layer*4;
     double *out = a.tau + (uint64_t)col*a.tau_col_stride + (uint64_t)layer*a.nw;
-    float const *gm = a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*a.gmom_stride;
+    CellStore<K> const gm(a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*a.gmom_stride, hierarchy_cells(a.nw, a.tree_levels));
     stage_column_state(a, cs, layer, ms_l, q_l, tid);
     for (int i = tid; i < F1 - F0; i += kBlock)
     {
@@ -2869,7 +2926,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArg
     near_radius(a, lay, ms_l, F0, F1, fsteps, &um, &cr, &zmax);
     double const sep = moment_separation(K);
     int const lmax = a.tree_levels;
-    unsigned const p2 = (unsigned)(level_offset(a.nw, 1, 1, lmax) << 1);        // 2 nw_pad: level l starts at (p2 - (p2 >> l)) K floats
+    unsigned const p2 = (unsigned)(level_offset(a.nw, 1, 1, lmax) << 1);        // 2 nw_pad: level l starts at cell p2 - (p2 >> l)
     // Admissible levels (see admissible_level): a cell of h = 2^l points whose first point is D grid steps from the
     // target is admissible when (D - 1/2 + h/2)^2 >= sep^2 (h^2/4 + eta^2), i.e. D >= thr(l).  Lane l keeps thr(l), so
     // "the highest admissible level at distance D" is one compare and the position of the ballot's top bit.  Level 0
@@ -2902,7 +2959,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArg
             float const h = __int_as_float((127 + l) << 23), rh = __int_as_float((127 - l) << 23);
             float const d = ((float)D - 0.5f) + 0.5f*h;                     // C - f
             float const u = -h*__builtin_amdgcn_rcpf(d);
-            sum += (double)(cell_series<TERMS>(gm + (p2 - (p2 >> l))*K + (size_t)(x >> l)*K, u)*rh);
+            sum += (double)(cell_series_at<K, TERMS>(gm, (uint64_t)(p2 - (p2 >> l)) + (uint64_t)(x >> l), u)*rh);
             x += 1 << l;
         }
         return sum;
@@ -2919,7 +2976,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArg
             float const h = __int_as_float((127 + l) << 23), rh = __int_as_float((127 - l) << 23);
             float const d = ((float)D - 0.5f) + 0.5f*h;                     // f - C
             float const u = h*__builtin_amdgcn_rcpf(d);
-            sum += (double)(cell_series<TERMS>(gm + (p2 - (p2 >> l))*K + (size_t)(x >> l)*K, u)*rh);
+            sum += (double)(cell_series_at<K, TERMS>(gm, (uint64_t)(p2 - (p2 >> l)) + (uint64_t)(x >> l), u)*rh);
             x -= 1 << l;
         }
         return sum;
@@ -2965,14 +3022,14 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArg
         {
             if (x - fhb > __builtin_amdgcn_readfirstlane(rtab[(x >> cell_shift) - t0]))
             {
-                sum += (double)cell_series<K>(gm + (size_t)x*K, -__builtin_amdgcn_rcpf((float)(x - f)));
+                sum += (double)cell_series_at<K, K>(gm, (uint64_t)x, -__builtin_amdgcn_rcpf((float)(x - f)));
             }
         }
         for (int x = fb - 1 - rmin; x >= fb - rmax && x > S0s; --x)
         {
             if (fb - x > __builtin_amdgcn_readfirstlane(rtab[(x >> cell_shift) - t0]))
             {
-                sum += (double)cell_series<K>(gm + (size_t)x*K, __builtin_amdgcn_rcpf((float)(f - x)));
+                sum += (double)cell_series_at<K, K>(gm, (uint64_t)x, __builtin_amdgcn_rcpf((float)(f - x)));
             }
         }
         // ---- the lane's own cells: the far end of its window ----
@@ -2987,7 +3044,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArg
                 {
                     if (x - fhb > rtab[(x >> cell_shift) - t0])
                     {
-                        sum += (double)cell_series<K>(gm + (size_t)x*K, -__builtin_amdgcn_rcpf((float)(x - f)));
+                        sum += (double)cell_series_at<K, K>(gm, (uint64_t)x, -__builtin_amdgcn_rcpf((float)(x - f)));
                     }
                 }
                 sum += four_up ? walk_up(f, x, e + 1, cap_up, four_terms) : walk_up(f, x, e + 1, cap_up, all_terms);
@@ -3000,7 +3057,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArg
                 {
                     if (fb - x > rtab[(x >> cell_shift) - t0])
                     {
-                        sum += (double)cell_series<K>(gm + (size_t)x*K, __builtin_amdgcn_rcpf((float)(f - x)));
+                        sum += (double)cell_series_at<K, K>(gm, (uint64_t)x, __builtin_amdgcn_rcpf((float)(f - x)));
                     }
                 }
                 sum += four_down ? walk_down(f, x, s - 1, cap_down, four_terms) : walk_down(f, x, s - 1, cap_down, all_terms);
@@ -3024,8 +3081,8 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArg
                 int const D = xs - fhb;                                     // the block's end decides
                 int const la = __builtin_ctz(xs), le = 31 - __builtin_clz(E0s - xs);
                 int const l = __builtin_amdgcn_readfirstlane(min(min(la, le), top_level(D)));
-                unsigned const off = (p2 - (p2 >> l))*K;
-                scalar_load_cell<K>(gm + off + (size_t)(xs >> l)*K, c[j]);
+                uint64_t const cell = (uint64_t)(p2 - (p2 >> l)) + (uint64_t)(xs >> l);
+                scalar_load_cell<K>(gm.lo(cell), gm.hi(cell), c[j]);
                 hh[j] = __int_as_float((127 + l) << 23);
                 ww[j] = live ? __int_as_float((127 - l) << 23) : 0.f;
                 xx[j] = xs;
@@ -3053,8 +3110,8 @@ __global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArg
                 int const D = fb - xs;
                 int const la = __builtin_ctz(xs + 1), le = 31 - __builtin_clz(xs - S0s);
                 int const l = __builtin_amdgcn_readfirstlane(min(min(la, le), top_level(D)));
-                unsigned const off = (p2 - (p2 >> l))*K;
-                scalar_load_cell<K>(gm + off + (size_t)(xs >> l)*K, c[j]);
+                uint64_t const cell = (uint64_t)(p2 - (p2 >> l)) + (uint64_t)(xs >> l);
+                scalar_load_cell<K>(gm.lo(cell), gm.hi(cell), c[j]);
                 hh[j] = __int_as_float((127 + l) << 23);
                 ww[j] = live ? __int_as_float((127 - l) << 23) : 0.f;
                 xx[j] = xs;
@@ -3110,8 +3167,8 @@ void launch_tree(hipStream_t s, GrtGasOpticsArgs const &b, long long fsteps, int
     {
         uint64_t const n_child = level_cells(b.nw, l - 1), n_parent = level_cells(b.nw, l);
         hipLaunchKernelGGL(moment_up_kernel<K>, dim3((unsigned)((n_parent + kBlock - 1)/kBlock), b.lay.num_layers, b.ncol),
-                           dim3(kBlock), 0, s, b.gmom, b.gmom_stride, level_offset(b.nw, l - 1, K, b.tree_levels), n_child,
-                           level_offset(b.nw, l, K, b.tree_levels), n_parent);
+                           dim3(kBlock), 0, s, b.gmom, b.gmom_stride, level_offset(b.nw, l - 1, 1, b.tree_levels), n_child,
+                           level_offset(b.nw, l, 1, b.tree_levels), n_parent, hierarchy_cells(b.nw, b.tree_levels));
     }
     if (b.near_block == 0)
     {

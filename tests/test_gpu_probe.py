@@ -37,8 +37,8 @@ def test_instrumented_instance_same_tau_and_one_record_per_workgroup(tmp_path, d
     # launch -- not with the lean form, which agrees with it to LEAN_TOL only and which this band's tiles, at the ends of
     # its short grid, take since round 5)
     import os
-    os.environ["GRT_LEAN"] = "0"
     production = optical_depth(go, grid, device, col)
+    os.environ["GRT_LEAN"] = "0"
     try:
         plain = optical_depth(go, grid, device, col)
     finally:
