@@ -319,7 +319,7 @@ class GasOpticsObject:
     def last_launch(self):
         info = (C.c_longlong * 8)()
         check(self.lib.grt_gas_optics_last_launch(C.byref(self.c), info))
-        return dict(zip(("fast", "tile", "nslice", "tree_levels", "halo", "moment_bytes", "moments"), info))
+        return dict(zip(("fast", "tile", "nslice", "tree_levels", "halo", "moment_bytes", "moments", "columns_per_launch"), info))
 
     def tile_items(self):
         """(items [n][4], ranges [tiles][2]) of the last two-pass launch table: grt_debug_tile_items (include/grt_ext.h)."""

@@ -270,6 +270,13 @@ int grt_dev_sync(Device_t device, void *stream)
     return GRTCODE_SUCCESS;
 }
 
+int grt_dev_mem_info(Device_t device, size_t *free_bytes, size_t *total_bytes)
+{
+    GRT_TRY(grt_dev_require(device));
+    GRT_TRY(grt_dev_check((int)hipMemGetInfo(free_bytes, total_bytes), "hipMemGetInfo"));
+    return GRTCODE_SUCCESS;
+}
+
 /* Events: "the uploads of this batch have left the staging buffer", so the host may refill it while the
    batch's kernels still run.  *ev is created on first use; waiting on an event that was never recorded
    returns at once. */

@@ -1624,6 +1624,9 @@ static int near_halo_bound(GasOptics_t const *go, int ncol, double w_top, double
     GrtColumnLayout const *lo = &im->layout;
     int const L = go->num_layers;
     double worst = 3.;
+    /* (a batch that runs in column groups -- launch_columns -- is bounded as a whole: every group gets the launch
+       parameters the undivided batch would have had) */
+    ncol = im->batch_cols > ncol ? im->batch_cols : ncol;
     for (int c = 0; c < ncol; ++c)
     {
         double const *cs = im->colstate_h + (size_t)c*lo->stride;
@@ -1659,7 +1662,8 @@ static int tile_ranges(GasOptics_t *go, int ncol, GrtGasOpticsArgs *a)
     GrtGasOpticsImpl *im = impl_of(go);
     GrtColumnLayout const *lo = &im->layout;
     double pmax = 0.;
-    for (int c = 0; c < ncol && im->colstate_h != NULL; ++c)
+    int const ncol_all = im->batch_cols > ncol ? im->batch_cols : ncol;     /* (see near_halo_bound) */
+    for (int c = 0; c < ncol_all && im->colstate_h != NULL; ++c)
     {
         double const *lay = im->colstate_h + (size_t)c*lo->stride + lo->off_lay;
         for (int i = 0; i < go->num_layers; ++i)
@@ -1760,7 +1764,7 @@ static int tile_ranges(GasOptics_t *go, int ncol, GrtGasOpticsArgs *a)
     char const *env = getenv("GRT_TILE_ITEMS");
     if (im->n_items > 0 && im->nslice == 0 && a->tree_levels == 0 && a->probe == NULL && !grt_deterministic()
         && !(env != NULL && env[0] == '0')
-        && tiles*(uint64_t)go->num_layers*(uint64_t)ncol < 16384)
+        && tiles*(uint64_t)go->num_layers*(uint64_t)ncol_all < 16384)
     {
         a->tile_items = im->tile_items_d;
         a->n_items = im->n_items;
@@ -1793,6 +1797,8 @@ EXTERN int grt_deterministic(void)
 int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_stride, GrtGasOpticsArgs *a)
 {
     GrtGasOpticsImpl *im = impl_of(go);
+    /* (tiles, slices and bounds are chosen for the BATCH, also where it runs in column groups: launch_columns) */
+    int const ncol_tune = im->batch_cols > ncol ? im->batch_cols : ncol;
     memset(a, 0, sizeof(*a));
     a->lines = im->store;
     a->lay = im->layout;
@@ -1809,7 +1815,7 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
     if (im->fast == 1 || im->fast == 3)
     {
         /* fused form: far wings by cell moments where the grid's windows are wide enough for that */
-        auto_tune(go, ncol, im->fast == 3 ? 2 : 1, &a->tile, &a->nslice);
+        auto_tune(go, ncol_tune, im->fast == 3 ? 2 : 1, &a->tile, &a->nslice);
         a->rcap = 12;
         if (im->fast == 3)
         {
@@ -1880,7 +1886,12 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
             if (grt_gas_optics_mp_applicable(a))
             {
                 size_t const need = sizeof(float)*(size_t)a->gmom_stride*(size_t)go->num_layers*(size_t)ncol;
-                if (need > im->gmom_bytes)
+                im->scratch_per_column = sizeof(float)*(size_t)a->gmom_stride*(size_t)go->num_layers;
+                if (im->sizing_only)
+                {
+                    a->gmom = (float *)8;       /* (launch_columns asks what a column needs before it divides a batch) */
+                }
+                else if (need > im->gmom_bytes)
                 {
                     GRT_TRY(grt_dev_free(go->device, im->gmom));
                     im->gmom = NULL;
@@ -1888,7 +1899,10 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
                     GRT_TRY(grt_dev_alloc(go->device, (void **)&im->gmom, need));
                     im->gmom_bytes = need;
                 }
-                a->gmom = im->gmom;
+                if (!im->sizing_only)
+                {
+                    a->gmom = im->gmom;
+                }
             }
             else
             {
@@ -1903,7 +1917,7 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
             a->rcap = 12;
             if (a->fast == 1)
             {
-                auto_tune(go, ncol, 1, &a->tile, &a->nslice);
+                auto_tune(go, ncol_tune, 1, &a->tile, &a->nslice);
                 if (!grt_gas_optics_mp_applicable(a))
                 {
                     a->fast = 2;
@@ -1913,7 +1927,7 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
     }
     if (a->fast != 1 && a->fast != 3)
     {
-        auto_tune(go, ncol, 0, &a->tile, &a->nslice);
+        auto_tune(go, ncol_tune, 0, &a->tile, &a->nslice);
     }
     if (im->probe != NULL && a->fast == 3 && (a->tree_levels == 0 || a->mom_terms == 12))
     {
@@ -2002,29 +2016,42 @@ static int launch_sweep_columns(GasOptics_t *go, int ncol, double *tau_dev, uint
     return GRTCODE_SUCCESS;
 }
 
-static int launch_columns(GasOptics_t *go, int ncol, double *tau_dev, uint64_t tau_col_stride)
+/* Scratch the library may hold for one launch's cell moments [bytes]: GRT_SCRATCH_CAP_MB in the environment (read at every
+   launch: tests), else 60 % of what the device has free plus what this object already holds -- asked once per object and
+   again whenever a batch needs more than the object has. */
+static size_t scratch_cap(GasOptics_t *go)
 {
     GrtGasOpticsImpl *im = impl_of(go);
-    if (go->optical_depth_method != line_sample)
+    char const *env = getenv("GRT_SCRATCH_CAP_MB");
+    if (env != NULL && atof(env) > 0.)
     {
-        return launch_sweep_columns(go, ncol, tau_dev, tau_col_stride);
+        return (size_t)(atof(env)*1048576.);
     }
+    size_t free_b = 0, total_b = 0;
+    if (grt_dev_mem_info(go->device, &free_b, &total_b) != GRTCODE_SUCCESS)
+    {
+        return (size_t)-1;
+    }
+    return (size_t)(0.6*(double)free_b) + im->gmom_bytes;
+}
+
+static int launch_column_group(GasOptics_t *go, int c0, int ncol, double *tau_dev, uint64_t tau_col_stride)
+{
+    GrtGasOpticsImpl *im = impl_of(go);
     void *s = grt_dev_stream(go->device);
     GrtGasOpticsArgs args;
-    GRT_TRY(grt_fill_gas_args(go, ncol, tau_dev, tau_col_stride, &args));
-    GRT_TRY(grt_dev_upload(go->device, im->colstate_d, im->colstate_h,
-                           sizeof(double)*im->layout.stride*ncol, s));
-    GRT_TRY(grt_dev_event_record(go->device, &im->colstate_uploaded, s));
+    GRT_TRY(grt_fill_gas_args(go, ncol, tau_dev + (size_t)c0*tau_col_stride, tau_col_stride, &args));
+    args.colstate = im->colstate_d + (size_t)c0*im->layout.stride;
     if (args.nslice > 1)
     {
         /* slices accumulate with atomics (launch.c:61 zeroes tau in every case) */
-        GRT_TRY(grt_dev_zero(go->device, tau_dev, sizeof(double)*tau_col_stride*ncol, s));
+        GRT_TRY(grt_dev_zero(go->device, tau_dev + (size_t)c0*tau_col_stride, sizeof(double)*tau_col_stride*ncol, s));
     }
     int const tag = im->profile_tag ? im->profile_tag : (args.nw <= 10000 ? 1 : 2);
     /* (with a work list, "nslice" reports the largest number of pieces a tile was cut into) */
     long long const info[8] = {args.fast, args.tile, args.tile_items != NULL ? im->items_cut : args.nslice, args.tree_levels, args.fast == 3 ? args.halo : 0,
                                args.fast == 3 ? (long long)im->gmom_bytes : 0,
-                               (args.fast == 1 || args.fast == 3) ? (args.mom_terms ? args.mom_terms : 8) : 0, 0};
+                               (args.fast == 1 || args.fast == 3) ? (args.mom_terms ? args.mom_terms : 8) : 0, ncol};
     memcpy(im->last_launch, info, sizeof(info));
     int rc;
     if (args.fast == 3)
@@ -2039,6 +2066,56 @@ static int launch_columns(GasOptics_t *go, int ncol, double *tau_dev, uint64_t t
         grt_profile_end(s, slot);
     }
     GRT_TRY(grt_dev_check(rc, "gas optics kernel"));
+    return GRTCODE_SUCCESS;
+}
+
+/* The batch's columns, all in one launch -- or, where the cell moments of all of them would not fit the device (18.7 GB
+   per column on the 0.001 cm-1 grid), in the largest column groups that do, one after the other on the stream through
+   the same scratch.  Every group is launched with the parameters the undivided batch would have had (its bounds are the
+   batch's: near_halo_bound, tile_ranges), so a column's optical depths do not depend on how the batch was divided -- bit
+   for bit in the deterministic mode.  The reference has no such limit either: one column per call, whatever the grid
+   (gas_optics.c:433-454). */
+static int launch_columns(GasOptics_t *go, int ncol, double *tau_dev, uint64_t tau_col_stride)
+{
+    GrtGasOpticsImpl *im = impl_of(go);
+    if (go->optical_depth_method != line_sample)
+    {
+        return launch_sweep_columns(go, ncol, tau_dev, tau_col_stride);
+    }
+    void *s = grt_dev_stream(go->device);
+    GRT_TRY(grt_dev_upload(go->device, im->colstate_d, im->colstate_h,
+                           sizeof(double)*im->layout.stride*ncol, s));
+    GRT_TRY(grt_dev_event_record(go->device, &im->colstate_uploaded, s));
+    im->batch_cols = ncol;
+    int group = ncol;
+    if (ncol > 1 && im->fast == 3)
+    {
+        /* what would one launch of the whole batch need? */
+        GrtGasOpticsArgs probe;
+        im->sizing_only = 1;
+        im->scratch_per_column = 0;
+        int const rc = grt_fill_gas_args(go, ncol, tau_dev, tau_col_stride, &probe);
+        im->sizing_only = 0;
+        GRT_TRY(rc);
+        size_t const per = im->scratch_per_column;
+        if (per > 0 && per*(size_t)ncol > im->gmom_bytes)
+        {
+            size_t const cap = scratch_cap(go);
+            if (per*(size_t)ncol > cap)
+            {
+                group = (int)(cap/per);
+                group = group < 1 ? 1 : group;
+            }
+        }
+    }
+    int rc = GRTCODE_SUCCESS;
+    for (int c0 = 0; c0 < ncol && rc == GRTCODE_SUCCESS; c0 += group)
+    {
+        rc = launch_column_group(go, c0, ncol - c0 < group ? ncol - c0 : group, tau_dev, tau_col_stride);
+    }
+    im->last_launch[7] = group;         /* columns per launch (grt_gas_optics_last_launch) */
+    im->batch_cols = 0;
+    GRT_TRY(rc);
     return GRTCODE_SUCCESS;
 }
 

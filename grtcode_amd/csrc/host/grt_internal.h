@@ -52,6 +52,7 @@ int grt_dev_upload(Device_t device, void *dst, void const *src, size_t bytes, vo
 int grt_dev_download(Device_t device, void *dst, void const *src, size_t bytes, void *stream);
 int grt_dev_copy(Device_t device, void *dst, void const *src, size_t bytes, void *stream);
 int grt_dev_sync(Device_t device, void *stream);
+int grt_dev_mem_info(Device_t device, size_t *free_bytes, size_t *total_bytes);     /* hipMemGetInfo */
 int grt_dev_is_host_memory(void const *p);              /* 1: host memory the device writes in place */
 int grt_dev_sync_if_host_memory(Device_t device, void const *p, void *stream);
 void *grt_dev_upload_stream(Device_t device);           /* a stream of its own for the inputs of a one-column solver call */
@@ -101,6 +102,9 @@ typedef struct GrtGasOpticsImpl
     void *bins_block;              /* device allocation backing bins.w / bins.l / bins.r / bins.tau */
     float *gmom;                   /* two-pass moment kernel: [ncol][L][8][n] cell moments */
     size_t gmom_bytes;
+    size_t scratch_per_column;     /* ... what ONE column of the current form needs of it (set by grt_fill_gas_args) */
+    int sizing_only;               /* grt_fill_gas_args: work the launch parameters out, allocate nothing */
+    int batch_cols;                /* columns of the batch in colstate_h while launch_columns runs it in groups, else 0 */
     long long last_launch[8];    /* grt_gas_optics_last_launch */
     /* spectral tables on device, each [n]: */
     double *h2o_tables;            /* [4][n] F296,S296,CKDF,CKDS or NULL */

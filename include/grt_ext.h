@@ -69,7 +69,9 @@ EXTERN int grt_gas_optics_tune(GasOptics_t *gas_optics, int tile, int nslice, in
 
 /* What the last line-by-line launch of this object actually ran (the fused forms fall back 3 -> 1 -> 2 where a
  * grid does not suit them): info = {fast, tile, nslice, coarse levels of the cell hierarchy (0: single-level
- * far field), near-field halo in grid points, moment-buffer bytes, moments per cell (8; 12 on sparse fine grids), 0}.  Windows of more than 200 points a side
+ * far field), near-field halo in grid points, moment-buffer bytes, moments per cell (8; 12 on sparse fine grids), columns per
+ * launch -- a batch whose cell moments would not fit the device runs in column groups, one after the other through the same
+ * scratch, with the launch parameters of the undivided batch (GRT_SCRATCH_CAP_MB in the environment: a cap for tests)}.  Windows of more than 200 points a side
  * (grids finer than ~0.12 cm-1) make fast = 3 sum the far field through a hierarchy of cells. */
 EXTERN int grt_gas_optics_last_launch(GasOptics_t const *gas_optics, long long info[8]);
 

@@ -48,3 +48,46 @@ def test_fast_form_within_tolerance(tmp_path, oracle, lib, device):
     assert np.max(np.abs(fast - want) / scale) < 2e-6      # fp32 core re-association: ~1e-7 per term
     opt.destroy()
     go.destroy()
+
+
+@pytest.mark.parametrize("case", [(2000.0, 2060.0, 0.002, 2500, 9, "cell hierarchy, twelve moments (the 0.001 cm-1 class)"),
+                                  (600.0, 900.0, 1.0, 6000, 13, "single-level gather, lean first pass")],
+                         ids=["tree_0.002cm", "flat_1cm"])
+def test_batch_that_does_not_fit_runs_in_column_groups_with_the_same_bits(tmp_path, lib, device, case):
+    """VERDICT r4, task 5: the cell moments of a batch are sized per column (18.7 GB a column on the 0.001 cm-1 grid), so the
+    library divides a batch that would not fit into column groups itself -- same launch parameters as the undivided batch,
+    hence, in the deterministic mode, the same optical depths to the last bit.  GRT_SCRATCH_CAP_MB caps the scratch here."""
+    import os
+    w0, wn, dw, nlines, V, _ = case
+    band = Band(str(tmp_path), w0, wn, dw, nlines)
+    ncol = 8
+    cols = [syn.profile(20 + c, V) for c in range(ncol)]
+    go, grid = band.gas_optics(device, V, from_file=False)
+    go.tune(fast=3)
+    gcols, keep = api.make_columns(cols, MOL_ORDER, cfc_order=(0, 1))
+    buf = api.DeviceBuffer(device, 8 * ncol * (V - 1) * band.nw)
+    api.check(lib.grt_set_deterministic(1))
+    try:
+        api.check(lib.grt_optical_depth_batch(C.byref(go.c), C.byref(gcols), buf.ptr))
+        whole = buf.to_host((ncol, V - 1, band.nw)).copy()
+        info = go.last_launch()
+        assert info["fast"] == 3 and info["columns_per_launch"] == ncol, info
+        per_col = info["moment_bytes"] / ncol
+        # room for three columns' moments: groups of 3, 3, 2
+        os.environ["GRT_SCRATCH_CAP_MB"] = str(3.5 * per_col / 1048576.0)
+        go2, _ = band.gas_optics(device, V, from_file=False)         # (a fresh object: nothing allocated yet)
+        go2.tune(fast=3)
+        api.check(lib.grt_optical_depth_batch(C.byref(go2.c), C.byref(gcols), buf.ptr))
+        grouped = buf.to_host((ncol, V - 1, band.nw))
+        info2 = go2.last_launch()
+        assert info2["columns_per_launch"] == 3 and info2["moment_bytes"] <= 3.5 * per_col, info2
+        assert (info2["tile"], info2["nslice"], info2["tree_levels"], info2["halo"], info2["moments"]) == \
+               (info["tile"], info["nslice"], info["tree_levels"], info["halo"], info["moments"])
+        assert np.array_equal(grouped, whole)
+        go2.destroy()
+    finally:
+        os.environ.pop("GRT_SCRATCH_CAP_MB", None)
+        api.check(lib.grt_set_deterministic(-1))
+    assert np.all(whole > 0.0)
+    buf.free()
+    go.destroy()
