@@ -1853,6 +1853,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
             // x), by what the wave's lines have there: only Lorentzians but for a line's own point | region 1 throughout
             // | the point's region picks the formula.  Near-centre points (|x| < XLIM1) are left out and noted in ncm. ----
             v2f v[7];
+            v2f xq[7];                                      // x^2 of the seven points (the regimes fill what they test)
             unsigned ncm[2] = {0u, 0u};
 #ifdef GRT_ABL_NOSLOTS
             for (int k = 0; k < 7; ++k) v[k] = splat2(0.f);
@@ -1880,6 +1881,7 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                 v[3] = sel2(nc[0], nc[1], splat2(0.f), (amp*num)*rcp2(den));
                 ncm[0] = nc[0] ? 8u : 0u;
                 ncm[1] = nc[1] ? 8u : 0u;
+                xq[3] = xq0;
             }
 #ifdef GRT_ABL_NOSLOTS
             else if (hi < 0)
@@ -1888,7 +1890,6 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
 #endif
             {
                 v2f const acl = amp*cl;
-                v2f xq[7];
 #pragma unroll
                 for (int k = 0; k < 7; ++k)
                 {
@@ -1949,6 +1950,45 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                     }
                 }
             }
+#ifndef GRT_NO_LEAN_REGION2
+            // ---- Humlicek region 2 (XLIM2 = 6.8 - y <= |x| < XLIM1, RFM_voigt.c:113, :187-199) is evaluated HERE (round 5):
+            // like region 1 it is one rational function of x^2 -- one reciprocal, nothing that cancels -- and out there the
+            // line shape falls as y/x^2 (e^-x^2 is below 3e-15 of it for any y > 1e-12): a relative error of x comes back
+            // doubled, not 2 x^2-fold as in the Doppler core, so the loop's own fp32 x and y (1e-7) do.  Only |x| < XLIM2
+            // (regions 3 and 4) still needs the reference's x and y to the bit and goes to the queues: 0.41 instead of 0.78
+            // points per line and layer on the 1 cm-1 shortwave band.
+            //   K = RSQRPI REPWID x RSQRPI y (E0 + XQ (E2 + XQ (E4 + XQ)))/(H0 + XQ (H2 + XQ (H4 + XQ (H6 + XQ)))) = cl num/den
+            if (ballot_b((ncm[0] | ncm[1]) != 0u) != 0ull)
+            {
+                v2f const xl2 = 6.8f - y;
+                v2f const x2q = {xl2.x > 0.f ? xl2.x*xl2.x : 0.f, xl2.y > 0.f ? xl2.y*xl2.y : 0.f};     // XLIM2^2 (0: XLIM2 <= 0)
+                v2f const h0 = pk_fma(yq, pk_fma(yq, pk_fma(yq, 6.0f + yq, splat2(10.5f)), splat2(4.5f)), splat2(0.5625f));
+                v2f const h2 = pk_fma(yq, pk_fma(yq, pk_fma(yq, splat2(4.0f), splat2(6.0f)), splat2(9.0f)), splat2(-4.5f));
+                v2f const h4 = pk_fma(yq, pk_fma(yq, splat2(6.0f), splat2(-6.0f)), splat2(10.5f));
+                v2f const h6 = pk_fma(yq, splat2(4.0f), splat2(-6.0f));
+                v2f const e0 = pk_fma(yq, pk_fma(yq, 5.5f + yq, splat2(8.25f)), splat2(1.875f));
+                v2f const e2 = pk_fma(yq, pk_fma(yq, splat2(3.0f), splat2(1.0f)), splat2(5.25f));
+                v2f const e4 = 0.75f*h6;
+                v2f const acl2 = amp*cl;
+                // (which points can be core points at all: the tile's regime)
+                unsigned const kset = (tfl & (kTfLreg | kTfNcOne)) ? 0x08u : ((tfl & kTfNcThree) ? 0x1cu : 0x7fu);
+#pragma unroll
+                for (int k = 0; k < 7; ++k)
+                {
+                    if (!(kset & (1u << k)))
+                    {
+                        continue;
+                    }
+                    v2f const q = xq[k];
+                    bool const r2[2] = {bool(((ncm[0] & (1u << k)) != 0u) & (q.x >= x2q.x)), bool(((ncm[1] & (1u << k)) != 0u) & (q.y >= x2q.y))};
+                    v2f const den = pk_fma(q, pk_fma(q, pk_fma(q, h6 + q, h4), h2), h0);
+                    v2f const num = pk_fma(q, pk_fma(q, e4 + q, e2), e0);
+                    v[k] = sel2(r2[0], r2[1], (acl2*num)*rcp2(den), v[k]);
+                    ncm[0] = r2[0] ? (ncm[0] & ~(1u << k)) : ncm[0];
+                    ncm[1] = r2[1] ? (ncm[1] & ~(1u << k)) : ncm[1];
+                }
+            }
+#endif
             // into the row's eight slots (grid points cr - 3 .. cr + 4): a line of cell cr + o has its points in slots o .. 6 + o
 #ifdef GRT_ABL_NOREDUCE
             if (hi < 0)
