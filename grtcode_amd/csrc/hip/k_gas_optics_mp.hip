@@ -1613,7 +1613,9 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
             int const hi = nrel - base < 128u ? (int)(nrel - base) : 128;
             float4 const ra0 = next_a0, ra1 = next_a1, rb0 = next_b0, rb1 = next_b1;
             uint2 const rcc = next_c;
+#ifdef GRT_LEAN_FETCH_EARLY
             lean_fetch(base + walk_stride);
+#endif
             // (the tile's flags, tested where they are used: hoisted out of the loop, each test became a lane mask in two
             // scalar registers, spilled to a vector register's lanes and read back with v_readlane at every use)
             unsigned tfl = tflags;
@@ -2104,6 +2106,13 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
                 }
                 rawcount += __popcll(mk);
             }
+            // (the next block's records are asked for HERE, not at the top of this block -- round 4's place: eighteen registers
+            // less alive across the queues' code, no scratch; the other waves cover the loads -- G1 shortwave 76.0 -> 75.4 ms.
+            // Measured and dropped in the same round: the waves' leftover class queues evaluated as one list per workgroup
+            // -- 75.4 ms either way)
+#ifndef GRT_LEAN_FETCH_EARLY
+            lean_fetch(base + walk_stride);
+#endif
         }
     };
 
