@@ -319,7 +319,9 @@ __device__ __forceinline__ double voigt_near(float xi, float y)
     double k = 0.0;
     // (round 4: the -T[J] and +T[J] branches of a term side by side in packed registers -- half the fp32 instructions of
     // this region -- were measured SLOWER in the lean kernel, whose waves are at their register limit: longwave launch
-    // 32.3 -> 34.8 ms, shortwave 90.1 -> 91.8; so was one shared copy of the queues' evaluation code behind a call: 98.7)
+    // 32.3 -> 34.8 ms, shortwave 90.1 -> 91.8; so was one shared copy of the queues' evaluation code behind a call: 98.7.
+    // Round 5, with the kernel at 127 registers and no scratch, the packed form again: shortwave 75.5 -> 74.4 ms, longwave
+    // 22.9 -> 23.4 -- within the noise of the pair; left out)
     if (ONLY == 1 || (ONLY < 0 && abx <= xlim4))
     {
 #pragma unroll

@@ -1579,8 +1579,11 @@ static void auto_tune(GasOptics_t const *go, int ncol, int moments, int *tile, i
            128-cell 36.5, 64-cell 34.9 (scripts/tile_sweep.sh). */
         /* ONE column of that band with the round-4 lean first pass: 128-cell tiles in four slices 0.559 ms, 64-cell tiles
            in two 0.594, 256-cell in eight 0.581 (scripts/sweep_one_column.py) -- a lone column stops at 128 */
+        /* Round 5 (all layers on the lean loop, region 2 inside it): with many columns the wide tile is ahead again -- G1
+           longwave, 64 columns per launch: 256-cell tiles 22.35 ms, 128-cell 22.6, 64-cell 22.9-23.2 (a workgroup's fixed
+           costs weigh more against a faster loop) -- so tiles are narrowed only to make workgroups, not for the L2's sake */
         while (moments == 2 && want > (ncol == 1 ? 128 : 64) && per_cell*(double)(want/2) >= 6000.
-               && (((nw + want - 1)/want)*(uint64_t)go->num_layers*(uint64_t)ncol < 16384 || per_cell*(double)want > 24000.))
+               && ((nw + want - 1)/want)*(uint64_t)go->num_layers*(uint64_t)ncol < 16384)
         {
             want >>= 1;
         }
