@@ -643,7 +643,14 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("cols") == round(cols_launch) and tj.get("fast") == args.fast and (lw_grid[2], sw_grid[2]) == (1.0, 1.0) \
+                import hashlib
+                live_sha = hashlib.sha256(b"".join(open(os.path.join(ROOT, "grtcode_amd", "csrc", "hip", f), "rb").read()
+                                                   for f in ("k_gas_optics_mp.hip", "gas_optics_dev.h"))).hexdigest()
+                if tj.get("kernel_source_sha256") != live_sha:
+                    # (counters of another version of the kernel: not carried -- ADVICE r4)
+                    traffic_src = (f"profiles/traffic_latest.json (round tag {tj.get('tag')}) was taken on another version of the "
+                                   "kernel source: its counters are not carried into this line")
+                elif tj.get("cols") == round(cols_launch) and tj.get("fast") == args.fast and (lw_grid[2], sw_grid[2]) == (1.0, 1.0) \
                         and args.lw_lines is None and args.sw_lines is None:
                     traffic = tj["gas_optics_sw"]["hbm_bytes_per_launch"]
                     traffic_src = f"profiles/traffic_latest.json: rocprofv3 --pmc passes of this command, round tag {tj.get('tag')} (not measured in this run)"
@@ -713,6 +720,21 @@ def main():
                                    "far_field_lw": ms[6][0] / args.steps, "far_field_sw": ms[7][0] / args.steps,
                                    "lw_solver": ms[3][0] / args.steps, "sw_solver": ms[4][0] / args.steps,
                                    "clear_sky_optics": ms[5][0] / args.steps},
+            # the LONGWAVE column-band against HBM with SURVEY §8(d)'s algorithmic bytes B_band (line store once, 11 tables,
+            # tau/omega/g written once and read once, fluxes out) -- on the ~3M-point grid (--lw-dw 0.001) this is the
+            # north-star's "fraction of HBM roofline": the far-field gather there is gas_optics_tree_kernel (+ the coarse levels)
+            "roofline_hbm_lw_band": (lambda b_lw, ms1, ms6, ms3: {
+                "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_column": b_lw,
+                "far_field_kernel": "gas_optics_tree_kernel (cell hierarchy)" if lw_grid[2] < 0.12 else "gas_optics_far_kernel",
+                "far_field_ms_per_launch": ms6, "first_pass_ms_per_launch": ms1, "solver_ms_per_launch": ms3,
+                "achieved_far_field": b_lw * cols_launch / (ms6 * 1e-3) / 1e9 if ms6 > 0 else None,
+                "frac_far_field": b_lw * cols_launch / (ms6 * 1e-3) / 1e9 / HBM_PEAK_GBS if ms6 > 0 else None,
+                "achieved_band": b_lw * cols_launch / ((ms1 + ms6 + ms3) * 1e-3) / 1e9 if ms1 + ms6 + ms3 > 0 else None,
+                "frac_band": b_lw * cols_launch / ((ms1 + ms6 + ms3) * 1e-3) / 1e9 / HBM_PEAK_GBS if ms1 + ms6 + ms3 > 0 else None,
+                "note": "frac_far_field prices the gather ALONE against the whole band's algorithmic bytes (VERDICT r4, task 3); "
+                        "frac_band the band's three kernels together"})(
+                60.0 * S["lw"] + n_lw * (8.0 * 11 + 24.0 * L + 24.0 * L + 16.0 * V),
+                ms[1][0] / max(ms[1][1], 1), ms[6][0] / max(ms[6][1], 1), ms[3][0] / max(ms[3][1], 1)),
             "sample_fluxes_col0": {"rlut": fluxes[0, 0], "rlus": fluxes[0, 1], "rlds": fluxes[0, 4],
                                    "rsut": fluxes[0, 6], "rsdt": fluxes[0, 9], "rsds": fluxes[0, 10]},
         }
