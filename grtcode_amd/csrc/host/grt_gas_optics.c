@@ -2020,8 +2020,8 @@ static int launch_sweep_columns(GasOptics_t *go, int ncol, double *tau_dev, uint
 }
 
 /* Scratch the library may hold for one launch's cell moments [bytes]: GRT_SCRATCH_CAP_MB in the environment (read at every
-   launch: tests), else 60 % of what the device has free plus what this object already holds -- asked once per object and
-   again whenever a batch needs more than the object has. */
+   launch: tests), else 60 % of what the device had free, plus what this object already held, when a batch of this object
+   first did not fit. */
 static size_t scratch_cap(GasOptics_t *go)
 {
     GrtGasOpticsImpl *im = impl_of(go);
@@ -2030,12 +2030,18 @@ static size_t scratch_cap(GasOptics_t *go)
     {
         return (size_t)(atof(env)*1048576.);
     }
-    size_t free_b = 0, total_b = 0;
-    if (grt_dev_mem_info(go->device, &free_b, &total_b) != GRTCODE_SUCCESS)
+    if (im->scratch_cap_bytes == 0)
     {
-        return (size_t)-1;
+        /* asked ONCE per object: a cap that followed the free memory would grow with every batch (what the object holds is
+           no longer free), and every growth is a hipFree + hipMalloc of tens of GB -- seconds on this runtime */
+        size_t free_b = 0, total_b = 0;
+        if (grt_dev_mem_info(go->device, &free_b, &total_b) != GRTCODE_SUCCESS)
+        {
+            return (size_t)-1;
+        }
+        im->scratch_cap_bytes = (size_t)(0.6*(double)free_b) + im->gmom_bytes;
     }
-    return (size_t)(0.6*(double)free_b) + im->gmom_bytes;
+    return im->scratch_cap_bytes;
 }
 
 static int launch_column_group(GasOptics_t *go, int c0, int ncol, double *tau_dev, uint64_t tau_col_stride)
