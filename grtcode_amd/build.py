@@ -21,12 +21,12 @@ SO = os.path.join(LIB, "libgrtcode_hip.so")
 HOST_SRC = ["grt_error.c", "grt_util.c", "grt_grid.c", "grt_device.c", "grt_optics.c", "grt_tips.c",
             "grt_gas_optics.c", "grt_solvers.c", "grt_pipeline.c", "grt_multi.c", "grt_clouds.c"]
 NOT_IN_SO = {"grt_clouds"}      # libclouds.a only: a maintainer links the reference's own libclouds.a in its place
-HIP_SRC = ["k_gas_optics.hip", "k_gas_optics_mp.hip", "k_gas_optics_sweep.hip", "k_optics.hip", "k_longwave.hip", "k_shortwave.hip"]
+HIP_SRC = ["k_gas_optics.hip", "k_gas_optics_mp.hip", "k_gas_optics_far.hip", "k_gas_optics_sweep.hip", "k_optics.hip", "k_longwave.hip", "k_shortwave.hip"]
 
 # the reference's archive names (*/src/Makefile.am): which objects go where
 ARCHIVES = {
     "libgrtcode_utilities.a": ["grt_error", "grt_util", "grt_grid", "grt_device", "grt_optics", "k_optics"],
-    "libgas_optics.a": ["grt_tips", "grt_gas_optics", "k_gas_optics", "k_gas_optics_mp", "k_gas_optics_sweep"],
+    "libgas_optics.a": ["grt_tips", "grt_gas_optics", "k_gas_optics", "k_gas_optics_mp", "k_gas_optics_far", "k_gas_optics_sweep"],
     "liblongwave.a": ["k_longwave"],
     "libshortwave.a": ["k_shortwave"],
     # solvers' host entry points and the batched pipeline reference both bands
@@ -84,7 +84,7 @@ def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     force = force or _flags_changed()
     headers = [os.path.join(ROOT, "include", h) for h in ("grtcode_hip_api.h", "grt_ext.h")]
-    headers += [os.path.join(CSRC, "grt_kernels.h"), os.path.join(CSRC, "hip", "gas_optics_dev.h"),
+    headers += [os.path.join(CSRC, "grt_kernels.h"), os.path.join(CSRC, "hip", "gas_optics_dev.h"), os.path.join(CSRC, "hip", "gas_optics_mp_dev.h"),
                 os.path.join(CSRC, "hip", "optics_dev.h"), os.path.join(CSRC, "host", "grt_internal.h"), os.path.join(CSRC, "host", "grt_molecule_table.h")]
     objs, jobs = [], []
     for f in HOST_SRC:

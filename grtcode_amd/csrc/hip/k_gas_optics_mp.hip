@@ -27,427 +27,17 @@
 // Humlicek region 1 (XLIM1 <= |x| < XLIM0) is evaluated inside the ring whenever it lies within R (or travels
 // with the moments: near_radius); regions 2-4 go through per-wave queues, one per class of formula, and those
 // points are skipped by the ring, whose tokens are fp32 sums of at most 16 lines' values (fp64 from there on).
-#include <type_traits>
-#include "gas_optics_dev.h"
+#include "gas_optics_mp_dev.h"
+
+// k_gas_optics_far.hip: the second pass
+extern "C" size_t grt_far_lds_bytes(int tile, int ncell, int fsteps, int num_slots, int cell_shift);
+extern "C" size_t grt_tree_lds_bytes(int tile, int num_slots, int ntab);
+extern "C" int grt_tree_gather_tile(void);
+extern "C" int grt_tree_gather_ntab(int tile, int halo);
+extern "C" int grt_tree_gather_by_wave(long long fsteps);
+extern "C" int grt_launch_far_field(void *stream, GrtGasOpticsArgs const *b, long long fsteps, int shift);
 
 namespace {
-
-constexpr int kMom = 8;         // moments per cell
-#ifndef GRT_FAR_GRADED_MIN
-#define GRT_FAR_GRADED_MIN 64   // single-level gather: windows wider than this many points a side take fewer terms for far cells
-#endif
-constexpr int kMomWide = 12;    // ... of the tree form on sparse lines (args.mom_terms)
-
-// The series is geometric in |z|/r: K terms leave (|z|/r)^K.  Near field out to r = sep |z|max keeps that at 7e-8.
-__host__ __device__ inline double moment_separation(int terms)
-{
-    return terms == kMomWide ? 3.95 : 7.8;        // 3.95^-12 = 7e-8 = 7.8^-8
-}
-// LDS a workgroup of these kernels may ask for.  gfx950 would let one workgroup declare 160 KB (opt-in per kernel), but every
-// form here lives on several workgroups per CU (five of 27 KB for the 1 cm-1 first pass, four of 38 KB for the 0.001 cm-1
-// one): a form that does not fit 64 KB hands over to the next one -- single level -> cell hierarchy at windows of 200
-// points a side, eight moments in LDS -> twelve straight to global memory -- and those crossovers were MEASURED earlier than
-// the cap would force them, so the cap only guards odd hand-made tilings (tests, grt_gas_optics_tune).
-constexpr size_t kLdsPerWorkgroup = 64*1024;
-constexpr int kRcap = 12;       // widest near field taken for the sake of region 1 unless the host says otherwise (args.rcap)
-constexpr int kPowTable = 128;  // tabulated temperature exponents n = k/100 (kernels.c:105)
-constexpr int kCellLoop = 3;    // passes of the in-register moment reduction before falling back to per-lane adds
-
-// (old = 0 with bound_ctrl: every control used here -- rotations, mirrors, quad permutations -- has a source lane for every
-// lane, so the value is the same as with old = v, and in this form the compiler folds the move into the instruction that
-// uses it: one v_add_f32_dpp instead of v_mov_b32_dpp + v_add_f32)
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v)
-{
-    int const b = __float_as_int(v);
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, b, CTRL, 0xf, 0xf, true));
-}
-
-// row_ror:1 (DPP control 0x121): rotation by one lane inside each row of 16 lanes
-__device__ __forceinline__ double row_pass(double v)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x121, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x121, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-
-template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v)
-{
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
-}
-
-// Wave-wide integer max as a scalar: rotations inside the rows of 16 lanes (every lane of a row
-// ends up with the row's extreme, whatever the direction of row_ror), then the four rows on the
-// scalar unit.
-__device__ __forceinline__ int wave_max_s(int v)
-{
-    v = max(v, dpp_i<0x121>(v));
-    v = max(v, dpp_i<0x122>(v));
-    v = max(v, dpp_i<0x124>(v));
-    v = max(v, dpp_i<0x128>(v));
-    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
-               max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
-}
-
-// a + (a of the lane's partner under CTRL) where the lane's bit is clear, b + (b of the partner) where it is set -- the bit
-// being one that splits a row of 16 lanes into whole banks of four (8: row_mirror partner, lanes 8-15 = banks 2, 3;
-// 4: row_half_mirror partner, lanes 4-7 and 12-15 = banks 1, 3).  A DPP instruction writes only the banks its bank_mask
-// names, so two adds do what two selects and an add did.  (Inline assembly: the compiler's DPP folding takes full masks
-// only.  s_nop: a DPP operand may not be read within two wait states of its write, and the hazard recogniser does not
-// look into assembly.)
-template <int BIT>
-__device__ __forceinline__ float dpp_add_by_bit(float a, float b)
-{
-    static_assert(BIT == 8 || BIT == 4, "");
-    float w;
-    if constexpr (BIT == 8)
-    {
-        asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_mirror row_mask:0xf bank_mask:0x3\n\t"
-            "v_add_f32_dpp %0, %2, %2 row_mirror row_mask:0xf bank_mask:0xc" : "=&v"(w) : "v"(a), "v"(b));
-    }
-    else
-    {
-        asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-            "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa" : "=&v"(w) : "v"(a), "v"(b));
-    }
-    return w;
-}
-
-// Row sums of eight values per lane, transposed: on return lane l holds the sum over its row of 16
-// lanes of m[4 b3 + 2 b2 + b1] (b_i = bits of l & 15).  Three halving exchanges (partner = lane ^ 15,
-// lane ^ 7, lane ^ 3: row_mirror, row_half_mirror, reversed quad), each lane keeping the half of the
-// values its bit selects and adding the partner's copy of that half, then one exchange with lane ^ 1.
-// 14 selects + 8 DPP adds instead of 8 x 4 DPP adds.
-__device__ __forceinline__ float row_sum_transposed(float const (&m)[8], bool b3, bool b2, bool b1)
-{
-    (void)b3; (void)b2;
-    float w[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-    {
-        w[i] = dpp_add_by_bit<8>(m[i], m[i + 4]);       // b3 clear: m[i] + partner's m[i]; set: m[i + 4] + partner's (row_mirror)
-    }
-    float x[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-    {
-        x[i] = dpp_add_by_bit<4>(w[i], w[i + 2]);       // likewise by b2 (row_half_mirror)
-    }
-    float const keep = b1 ? x[1] : x[0];
-    float const send = b1 ? x[0] : x[1];
-    float const y = keep + dpp_f<0x1B>(send);           // quad_perm:[3,2,1,0]
-    return y + dpp_f<0xB1>(y);                          // quad_perm:[1,0,3,2]
-}
-
-// Row sums of eight values per lane for TWO groups of lanes at once: every lane hands in its eight values and says
-// whether it belongs to group 0, group 1 or neither.  On return lane l of the row holds, for group b3 (bit 3 of l & 15),
-// the sum over the group's lanes of m[l & 7]: sixteen sums in sixteen lanes, none twice.  The first exchange
-// (partner = lane ^ 15) sends each half of the row the other group's values; the three halving exchanges of
-// row_sum_transposed follow inside the halves.  15 DPP adds + 30 selects, where two calls of row_sum_transposed take
-// 18 + 28 + 16 for the masks -- and one chain of dependent exchanges instead of two.
-__device__ __forceinline__ float row_sum_transposed_pair(float const (&m)[8], bool in0, bool in1, bool b3, bool b2, bool b1, bool b0)
-{
-    bool const keep_mine = b3 ? in1 : in0, send_mine = b3 ? in0 : in1;
-    float w[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-    {
-        float const keep = keep_mine ? m[i] : 0.f;
-        float const send = send_mine ? m[i] : 0.f;
-        w[i] = keep + dpp_f<0x140>(send);               // row_mirror: the partner is in the other half
-    }
-    float x[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-    {
-        float const keep = b2 ? w[i + 4] : w[i];
-        float const send = b2 ? w[i] : w[i + 4];
-        x[i] = keep + dpp_f<0x141>(send);               // row_half_mirror: lane ^ 7, other b2
-    }
-    float y[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-    {
-        float const keep = b1 ? x[i + 2] : x[i];
-        float const send = b1 ? x[i] : x[i + 2];
-        y[i] = keep + dpp_f<0x1B>(send);                // quad_perm:[3,2,1,0]: lane ^ 3, other b1
-    }
-    float const keep = b0 ? y[1] : y[0];
-    float const send = b0 ? y[0] : y[1];
-    return keep + dpp_f<0xB1>(send);                    // quad_perm:[1,0,3,2]: lane ^ 1, other b0
-}
-
-// The same for two groups whose contributions every lane holds in two arrays (the lean line loop: a lane's lines of the
-// row's first cell in g0, of the next cell in g1).  On return lane l of the row holds, for group b3, the row's sum of
-// value l & 7.
-__device__ __forceinline__ float row_sum_two_groups(float const (&g0)[8], float const (&g1)[8], bool b3, bool b2, bool b1, bool b0)
-{
-    (void)b3; (void)b2;
-    float w[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-    {
-        w[i] = dpp_add_by_bit<8>(g0[i], g1[i]);         // row_mirror: the partner is in the other half
-    }
-    float x[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-    {
-        x[i] = dpp_add_by_bit<4>(w[i], w[i + 4]);       // row_half_mirror
-    }
-    float y[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-    {
-        float const keep = b1 ? x[i + 2] : x[i];
-        float const send = b1 ? x[i] : x[i + 2];
-        y[i] = keep + dpp_f<0x1B>(send);                // quad_perm:[3,2,1,0]
-    }
-    float const keep = b0 ? y[1] : y[0];
-    float const send = b0 ? y[0] : y[1];
-    return keep + dpp_f<0xB1>(send);                    // quad_perm:[1,0,3,2]
-}
-
-// The lean line loop's near-centre points wait here until a wave has 64 of them (line, strength S(T) N_s, accumulator index)
-// ... and the blocks with lines the lean loop hands over to the general one are listed here (block start, lanes per p)
-constexpr int kRawCap = 128;
-constexpr int kLeanListCap = 12;
-constexpr int kLeanMaxP = 4;
-// The lean loop's per-layer tables sit at FIXED distances from one LDS address (room for kLeanSlots molecule slots, whatever
-// the object has: a launch with more slots takes the general loop), so that one address register per index serves all the
-// tables that index reads -- the distances go into the ds_read's offset field instead of a vector add per table.
-constexpr int kLeanSlots = 16;
-struct LeanTables
-{
-    float ps[kLeanSlots], p_ps[kLeanSlots], dop[kLeanSlots];          // per slot: ps | p - ps | sqrt(ln 2) x doppler factor
-    float qn_m[kLeanSlots*GRT_MAX_ISO], qn_e[kLeanSlots*GRT_MAX_ISO]; // per (slot, isotopologue): N_s/Q as mantissa | exponent
-    float ptab[kPowTable];                                            // (296/T)^(k/100)
-};
-struct LeanRaw
-{
-    unsigned long long xl_mask[kWaves][kLeanListCap][kLeanMaxP];
-    unsigned j[kWaves][kRawCap];             // the line
-    float amp[kWaves][kRawCap];              // S(T) N_s
-    float delta[kWaves][kRawCap];            // its pressure shift coefficient
-    unsigned idx[kWaves][kRawCap];           // accumulator index f - A0 | the point's k << 12 | the line's molecule slot << 16
-                                             // | the index of its temperature exponent << 22
-    unsigned xl_base[kWaves][kLeanListCap];
-};
-
-// Near-centre points (Humlicek regions 1-4 inside XLIM1) wait in per-wave LDS queues, one queue per
-// class of formula (voigt_class), so that a batch of 64 points runs ONE formula with all lanes busy:
-// evaluated unsorted, a batch pays for every formula present in it (~4x the work of the usual mix).
-// Four classes: regions 1-2 | region 4 inner sums | region 4 outer sums | region 3.  Region 3 used to share class 0: a
-// batch then ran both formulas whenever one lane wanted region 3 -- ten polynomials of y for a handful of points
-// (1 cm-1 shortwave launch 14.8 -> 14.4 ms).  Entries are 14 bytes so that four queues fit where three of 22 did.
-constexpr int kClasses = 3;
-constexpr int kClassesSplit = 4;
-// entries per (class, wave): batches of 64 leave at most 63 behind, so 64 is the least a queue can have.  At four
-// workgroups per CU 80 ... 96 measured the same (104 cost the fourth workgroup: 14.4 -> 16.6 ms); at five (see
-// gas_optics_mp_kernel_w5) the LDS they take is what decides: 64 entries.  The tree form's first pass is short of LDS
-// anyway (0.001 cm-1: four workgroups per CU instead of three, 42 -> 39 ms) and its pushes mostly come as full batches
-#ifndef GRT_MP_QUEUE
-#define GRT_MP_QUEUE 64
-#endif
-constexpr int kMpQueue = GRT_MP_QUEUE;
-constexpr int kMpQueueTree = 64;
-
-template <int CAP, int NCLS>
-struct MpQueue
-{
-    static constexpr int capacity = CAP;
-    static constexpr int classes = NCLS;
-    float amp[NCLS][kWaves][CAP];      // S(T)*N_s of the line times RSQRPI*REPWID (RFM_voigt.c:278), rounded to fp32 once
-    float xi[NCLS][kWaves][CAP];
-    float y[NCLS][kWaves][CAP];
-    unsigned short idx[NCLS][kWaves][CAP];   // accumulator index f - F0 (< 2^15); top bit: beyond the near field, where the
-                                             // moments supply the Lorentzian -- to be taken back
-};
-using MpQueueFlat = MpQueue<kMpQueue, kClassesSplit>;
-using MpQueueTree = MpQueue<kMpQueueTree, kClassesSplit>;
-
-// (a call, not inline code: the lines that need it -- exponents that are not hundredths -- are rare, and its registers
-// would count against every wave)
-__device__ __attribute__((noinline)) double exp_fp64_call(double x)
-{
-    return exp_fp64(x);
-}
-
-constexpr int binomial(int n, int k)
-{
-    int r = 1;
-    for (int i = 1; i <= k; ++i)
-    {
-        r = r*(n - k + i)/i;
-    }
-    return r;
-}
-
-// a Voigt line with a region 1 at all (RFM_voigt.c:97,122-126)
-__device__ __forceinline__ bool voigt_reg1(float y, bool lorentz)
-{
-    return !lorentz & (y > 0.000001f);
-}
-
-// Near-field radius R of a (cell tile, layer), the same for every line of the tile.
-// moment series: every line has |z| <= sqrt(1/4 + eta_max^2), eta_max from the largest half-width any
-// line of the store can have in this layer (kernels.c:105-106: per molecule, the largest air- and
-// self-broadening coefficients times this layer's partial pressures); ratio |z|/(R+1) <= 0.128 keeps the
-// 8-term remainder below 1e-7 of the far-wing value (0.253 with 12 terms: moment_separation).  If that asks
-// for more than the window, the whole window is "near" (R = fsteps) and no moments are formed.
-// ms_l: this layer's [slot][4] block in LDS.
-//
-// Humlicek region 1 (XLIM1 <= |x| < XLIM0 <= 123.4 Doppler widths) differs from the Lorentzian the moments carry,
-//     K1 - K0 = cl [ 1.5/q^2 + (1.25 - 5 Y)/q^3 + (10.5 Y^2 - 8.75 Y + 0.875)/q^4 + ... ],   q = x^2, Y = y^2
-// (RFM_voigt.c:172-183 against :103, both expanded in 1/q).  Where every line of the (tile, layer) has y <= 4 the
-// three terms are FOLDED INTO THE MOMENTS (`corrected`: with x = (r - delta) wr they are multiples of
-// (r - delta)^-4, ^-6, ^-8, expanded about the cell centre like the Lorentzian), so the near field only has to
-// reach where that series is good -- X1 = max(13, 8 y_max) Doppler widths, which also covers XLIM1 <= 12.85 --
-// instead of all of region 1.  Cost: the series goes on beyond a line's XLIM0, where the reference has switched
-// back to the Lorentzian: 1.5 cl/x^4 there, 1e-4 of the line's value at XLIM0 and falling as x^-4 -- 1e-7 of the
-// line's own peak at y = 4 (3e-8 at y = 2); against a layer maximum that is itself a wing value see kFoldWrMax.
-// Elsewhere (some line of the tile may have y > 4: low wavenumbers, high pressures) region 1 is evaluated inside
-// the ring where it lies within rcap grid steps (a performance choice: region-1 points beyond R are picked up
-// line by line in pre-pass 2; shrinking R below that was measured slower).
-// [F0l, F1l): the cells of the tile (one-pass form: including the fsteps cells either side it prepares).
-constexpr double kCorrectedYmax = 4.;
-constexpr double kEtaSevenPoints = 0.3;  // Lorentz widths up to this many grid steps keep the seven-point near field (near_radius)
-constexpr float kFoldWrMax = 25.f;      // region 1 is folded for lines within kFoldWrMax/2 Doppler widths of their grid point (see the kernel)
-__device__ int near_radius(GrtGasOpticsArgs const &a, double const *lay, double const *ms_l, long long F0l, long long F1l,
-                           int fsteps, bool *use_moments, bool *corrected, double *zmax = nullptr)
-{
-    // max over slots of yair_max (P - Ps) + yself_max Ps (Lorentz width at 296 K); of the Doppler factor; of their
-    // quotient, molecule by molecule (y = gamma/(nu dop))
-    double gmax = 0., dop = 0., gd_max = 0.;
-    for (int sl = 0; sl < a.lay.num_slots; ++sl)
-    {
-        double const g = (double)a.lines.yair_max[sl]*fabs(ms_l[sl*4 + 1]) + (double)a.lines.yself_max[sl]*fabs(ms_l[sl*4]);
-        gmax = fmax(gmax, g);
-        dop = fmax(dop, ms_l[sl*4 + 3]);
-        gd_max = fmax(gd_max, ms_l[sl*4 + 3] > 0. ? g/ms_l[sl*4 + 3] : 1e300);
-    }
-    double const tfac = exp(a.lines.nmax*fabs(lay[3]));
-    double const gamma_max = gmax*tfac;
-    double const eta = gamma_max/a.wres;
-    if (zmax != nullptr)
-    {
-        *zmax = sqrt(0.25 + eta*eta);       // every line of the layer has |z| = |delta + i eta| below this
-    }
-    int r_mp = (int)ceil(moment_separation(a.mom_terms)*sqrt(0.25 + eta*eta)) - 1;
-    // Seven points serve wider lines than the |z| bound says (round 5).  What the series leaves out is the line's
-    // A Im(z^9)/eta r^-10 and beyond, and for |delta| <= 1/2 that is LARGEST for a narrow line half-way between two grid
-    // points (9 x 0.5^8 = 0.035, against |z|^9 sin(9 theta)/eta = 0.016 at eta = 0.24): with R = 3 the worst single-line
-    // remainder is the same 6e-7 of the line's far-wing value for every eta up to 0.3 as for eta -> 0
-    // (tests/test_moment_series.py).  The bound alone had the twelve lowest layers of a 1 013 mb atmosphere at R = 4
-    // -- O2's self-broadened lines, 0.5 cm-1/atm x 0.209 -- and with that a fifth of the 1 cm-1 grids' (tile, layer)s on
-    // the general line loop at six times the lean loop's cost per line.
-    if (a.tree_levels == 0 && r_mp == 4 && eta <= kEtaSevenPoints)
-    {
-        r_mp = 3;
-    }
-    int const r_lo = r_mp < 3 ? 3 : r_mp;
-    double const w_hi = a.w0 + (double)(F1l + fsteps)*a.wres;
-    double const alpha_max = 0.83255461115*w_hi*dop;
-    double const reach = 123.4*alpha_max/(0.832554611*a.wres) + 0.51;
-    int const rcap = a.rcap > 0 ? a.rcap : kRcap;
-    int const r_reg1 = reach < (double)rcap ? (int)reach : rcap;
-    int R = r_lo > r_reg1 ? r_lo : r_reg1;
-    *corrected = false;
-    // largest y = sqrt(ln 2) gamma/alpha = gamma/(nu dop) any line of the tile can have in this layer, molecule by
-    // molecule (kernels.c:105-106,127)
-    double const w_lo = a.w0 + ((double)F0l - 1.)*a.wres;
-    double const y_num = 1.001*gd_max*tfac;
-    if (w_lo > 0. && y_num <= kCorrectedYmax*w_lo)
-    {
-        double const y_max = y_num/w_lo;
-        double const x1 = fmax(13., 8.*y_max);
-        double const reach_c = x1*alpha_max/(0.832554611*a.wres) + 1.51;
-        int const rc = reach_c < 1e9 ? (int)reach_c : 1000000000;
-        int const Rc = r_lo > rc ? r_lo : rc;
-        if (Rc + 4 <= fsteps && (Rc < R || reach >= (double)(rcap + 1)))
-        {
-            *corrected = true;
-            R = Rc;
-        }
-    }
-    *use_moments = (R + 4 <= fsteps);
-    *corrected = *corrected && *use_moments;
-    return *use_moments ? R : fsteps;
-}
-
-// ---- the cell hierarchy of the tree form (described above gas_optics_tree_kernel): sizes, offsets, the shift of
-// a child's moments to its parent's centre ----
-constexpr int kMaxLevels = 20;
-constexpr int kDirectTile = 512;    // tree form, cell tiles wider than this (sparse lines): moments added straight to global memory
-static_assert(kDirectTile <= 2*kBlock, "the in-place coarser levels take one parent per thread");
-
-__host__ __device__ inline uint64_t level_cells(uint64_t nw, int l)
-{
-    return (nw + ((uint64_t)1 << l) - 1) >> l;
-}
-
-// offset of level l in the (column, layer) block of gmom, floats; `terms` moments per cell.  Level i has room for
-// nw_pad >> i cells, nw_pad = nw rounded up to a whole number of top-level cells, so that the offset is a closed
-// form -- the gather's scalar walk computes it instead of looking it up (an LDS read shares its counter with the
-// scalar loads and would make every cell wait for the one before).
-__host__ __device__ inline uint64_t level_offset(uint64_t nw, int l, int terms, int levels)
-{
-    uint64_t const p2 = 2*(((nw + ((uint64_t)1 << levels) - 1) >> levels) << levels);
-    return (p2 - (p2 >> l))*terms;
-}
-
-// Layout of a (column, layer) block of the hierarchy.  A cell's number counts the cells of the levels before its own
-// (level l begins at cell level_offset(nw, l, 1, levels)).  Eight moments per cell: [cell][8].  TWELVE (sparse lines, the
-// 0.001 cm-1 class of grids; round 5): TWO PLANES -- the first four moments of every cell, [cell][4], then the other
-// eight, [cell][8].  The gather's lanes take only four terms from the cells at the far ends of their windows (one
-// 16-byte load each), and with 48-byte cells those loads still drew every line of the level-0 and level-1 cells through
-// the memory system once per side: 56 of the 100 GB that a 0.001 cm-1 column moved (profiles/traffic_latest.json, r4).
-template <int K>
-struct CellStore
-{
-    float *a, *b;
-    __host__ __device__ CellStore(float *blk, uint64_t total_cells)
-        : a(blk), b(K == kMomWide ? blk + total_cells*4 : blk + 4) {}
-    __host__ __device__ float *lo(uint64_t cell) const { return a + cell*(K == kMomWide ? 4 : K); }      // moments 1-4
-    __host__ __device__ float *hi(uint64_t cell) const { return b + cell*(K == kMomWide ? 8 : K); }      // moments 5 ..
-    __host__ __device__ float *moment(uint64_t cell, int k) const { return k < 4 ? lo(cell) + k : hi(cell) + (k - 4); }
-};
-// cells of all the levels of a block (levels 0 .. `levels`)
-__host__ __device__ inline uint64_t hierarchy_cells(uint64_t nw, int levels)
-{
-    return level_offset(nw, levels + 1, 1, levels);
-}
-
-// |C(k, j) (1/4)^(k-j) (1/2)^j|: the parent's m_k from a child's m_j (1-based, j <= k); the lower child's takes the
-// sign (-1)^(k-j), the upper child's is positive
-constexpr float shift_coef(int k, int j)
-{
-    double v = (double)binomial(k, j);
-    for (int i = 0; i < k - j; ++i) v *= 0.25;
-    for (int i = 0; i < j; ++i) v *= 0.5;
-    return (float)v;
-}
-
-// a parent's scaled moments from its two children's (the coefficients are literals in the code)
-template <int K>
-__device__ __forceinline__ void shift_pair(float const (&lo)[K], float const (&hi)[K], float (&m)[K])
-{
-#pragma unroll
-    for (int k = 1; k <= K; ++k)
-    {
-        float v = 0.f;
-#pragma unroll
-        for (int j = 1; j <= k; ++j)
-        {
-            float const cf = shift_coef(k, j);
-            v = fmaf(((k - j) & 1) ? -cf : cf, lo[j - 1], v);
-            v = fmaf(cf, hi[j - 1], v);
-        }
-        m[k - 1] = v;
-    }
-}
 
 // CLASS: the queue; ONLY: the formula(s) voigt_near generates for it
 template <int CLASS, int ONLY, typename Queue>
@@ -2417,820 +2007,6 @@ void gas_optics_mp_probe_kernel(GrtGasOpticsArgs a, long long fsteps_ll, unsigne
     mp_kernel_body<true, false, kMom, LEAN, true>(a, fsteps_ll, ngroups, perm_stride, ncell, nacc, halo);
 }
 
-// Second pass of the two-pass form: workgroup = (tile of grid points, layer, column).  Stages the moments
-// of the cells within fsteps of the tile, gathers for every point the series of the cells at distance
-// R(cell's tile) < |f - c| <= fsteps, adds the near fields the first pass left in tau and the continua, and
-// writes tau.  cell_shift: log2 of the first pass's cell-tile size.
-__global__ __launch_bounds__(kBlock) void gas_optics_far_kernel(GrtGasOpticsArgs a, long long fsteps_ll, int cell_shift, int ncell)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int const fsteps = (int)fsteps_ll;
-    double *acc = reinterpret_cast<double *>(smem);                               // [tile]
-    double *ms_l = acc + a.tile;                                                  // [num_slots][4]
-    double *q_l = ms_l + 4*a.lay.num_slots;                                       // [num_slots][GRT_MAX_ISO] (unused here)
-    float *mom = reinterpret_cast<float *>(q_l + GRT_MAX_ISO*a.lay.num_slots);    // [ncell][kMom]: cell-major, as in global memory
-    float *invr = mom + (size_t)kMom*ncell;                                       // [fsteps + 1]
-    int *rtab = reinterpret_cast<int *>(invr + fsteps + 1);                       // [cell tiles touched]
-    int const tid = threadIdx.x;
-    int const layer = blockIdx.y, col = blockIdx.z;
-    long long const nw = (long long)a.nw;
-    long long const F0l = (long long)blockIdx.x*a.tile;
-    long long const F1l = (F0l + a.tile < nw) ? F0l + a.tile : nw;
-    int const F0 = (int)F0l, F1 = (int)F1l;
-    double const *cs = a.colstate + (uint64_t)col*a.lay.stride;
-    double const *lay = cs + a.lay.off_lay + (uint64_t)layer*4;
-    double *out = a.tau + (uint64_t)col*a.tau_col_stride + (uint64_t)layer*a.nw;
-    stage_column_state(a, cs, layer, ms_l, q_l, tid);
-    for (int i = tid; i <= fsteps; i += kBlock)
-    {
-        invr[i] = i > 0 ? 1.0f/(float)i : 0.f;
-    }
-    int const cell0 = F0 - fsteps;
-    float const *gm = a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*a.gmom_stride;       // [cell][8]
-    // the cells' moments in LDS as two planes of 16-byte pieces: [2][cell][4] (moments 0-3 | 4-7) -- staged 16 bytes per
-    // lane, and read by the gather two ds_read_b128 per cell, neighbouring lanes neighbouring pieces (round 3 kept them
-    // [cell][8] as they lie in global memory: lanes then read every other piece)
-    for (int i = tid; i < 2*ncell; i += kBlock)
-    {
-        long long const c = (long long)cell0 + (i >> 1);
-        float4 const v = (c >= 0 && c < nw) ? reinterpret_cast<float4 const *>(gm + (uint64_t)c*kMom)[i & 1] : make_float4(0.f, 0.f, 0.f, 0.f);
-        reinterpret_cast<float4 *>(mom)[(i & 1)*ncell + (i >> 1)] = v;
-    }
-    for (int i = tid; i < F1 - F0; i += kBlock)
-    {
-        acc[i] = out[F0 + i];
-    }
-    __syncthreads();
-    int const t0 = (cell0 > 0 ? cell0 : 0) >> cell_shift;
-    int const t1 = (int)((F1l - 1 + fsteps < nw - 1 ? F1l - 1 + fsteps : nw - 1) >> cell_shift);
-    if (tid <= t1 - t0)
-    {
-        long long const c1 = ((long long)(t0 + tid + 1) << cell_shift);
-        bool um, cr;
-        rtab[tid] = near_radius(a, lay, ms_l, (long long)(t0 + tid) << cell_shift, c1 < nw ? c1 : nw, fsteps, &um, &cr);
-    }
-    __syncthreads();
-    int rmin = fsteps, rmax = 0;
-    for (int t = 0; t <= t1 - t0; ++t)
-    {
-        rmin = rtab[t] < rmin ? rtab[t] : rmin;
-        rmax = rtab[t] > rmax ? rtab[t] : rmax;
-    }
-    // The series is geometric in |z|/r, so the far cells need fewer terms: K terms leave (|z|max/r)^K, kept
-    // below the 7e-8 that 8 terms leave at the edge of the near field (ratio 0.128).  r >= rk[K] may use K terms.
-    int rk[kMom + 1];
-    for (int k = 0; k <= kMom; ++k)
-    {
-        rk[k] = fsteps + 1;
-    }
-    if (fsteps > GRT_FAR_GRADED_MIN)
-    {
-        bool um, cr;
-        double zmax;
-        near_radius(a, lay, ms_l, F0l, F1l, fsteps, &um, &cr, &zmax);
-        double const need[kMom + 1] = {1e30, 1e30, 1e30, 240., 61., 27., 15.6, 10.5, 0.};     // (7e-8)^(-1/K)
-        for (int k = 0; k <= kMom; ++k)
-        {
-            double const r = ceil(zmax*need[k]);
-            rk[k] = r < (double)(fsteps + 1) ? (int)r : fsteps + 1;
-        }
-    }
-    auto gather = [&](int i, int f, int r_from, int r_to, auto terms_tag) -> double
-    {
-        constexpr int TERMS = decltype(terms_tag)::value;
-        double sum = 0.;
-        for (int r = r_from; r <= r_to; ++r)
-        {
-            float const u = invr[r];
-            float4 const *ma = reinterpret_cast<float4 const *>(mom) + (i + fsteps - r);      // cell f - r: offset +r
-            float4 const *mb = reinterpret_cast<float4 const *>(mom) + (i + fsteps + r);      // cell f + r: offset -r
-            float a[8], b[8];
-            {
-                float4 const a0 = ma[0], b0 = mb[0];
-                a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w;
-                b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w;
-                if (TERMS > 4)
-                {
-                    float4 const a1 = ma[ncell], b1 = mb[ncell];
-                    a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
-                    b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
-                }
-            }
-            float pa = a[TERMS - 1], pb = b[TERMS - 1];
-#pragma unroll
-            for (int k = TERMS - 2; k >= 0; --k)
-            {
-                pa = fmaf(pa, u, a[k]);
-                pb = fmaf(pb, -u, b[k]);
-            }
-            if (r <= rmax)
-            {
-                // inside some tile's near field: each cell decides with its own tile's radius
-                int const ca = f - r, cb = f + r;
-                if (ca < 0 || r <= rtab[(ca >> cell_shift) - t0]) pa = 0.f;
-                if (cb >= nw || r <= rtab[(cb >> cell_shift) - t0]) pb = 0.f;
-            }
-            sum += (double)((pa + pb)*(u*u));
-        }
-        return sum;
-    };
-    // Short windows with one near-field radius all around (1 cm-1: always): a lane takes TWO neighbouring points f, f + 1.
-    // Point f wants the cells f - r and f + r, point f + 1 the cells f + 1 - r and f + 1 + r: of the four, f + 1 - r and
-    // f + r were read one step earlier (as f - (r - 1) and f + 1 + (r - 1)), so a step reads two cells for four series
-    // instead of four for two (5.4 -> 4.8 ms per shortwave launch of 64 columns).
-    bool const pair_form = fsteps <= GRT_FAR_GRADED_MIN && rmin == rmax && rmin >= 1;
-    if (pair_form)
-    {
-        // (all eight terms at every distance, as the general loop below takes them for short windows: the same terms per
-        // point, grouped by parity (below).  Fewer terms for the far cells -- five beyond r = 14 at 1 cm-1 -- were
-        // measured slower here: four short loops and their hand-overs instead of one, 4.84 -> 5.1 ms per shortwave launch)
-        float4 const *m4 = reinterpret_cast<float4 const *>(mom);
-        // A cell's series sum_k a_k u^k as its even and its odd part in the halves of one packed register,
-        //     {E, O} = {a6, a7};  {E, O} = {E, O} u^2 + {a4, a5};  ... + {a2, a3};  ... + {a0, a1}
-        // -- three v_pk_fma_f32 on the register pairs the 16-byte LDS reads deliver -- so that the cell at distance +r (u) and
-        // the one at -r (-u) are (E+ + u O+) + (E- - u O-): ten instructions a point and step instead of eighteen
-        // with Horner's rule per cell (round 4; another grouping of the same fp32 sums: 1e-7 of a far-field term)
-        auto eo = [](float4 const &lo, float4 const &hi, v2f uu2) -> v2f
-        {
-            v2f p = (v2f){hi.z, hi.w};
-            p = pk_fma(p, uu2, (v2f){hi.x, hi.y});
-            p = pk_fma(p, uu2, (v2f){lo.z, lo.w});
-            p = pk_fma(p, uu2, (v2f){lo.x, lo.y});
-            return p;
-        };
-        auto both = [](v2f plus, v2f minus, float u, float uu) -> double
-        {
-            float const m = fmaf(minus.y, -u, minus.x);        // E - u O: the cell on the other side
-            float const p = fmaf(plus.y, u, plus.x);
-            return (double)((p + m)*uu);
-        };
-        for (int i = 2*tid; i < F1 - F0; i += 2*kBlock)
-        {
-            double sum0 = 0., sum1 = 0.;
-            int const dn = i + fsteps, up = i + 1 + fsteps;           // LDS indices of cells f and f + 1
-            float4 l0 = m4[dn - rmin], l1 = m4[ncell + dn - rmin];    // cell f - rmin     = (f + 1) - (rmin + 1)
-            float4 u0 = m4[up + rmin], u1 = m4[ncell + up + rmin];    // cell f + 1 + rmin = f + (rmin + 1)
-            int r = rmin + 1;
-            for (; r + 1 <= fsteps; r += 2)
-            {
-                float4 const x0 = m4[dn - r], x1 = m4[ncell + dn - r], y0 = m4[up + r], y1 = m4[ncell + up + r];
-                {
-                    float const u = invr[r];
-                    float const uu = u*u;
-                    v2f const uu2 = splat2(uu);
-                    sum0 += both(eo(x0, x1, uu2), eo(u0, u1, uu2), u, uu);
-                    sum1 += both(eo(l0, l1, uu2), eo(y0, y1, uu2), u, uu);
-                }
-                l0 = m4[dn - r - 1]; l1 = m4[ncell + dn - r - 1]; u0 = m4[up + r + 1]; u1 = m4[ncell + up + r + 1];
-                {
-                    float const u = invr[r + 1];
-                    float const uu = u*u;
-                    v2f const uu2 = splat2(uu);
-                    sum0 += both(eo(l0, l1, uu2), eo(y0, y1, uu2), u, uu);
-                    sum1 += both(eo(x0, x1, uu2), eo(u0, u1, uu2), u, uu);
-                }
-            }
-            if (r <= fsteps)
-            {
-                float4 const x0 = m4[dn - r], x1 = m4[ncell + dn - r], y0 = m4[up + r], y1 = m4[ncell + up + r];
-                float const u = invr[r];
-                float const uu = u*u;
-                v2f const uu2 = splat2(uu);
-                sum0 += both(eo(x0, x1, uu2), eo(u0, u1, uu2), u, uu);
-                sum1 += both(eo(l0, l1, uu2), eo(y0, y1, uu2), u, uu);
-            }
-            acc[i] += sum0;
-            if (i + 1 < F1 - F0)
-            {
-                acc[i + 1] += sum1;
-            }
-        }
-    }
-    for (int i = tid; i < F1 - F0 && !pair_form; i += kBlock)
-    {
-        int const f = F0 + i;
-        int r = rmin + 1;
-        double sum = 0.;
-        auto upto = [&](int bound) { int const e = bound - 1 < fsteps ? bound - 1 : fsteps; return e; };
-        // (short windows, fsteps <= 64 -- 1 cm-1 has 22 cells a side -- take all terms in one loop: rk[] = fsteps + 1)
-        { int const e = upto(rk[7]); if (r <= e) { sum += gather(i, f, r, e, std::integral_constant<int, 8>{}); r = e + 1; } }
-        { int const e = upto(rk[6]); if (r <= e) { sum += gather(i, f, r, e, std::integral_constant<int, 7>{}); r = e + 1; } }
-        { int const e = upto(rk[5]); if (r <= e) { sum += gather(i, f, r, e, std::integral_constant<int, 6>{}); r = e + 1; } }
-        { int const e = upto(rk[4]); if (r <= e) { sum += gather(i, f, r, e, std::integral_constant<int, 5>{}); r = e + 1; } }
-        { int const e = upto(rk[3]); if (r <= e) { sum += gather(i, f, r, e, std::integral_constant<int, 4>{}); r = e + 1; } }
-        if (r <= fsteps) { sum += gather(i, f, r, fsteps, std::integral_constant<int, 3>{}); }
-        acc[i] += sum;
-    }
-    __syncthreads();
-    write_tile(a, acc, cs, col, layer, 0, F0l, F1l, tid);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Fine grids (windows of thousands of points): the far field through a hierarchy of cells.
-//
-// A level-l cell is 2^l consecutive level-0 cells, [j 2^l, (j+1) 2^l): its lines sit within h/2 = 2^(l-1) grid
-// steps of its centre C = j 2^l + 2^(l-1) - 1/2, so in units of h the series of the level-0 cells holds again,
-//
-//     sum_i A_i/((f - x_i)^2 + eta_i^2) = (1/h) u^2 (m_1 + u (m_2 + ...)),  u = h/(f - C),  m_k = M_k/h^k,
-//
-// wherever |f - C| >= 7.8 sqrt(h^2/4 + eta_max^2) (the same ratio 0.128 as level 0).  A parent's scaled moments
-// follow from its two children's by the binomial shift  m'_k = sum_{j<=k} C(k,j) (-+1/4)^(k-j) 2^-j m_j  -- one
-// 8 x 8 table for every level (moment_up_kernel).  A grid point must receive exactly the cells c with
-// R(c) < |f - c| <= fsteps (kernels.c:435-437: a line's window is its centre index +- fsteps), so the interval
-// on either side of it is tiled greedily with the largest aligned, admissible cells that stay inside the
-// window: ~8 cells per level, ~100 at 0.001 cm-1 instead of 50 000 (gas_optics_tree_kernel).
-// tests/test_moment_tree.py is the same construction in numpy.
-// ---------------------------------------------------------------------------------------------------------
-template <int K>
-__global__ __launch_bounds__(kBlock) void moment_up_kernel(float *gmom, uint64_t stride, uint64_t off_child, uint64_t n_child,
-                                                            uint64_t off_parent, uint64_t n_parent, uint64_t total_cells)
-{
-    uint64_t const j = (uint64_t)blockIdx.x*kBlock + threadIdx.x;
-    if (j >= n_parent)
-    {
-        return;
-    }
-    // (off_child, off_parent: the levels' first cells; total_cells: of the whole block -- CellStore)
-    CellStore<K> const cells(gmom + ((uint64_t)blockIdx.z*gridDim.y + blockIdx.y)*stride, total_cells);      // block of (column z, layer y)
-    bool const two = 2*j + 1 < n_child;
-    float lo[K], hi[K];
-#pragma unroll
-    for (int q = 0; q < K/4; ++q)
-    {
-        float const *pa = q == 0 ? cells.lo(off_child + 2*j) : cells.hi(off_child + 2*j) + 4*(q - 1);
-        float const *pb = q == 0 ? cells.lo(off_child + 2*j + 1) : cells.hi(off_child + 2*j + 1) + 4*(q - 1);
-        float4 const a = *reinterpret_cast<float4 const *>(pa);
-        float4 const b = two ? *reinterpret_cast<float4 const *>(pb) : make_float4(0.f, 0.f, 0.f, 0.f);
-        lo[4*q] = a.x; lo[4*q + 1] = a.y; lo[4*q + 2] = a.z; lo[4*q + 3] = a.w;
-        hi[4*q] = b.x; hi[4*q + 1] = b.y; hi[4*q + 2] = b.z; hi[4*q + 3] = b.w;
-    }
-    float m[K];
-    shift_pair<K>(lo, hi, m);
-#pragma unroll
-    for (int q = 0; q < K/4; ++q)
-    {
-        float *o = q == 0 ? cells.lo(off_parent + j) : cells.hi(off_parent + j) + 4*(q - 1);
-        *reinterpret_cast<float4 *>(o) = make_float4(m[4*q], m[4*q + 1], m[4*q + 2], m[4*q + 3]);
-    }
-}
-
-template <int K>
-__device__ __forceinline__ float cell_series(float const *cell, float u)
-{
-    float4 const *c4 = reinterpret_cast<float4 const *>(cell);
-    float4 v = c4[K/4 - 1];
-    float p = v.w;
-    p = fmaf(p, u, v.z); p = fmaf(p, u, v.y); p = fmaf(p, u, v.x);
-#pragma unroll
-    for (int q = K/4 - 2; q >= 0; --q)
-    {
-        v = c4[q];
-        p = fmaf(p, u, v.w); p = fmaf(p, u, v.z); p = fmaf(p, u, v.y); p = fmaf(p, u, v.x);
-    }
-    return p*(u*u);
-}
-
-// ... of cell number `cell` of a block (CellStore): TERMS = K, or 4 -- the first plane alone
-template <int K, int TERMS>
-__device__ __forceinline__ float cell_series_at(CellStore<K> const &cs, uint64_t cell, float u)
-{
-    float4 const lo = *reinterpret_cast<float4 const *>(cs.lo(cell));
-    float p = 0.f;
-    if constexpr (TERMS > 4)
-    {
-        float4 const *h4 = reinterpret_cast<float4 const *>(cs.hi(cell));
-#pragma unroll
-        for (int q = K/4 - 2; q >= 0; --q)
-        {
-            float4 const v = h4[q];
-            p = fmaf(p, u, v.w); p = fmaf(p, u, v.z); p = fmaf(p, u, v.y); p = fmaf(p, u, v.x);
-        }
-        p = fmaf(p, u, lo.w);
-    }
-    else
-    {
-        p = lo.w;
-    }
-    p = fmaf(p, u, lo.z); p = fmaf(p, u, lo.y); p = fmaf(p, u, lo.x);
-    return p*(u*u);
-}
-
-template <int K>
-__device__ __forceinline__ float cell_series_regs(float4 const (&c)[K/4], float u)
-{
-    float p = c[K/4 - 1].w;
-    p = fmaf(p, u, c[K/4 - 1].z); p = fmaf(p, u, c[K/4 - 1].y); p = fmaf(p, u, c[K/4 - 1].x);
-#pragma unroll
-    for (int q = K/4 - 2; q >= 0; --q)
-    {
-        p = fmaf(p, u, c[q].w); p = fmaf(p, u, c[q].z); p = fmaf(p, u, c[q].y); p = fmaf(p, u, c[q].x);
-    }
-    return p*(u*u);
-}
-
-// Largest level whose cell, with its near edge dm grid steps from the target, is admissible:
-// (dm + h/2)^2 >= sep^2 (h^2/4 + eta^2)  <=>  a h^2 - dm h - (dm^2 - sep^2 eta^2) <= 0,  a = (sep^2 - 1)/4.
-// eta2x = sep^2 eta^2, a4 = 4 a, r2a = 0.999/(2 a).
-__device__ __forceinline__ int admissible_level(float dm, float eta2x, float a4, float r2a)
-{
-    float const q = fmaf(dm, dm, -eta2x);
-    float const disc = fmaf(a4, q, dm*dm);
-    float const hmax = disc >= 0.f ? (dm + __builtin_amdgcn_sqrtf(fmaxf(disc, 0.f)))*r2a : 0.f;    // (no root: no level)
-    int const e = (__float_as_int(hmax) >> 23) - 127;           // floor(log2 hmax); below 1: level 0
-    return e > 0 ? e : 0;
-}
-
-// Second pass of the tree form, windows of a few hundred points (0.1 cm-1): workgroup = (tile of grid points, layer,
-// column); one grid point per thread and turn, every lane walking its own cells -- the stretches the lanes of a wave
-// could share (gas_optics_tree_kernel below) are no longer than the ones they could not.  cell_shift: log2 of the first pass's cell-tile size (near-field radii are per cell tile).
-template <int K>
-__global__ __launch_bounds__(kBlock) void gas_optics_tree_lane_kernel(GrtGasOpticsArgs a, long long fsteps_ll, int cell_shift, int ntab)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int const fsteps = (int)fsteps_ll;
-    double *acc = reinterpret_cast<double *>(smem);                               // [tile]
-    double *ms_l = acc + a.tile;                                                  // [num_slots][4]
-    double *q_l = ms_l + 4*a.lay.num_slots;                                       // [num_slots][GRT_MAX_ISO] (unused here)
-    int *rtab = reinterpret_cast<int *>(q_l + GRT_MAX_ISO*a.lay.num_slots);       // [ntab]
-    unsigned *loff = reinterpret_cast<unsigned *>(rtab + ntab);                   // [kMaxLevels + 1] level offsets (cells)
-    int const tid = threadIdx.x;
-    int const layer = blockIdx.y, col = blockIdx.z;
-    int const nw = (int)a.nw;
-    int const F0 = (int)blockIdx.x*a.tile;
-    int const F1 = F0 + a.tile < nw ? F0 + a.tile : nw;
-    double const *cs = a.colstate + (uint64_t)col*a.lay.stride;
-    double const *lay = cs + a.lay.off_lay + (uint64_t)layer*4;
-    double *out = a.tau + (uint64_t)col*a.tau_col_stride + (uint64_t)layer*a.nw;
-    CellStore<K> const gm(a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*a.gmom_stride, hierarchy_cells(a.nw, a.tree_levels));
-    stage_column_state(a, cs, layer, ms_l, q_l, tid);
-    for (int i = tid; i < F1 - F0; i += kBlock)
-    {
-        acc[i] = out[F0 + i];
-    }
-    if (tid <= a.tree_levels)
-    {
-        loff[tid] = (unsigned)level_offset(a.nw, tid, 1, a.tree_levels);       // the levels' first cells
-    }
-    __syncthreads();
-    // near-field radii of the cell tiles within `halo` of this tile (level-0 cells further away are far for sure)
-    int const t0 = (F0 - a.rcap > 0 ? F0 - a.rcap : 0) >> cell_shift;                 // (rcap: no near field is wider)
-    int const t1 = (F1 - 1 + a.rcap < nw - 1 ? F1 - 1 + a.rcap : nw - 1) >> cell_shift;
-    if (tid <= t1 - t0)
-    {
-        long long const c1 = ((long long)(t0 + tid + 1) << cell_shift);
-        bool um, cr;
-        rtab[tid] = near_radius(a, lay, ms_l, (long long)(t0 + tid) << cell_shift, c1 < nw ? c1 : nw, fsteps, &um, &cr);
-    }
-    __syncthreads();
-    int rmin = fsteps, rmax = 0;
-    for (int t = 0; t <= t1 - t0; ++t)
-    {
-        rmin = rtab[t] < rmin ? rtab[t] : rmin;
-        rmax = rtab[t] > rmax ? rtab[t] : rmax;
-    }
-    bool um, cr;
-    double zmax;
-    near_radius(a, lay, ms_l, F0, F1, fsteps, &um, &cr, &zmax);
-    double const sep = moment_separation(K);
-    float const eta2x = (float)(sep*sep*(zmax*zmax - 0.25))*1.0001f;
-    float const a4 = (float)(sep*sep - 1.), r2a = (float)(0.999*2./(sep*sep - 1.));
-    int const lmax = a.tree_levels;
-
-    for (int i = tid; i < F1 - F0; i += kBlock)
-    {
-        int const f = F0 + i;
-        double sum = 0.;
-        // cells above f: x = lowest level-0 cell not yet covered.  First the level-0 cells within the largest near
-        // field of the neighbourhood (each asks its own cell tile's radius, as the first pass did), then the greedy
-        // walk, free of branches: level = min(alignment, room to the window's edge, admissible, top level)
-        {
-            int const e = f + fsteps < nw - 1 ? f + fsteps : nw - 1;
-            int x = f + 1 + rmin;
-            int const xa = f + rmax < e ? f + rmax : e;
-            for (; x <= xa; ++x)
-            {
-                int const D = x - f;
-                if (D > rtab[(x >> cell_shift) - t0])
-                {
-                    float const u = -__builtin_amdgcn_rcpf((float)D);
-                    sum += (double)cell_series_at<K, K>(gm, (uint64_t)x, u);
-                }
-            }
-            while (x <= e)
-            {
-                int const D = x - f;
-                int const la = __builtin_ctz(x), le = 31 - __builtin_clz(e - x + 1);
-                int const l = min(min(la, le), min(admissible_level((float)D - 0.5f, eta2x, a4, r2a), lmax));
-                float const h = __int_as_float((127 + l) << 23), rh = __int_as_float((127 - l) << 23);
-                float const d = ((float)D - 0.5f) + 0.5f*h;                     // C - f
-                float const u = -h*__builtin_amdgcn_rcpf(d);
-                sum += (double)(cell_series_at<K, K>(gm, (uint64_t)loff[l] + (uint64_t)(x >> l), u)*rh);
-                x += 1 << l;
-            }
-        }
-        // cells below f: x = highest level-0 cell not yet covered
-        {
-            int const s = f - fsteps > 0 ? f - fsteps : 0;
-            int x = f - 1 - rmin;
-            int const xa = f - rmax > s ? f - rmax : s;
-            for (; x >= xa; --x)
-            {
-                int const D = f - x;
-                if (D > rtab[(x >> cell_shift) - t0])
-                {
-                    float const u = __builtin_amdgcn_rcpf((float)D);
-                    sum += (double)cell_series_at<K, K>(gm, (uint64_t)x, u);
-                }
-            }
-            while (x >= s)
-            {
-                int const D = f - x;
-                int const la = __builtin_ctz(x + 1), le = 31 - __builtin_clz(x - s + 1);
-                int const l = min(min(la, le), min(admissible_level((float)D - 0.5f, eta2x, a4, r2a), lmax));
-                float const h = __int_as_float((127 + l) << 23), rh = __int_as_float((127 - l) << 23);
-                float const d = ((float)D - 0.5f) + 0.5f*h;                     // f - C
-                float const u = h*__builtin_amdgcn_rcpf(d);
-                sum += (double)(cell_series_at<K, K>(gm, (uint64_t)loff[l] + (uint64_t)(x >> l), u)*rh);
-                x -= 1 << l;
-            }
-        }
-        acc[i] += sum;
-    }
-    __syncthreads();
-    write_tile(a, acc, cs, col, layer, 0, (long long)F0, (long long)F1, tid);
-}
-
-// A cell's moments through the scalar cache: issue now, wait later (scalar loads return in any order, so the only
-// wait there is is for all of them; the operands of scalar_wait tie the values to it).
-typedef float sfloat4 __attribute__((ext_vector_type(4)));
-
-// (lo: the cell's first four moments, hi: the others -- CellStore; eight moments: one 32-byte record, hi = lo + 4)
-template <int K>
-__device__ __forceinline__ void scalar_load_cell(float const *lo, float const *hi, sfloat4 (&c)[K/4])
-{
-    static_assert(K == 8 || K == 12, "two or three 16-byte pieces");
-    if constexpr (K == 12)
-    {
-        asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx4 %1, %4, 0x0\n\ts_load_dwordx4 %2, %4, 0x10"
-                     : "=&s"(c[0]), "=&s"(c[1]), "=&s"(c[2]) : "s"(lo), "s"(hi) : "memory");
-    }
-    else
-    {
-        (void)hi;
-        asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x10"
-                     : "=&s"(c[0]), "=&s"(c[1]) : "s"(lo) : "memory");
-    }
-}
-
-template <int K>
-__device__ __forceinline__ void scalar_wait(sfloat4 (&a)[K/4], sfloat4 (&b)[K/4], sfloat4 (&c)[K/4], sfloat4 (&d)[K/4])
-{
-    if constexpr (K == 12)
-    {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a[0]), "+s"(a[1]), "+s"(a[2]), "+s"(b[0]), "+s"(b[1]), "+s"(b[2]),
-                                              "+s"(c[0]), "+s"(c[1]), "+s"(c[2]), "+s"(d[0]), "+s"(d[1]), "+s"(d[2]) :: "memory");
-    }
-    else
-    {
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a[0]), "+s"(a[1]), "+s"(b[0]), "+s"(b[1]),
-                                              "+s"(c[0]), "+s"(c[1]), "+s"(d[0]), "+s"(d[1]) :: "memory");
-    }
-}
-
-template <int K>
-__device__ __forceinline__ float cell_series_s(sfloat4 const (&c)[K/4], float u)
-{
-    float p = c[K/4 - 1].w;
-    p = fmaf(p, u, c[K/4 - 1].z); p = fmaf(p, u, c[K/4 - 1].y); p = fmaf(p, u, c[K/4 - 1].x);
-#pragma unroll
-    for (int q = K/4 - 2; q >= 0; --q)
-    {
-        p = fmaf(p, u, c[q].w); p = fmaf(p, u, c[q].z); p = fmaf(p, u, c[q].y); p = fmaf(p, u, c[q].x);
-    }
-    return p*(u*u);
-}
-
-// Second pass of the tree form, windows of kTreeWaveMin points a side and more: workgroup = (tile of grid points,
-// layer, column); a WAVE owns one 64-point block fb .. fb + 63 (a point per lane) at a time and walks the cells once
-// for all of them.  Near fields are whole blocks with this gather (GrtGasOpticsArgs.near_block: the first pass took
-// every block a line's c +- R touches), so a cell is near or far for the 64 points alike.  Going up from the block:
-//   fhb + 1 + rmin .. fhb + rmax   shared: the level-0 cells that may lie in some cell tile's near field (each asks its
-//                         own tile's radius, as the first pass did); fhb = fb + 63
-//   [XA, E0s)             shared, XA = fhb + rmax + 1: greedy walk, level = min(alignment, room to E0s, admissible
-//                         for the block's last point, top level) -- what is admissible for the closest point is for
-//                         all.  Everything about the walk is wave-uniform: it runs on the scalar unit, the cells'
-//                         moments come through the scalar cache (48 bytes per wave and cell instead of 48 bytes per
-//                         LANE through the L1 -> register path), and the lanes only evaluate the series.
-//                         E0 - 1 = fb + fsteps: the last cell inside EVERY lane's window (kernels.c:435-437);
-//                         E0s: E0 rounded down to a multiple of 64
-//   [E0s, f + fsteps]     per lane: the < 128 cells that are in this lane's window but not in every lane's
-// and the mirror image going down.  Round 1's form (gas_optics_tree_lane_kernel) walks per lane: as long on the walk
-// (ctz, clz, the admissible level: ~30 instructions per cell) and on its loads (3 KB per wave and cell) as on the series.
-// cell_shift: log2 of the first pass's cell-tile size (near-field radii are per cell tile); gtile: this kernel's tile.
-template <int K>
-__global__ __launch_bounds__(kBlock) void gas_optics_tree_kernel(GrtGasOpticsArgs a, long long fsteps_ll, int cell_shift, int ntab,
-                                                                  int gtile)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int const fsteps = (int)fsteps_ll;
-    double *acc = reinterpret_cast<double *>(smem);                               // [gtile]
-    double *ms_l = acc + gtile;                                                   // [num_slots][4]
-    double *q_l = ms_l + 4*a.lay.num_slots;                                       // [num_slots][GRT_MAX_ISO] (unused here)
-    int *rtab = reinterpret_cast<int *>(q_l + GRT_MAX_ISO*a.lay.num_slots);       // [ntab]
-    int const tid = threadIdx.x;
-    int const layer = blockIdx.y, col = blockIdx.z;
-    int const nw = (int)a.nw;
-    int const F0 = (int)blockIdx.x*gtile;
-    int const F1 = F0 + gtile < nw ? F0 + gtile : nw;
-    double const *cs = a.colstate + (uint64_t)col*a.lay.stride;
-    double const *lay = cs + a.lay.off_lay + (uint64_t)layer*4;
-    double *out = a.tau + (uint64_t)col*a.tau_col_stride + (uint64_t)layer*a.nw;
-    CellStore<K> const gm(a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*a.gmom_stride, hierarchy_cells(a.nw, a.tree_levels));
-    stage_column_state(a, cs, layer, ms_l, q_l, tid);
-    for (int i = tid; i < F1 - F0; i += kBlock)
-    {
-        acc[i] = out[F0 + i];
-    }
-    __syncthreads();
-    // near-field radii of the cell tiles within `halo` (>= the widest near field + 64) of this tile: level-0 cells
-    // further away are far for sure
-    int const t0 = (F0 - a.halo > 0 ? F0 - a.halo : 0) >> cell_shift;
-    int const t1 = (F1 - 1 + a.halo < nw - 1 ? F1 - 1 + a.halo : nw - 1) >> cell_shift;
-    for (int t = tid; t <= t1 - t0; t += kBlock)
-    {
-        long long const c1 = ((long long)(t0 + t + 1) << cell_shift);
-        bool um, cr;
-        rtab[t] = near_radius(a, lay, ms_l, (long long)(t0 + t) << cell_shift, c1 < nw ? c1 : nw, fsteps, &um, &cr);
-    }
-    __syncthreads();
-    int rmin_v = fsteps, rmax_v = 0;
-    for (int t = 0; t <= t1 - t0; ++t)
-    {
-        rmin_v = rtab[t] < rmin_v ? rtab[t] : rmin_v;
-        rmax_v = rtab[t] > rmax_v ? rtab[t] : rmax_v;
-    }
-    int const rmin = __builtin_amdgcn_readfirstlane(rmin_v), rmax = __builtin_amdgcn_readfirstlane(rmax_v);
-    bool um, cr;
-    double zmax;
-    near_radius(a, lay, ms_l, F0, F1, fsteps, &um, &cr, &zmax);
-    double const sep = moment_separation(K);
-    int const lmax = a.tree_levels;
-    unsigned const p2 = (unsigned)(level_offset(a.nw, 1, 1, lmax) << 1);        // 2 nw_pad: level l starts at cell p2 - (p2 >> l)
-    // Admissible levels (see admissible_level): a cell of h = 2^l points whose first point is D grid steps from the
-    // target is admissible when (D - 1/2 + h/2)^2 >= sep^2 (h^2/4 + eta^2), i.e. D >= thr(l).  Lane l keeps thr(l), so
-    // "the highest admissible level at distance D" is one compare and the position of the ballot's top bit.  Level 0
-    // always passes beyond a near field (R + 1 >= sep |z|max), and the levels that pass are 0 .. the highest.
-    int thr;
-    {
-        int const l = tid & 63;
-        double const h = (double)((uint64_t)1 << (l <= lmax ? l : 0));
-        double const e2 = sep*sep*(zmax*zmax - 0.25)*1.0001;
-        double const t = (sqrt(0.25*sep*sep*h*h + e2) - 0.5*h)*1.000001 + 1.5;
-        thr = l == 0 ? (int)0x80000000 : (l <= lmax && t < 2e9) ? (int)ceil(t) : 0x7fffffff;
-    }
-    auto top_level = [&](int D) -> int      // D wave-uniform
-    {
-        return 63 - __builtin_clzll(__ballot(D >= thr));
-    };
-
-    // one lane's own cells [x, end) going up / (end, x] going down: greedy, free of branches
-    // (cap: a level admissible at the smallest distance the stretch has for any lane)
-    // (terms: K, or 4 where the stretch is so far away that four terms leave what K leave at the near field's edge)
-    auto walk_up = [&](int f, int x, int end, int cap, auto terms_tag) -> double
-    {
-        constexpr int TERMS = decltype(terms_tag)::value;
-        double sum = 0.;
-        while (x < end)
-        {
-            int const D = x - f;
-            int const la = __builtin_ctz(x), le = 31 - __builtin_clz(end - x);
-            int const l = min(min(la, le), cap);
-            float const h = __int_as_float((127 + l) << 23), rh = __int_as_float((127 - l) << 23);
-            float const d = ((float)D - 0.5f) + 0.5f*h;                     // C - f
-            float const u = -h*__builtin_amdgcn_rcpf(d);
-            sum += (double)(cell_series_at<K, TERMS>(gm, (uint64_t)(p2 - (p2 >> l)) + (uint64_t)(x >> l), u)*rh);
-            x += 1 << l;
-        }
-        return sum;
-    };
-    auto walk_down = [&](int f, int x, int end, int cap, auto terms_tag) -> double
-    {
-        constexpr int TERMS = decltype(terms_tag)::value;
-        double sum = 0.;
-        while (x > end)
-        {
-            int const D = f - x;
-            int const la = __builtin_ctz(x + 1), le = 31 - __builtin_clz(x - end);
-            int const l = min(min(la, le), cap);
-            float const h = __int_as_float((127 + l) << 23), rh = __int_as_float((127 - l) << 23);
-            float const d = ((float)D - 0.5f) + 0.5f*h;                     // f - C
-            float const u = h*__builtin_amdgcn_rcpf(d);
-            sum += (double)(cell_series_at<K, TERMS>(gm, (uint64_t)(p2 - (p2 >> l)) + (uint64_t)(x >> l), u)*rh);
-            x -= 1 << l;
-        }
-        return sum;
-    };
-
-    int const lane = tid & 63;
-    int const wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int cb = wave*64; cb < F1 - F0; cb += kBlock)
-    {
-        int const fb = F0 + cb;                                             // (wave-uniform from here to the lanes' f)
-        int const np = F1 - fb < 64 ? F1 - fb : 64;
-        int const fhi = fb + np - 1;                                        // the wave's points: fb .. fhi
-        int const fhb = fb + 63;                                            // its 64-point block: fb .. fhb (fb is a multiple of 64)
-        // Near fields are whole blocks here (near_block, first pass): a cell x above the block is near when
-        // x - fhb <= R(x's cell tile), below it when fb - x <= R -- the same answer for all 64 points.
-        // shared stretches: cells [XA, E0) above, (S0, XB] below; E0 - 1 / S0 + 1: the last cell inside EVERY lane's window
-        int const E0 = (fb + fsteps < nw - 1 ? fb + fsteps : nw - 1) + 1;
-        int const XA = fhb + rmax + 1 < E0 ? fhb + rmax + 1 : E0;
-        int const S0 = (fhi - fsteps > 0 ? fhi - fsteps : 0) - 1;
-        int const XB = fb - rmax - 1 > S0 ? fb - rmax - 1 : S0;
-        // The shared stretches end on multiples of 64 where the window has room for that: a lane's own stretch then
-        // begins on one, and an interval of n < 128 cells with one end on a multiple of 64 is popcount(n) <= 7 aligned
-        // cells; with both ends anywhere it takes up to twice that.
-        int E0s = E0, S0s = S0;
-        {
-            int const ea = E0 & ~63, sa = ((S0 + 64) & ~63) - 1;
-            if (XA <= ea) { E0s = ea; }
-            if (XB >= sa) { S0s = sa; }
-        }
-        int const f = fb + lane;
-        double sum = 0.;
-        int const cap_near = top_level(rmax + 1);                           // every far cell is at least this far from every point
-        int const cap_up = max(top_level(E0s - fhb), cap_near), cap_down = max(top_level(fb - S0s), cap_near);
-        // the lanes' own stretches hold cells of at most 64 points: |z| <= sqrt(32^2 + eta^2); four terms do where (|z|/D)^4 <= 7e-8
-        float const z2far = (float)(1024. + (zmax*zmax - 0.25));
-        float const dup = (float)(E0s - fhb) - 0.5f, ddn = (float)(fb - S0s) - 0.5f;
-        bool const four_up = z2far <= 2.6e-4f*dup*dup, four_down = z2far <= 2.6e-4f*ddn*ddn;
-        std::integral_constant<int, K> const all_terms{};
-        std::integral_constant<int, 4> const four_terms{};
-        // ---- level-0 cells that may lie in some cell tile's near field: each asks its own tile's radius, as the first
-        // pass did (the radii of neighbouring tiles differ by a few cells at most: usually nothing to do here) ----
-        for (int x = fhb + 1 + rmin; x <= fhb + rmax && x < E0s; ++x)
-        {
-            if (x - fhb > __builtin_amdgcn_readfirstlane(rtab[(x >> cell_shift) - t0]))
-            {
-                sum += (double)cell_series_at<K, K>(gm, (uint64_t)x, -__builtin_amdgcn_rcpf((float)(x - f)));
-            }
-        }
-        for (int x = fb - 1 - rmin; x >= fb - rmax && x > S0s; --x)
-        {
-            if (fb - x > __builtin_amdgcn_readfirstlane(rtab[(x >> cell_shift) - t0]))
-            {
-                sum += (double)cell_series_at<K, K>(gm, (uint64_t)x, __builtin_amdgcn_rcpf((float)(f - x)));
-            }
-        }
-        // ---- the lane's own cells: the far end of its window ----
-        if (lane < np)
-        {
-            {
-                // (a near field nearly as wide as the window: the first cells of the lane's stretch may be near)
-                int const e = f + fsteps < nw - 1 ? f + fsteps : nw - 1;
-                int x = E0s;
-                int const xm = fhb + rmax < e ? fhb + rmax : e;
-                for (; x <= xm; ++x)
-                {
-                    if (x - fhb > rtab[(x >> cell_shift) - t0])
-                    {
-                        sum += (double)cell_series_at<K, K>(gm, (uint64_t)x, -__builtin_amdgcn_rcpf((float)(x - f)));
-                    }
-                }
-                sum += four_up ? walk_up(f, x, e + 1, cap_up, four_terms) : walk_up(f, x, e + 1, cap_up, all_terms);
-            }
-            {
-                int const s = f - fsteps > 0 ? f - fsteps : 0;
-                int x = S0s;
-                int const xm = fb - rmax > s ? fb - rmax : s;
-                for (; x >= xm; --x)
-                {
-                    if (fb - x > rtab[(x >> cell_shift) - t0])
-                    {
-                        sum += (double)cell_series_at<K, K>(gm, (uint64_t)x, __builtin_amdgcn_rcpf((float)(f - x)));
-                    }
-                }
-                sum += four_down ? walk_down(f, x, s - 1, cap_down, four_terms) : walk_down(f, x, s - 1, cap_down, all_terms);
-            }
-        }
-        // ---- the shared stretches: one scalar walk, the lanes evaluate the series.  Cells are taken kBatch at a time:
-        // scalar loads return in any order, so a wave can only wait for ALL of its loads -- with one cell per wait the
-        // kernel ran at the scalar cache's latency (22 ms at 0.001 cm-1, no faster than round 1's form).  A batch's
-        // unused places repeat the last cell with weight zero. ----
-        constexpr int kBatch = 4;       // (scalar_wait takes four)
-        for (int x = XA; x < E0s;)
-        {
-            sfloat4 c[kBatch][K/4];
-            float hh[kBatch], ww[kBatch];
-            int xx[kBatch];
-#pragma unroll
-            for (int j = 0; j < kBatch; ++j)
-            {
-                bool const live = x < E0s;
-                int const xs = live ? x : E0s - 1;
-                int const D = xs - fhb;                                     // the block's end decides
-                int const la = __builtin_ctz(xs), le = 31 - __builtin_clz(E0s - xs);
-                int const l = __builtin_amdgcn_readfirstlane(min(min(la, le), top_level(D)));
-                uint64_t const cell = (uint64_t)(p2 - (p2 >> l)) + (uint64_t)(xs >> l);
-                scalar_load_cell<K>(gm.lo(cell), gm.hi(cell), c[j]);
-                hh[j] = __int_as_float((127 + l) << 23);
-                ww[j] = live ? __int_as_float((127 - l) << 23) : 0.f;
-                xx[j] = xs;
-                x = __builtin_amdgcn_readfirstlane(live ? x + (1 << l) : x);
-            }
-            scalar_wait<K>(c[0], c[1], c[2], c[3]);
-#pragma unroll
-            for (int j = 0; j < kBatch; ++j)
-            {
-                float const d = ((float)(xx[j] - f) - 0.5f) + 0.5f*hh[j];   // C - f
-                float const u = -hh[j]*__builtin_amdgcn_rcpf(d);
-                sum += (double)(cell_series_s<K>(c[j], u)*ww[j]);
-            }
-        }
-        for (int x = XB; x > S0s;)
-        {
-            sfloat4 c[kBatch][K/4];
-            float hh[kBatch], ww[kBatch];
-            int xx[kBatch];
-#pragma unroll
-            for (int j = 0; j < kBatch; ++j)
-            {
-                bool const live = x > S0s;
-                int const xs = live ? x : S0s + 1;
-                int const D = fb - xs;
-                int const la = __builtin_ctz(xs + 1), le = 31 - __builtin_clz(xs - S0s);
-                int const l = __builtin_amdgcn_readfirstlane(min(min(la, le), top_level(D)));
-                uint64_t const cell = (uint64_t)(p2 - (p2 >> l)) + (uint64_t)(xs >> l);
-                scalar_load_cell<K>(gm.lo(cell), gm.hi(cell), c[j]);
-                hh[j] = __int_as_float((127 + l) << 23);
-                ww[j] = live ? __int_as_float((127 - l) << 23) : 0.f;
-                xx[j] = xs;
-                x = __builtin_amdgcn_readfirstlane(live ? x - (1 << l) : x);
-            }
-            scalar_wait<K>(c[0], c[1], c[2], c[3]);
-#pragma unroll
-            for (int j = 0; j < kBatch; ++j)
-            {
-                float const d = ((float)(f - xx[j]) - 0.5f) + 0.5f*hh[j];   // f - C
-                float const u = hh[j]*__builtin_amdgcn_rcpf(d);
-                sum += (double)(cell_series_s<K>(c[j], u)*ww[j]);
-            }
-        }
-        if (lane < np)
-        {
-            acc[cb + lane] += sum;
-        }
-    }
-    __syncthreads();
-    write_tile(a, acc, cs, col, layer, 0, (long long)F0, (long long)F1, tid);
-}
-
-size_t tree_lds_bytes(int tile, int num_slots, int ntab)
-{
-    return sizeof(double)*tile + sizeof(double)*num_slots*(4 + GRT_MAX_ISO) + sizeof(int)*((size_t)ntab + kMaxLevels + 2);
-}
-
-// windows of fewer points a side: every lane walks its own cells (gas_optics_tree_lane_kernel).  Measured, 10^6 lines,
-// lane form / wave form: 0.1 cm-1 0.22 / 0.75 ms, 0.01 cm-1 2.5 / 4.0, 0.005 cm-1 4.9 / 5.9, 0.0025 cm-1 10.1 / 9.6,
-// 0.001 cm-1 30.4 / 23.8 (coarse levels included).  The wave form comes with near fields rounded out to 64-point blocks
-// (near_block): 0.0025 cm-1 first pass 21.7 -> 24.1 ms for 7.9 -> 5.9 ms of gather, 0.001 cm-1 40.5 -> 41.6 for 16.0 -> 12.9
-constexpr int kTreeWaveMin = 16384;
-constexpr int kTreeTile = 1024;      // the gather's tile: four stretches of 64 points per wave
-
-// the gather's tile and the number of cell tiles (first-pass tiles of `tile` cells) whose near-field radius it looks up
-inline int tree_gather_tile() { return kTreeTile; }
-inline int tree_gather_ntab(int tile, int halo) { return (tree_gather_tile() + 2*halo)/tile + 3; }
-
-// windows of at least kTreeWaveMin points a side: the gather shares its walk per wave, near fields are whole 64-point blocks
-bool tree_gather_by_wave(long long fsteps)
-{
-    // GRT_TREE_WAVE_MIN in the environment (read at every launch): tests put both forms through the same cases
-    char const *env = getenv("GRT_TREE_WAVE_MIN");
-    return fsteps >= (env != NULL && atoll(env) > 0 ? atoll(env) : (long long)kTreeWaveMin);
-}
-
-// the coarse levels, one launch per level, then the gather
-template <int K>
-void launch_tree(hipStream_t s, GrtGasOpticsArgs const &b, long long fsteps, int shift, int first_level)
-{
-    for (int l = first_level; l <= b.tree_levels; ++l)
-    {
-        uint64_t const n_child = level_cells(b.nw, l - 1), n_parent = level_cells(b.nw, l);
-        hipLaunchKernelGGL(moment_up_kernel<K>, dim3((unsigned)((n_parent + kBlock - 1)/kBlock), b.lay.num_layers, b.ncol),
-                           dim3(kBlock), 0, s, b.gmom, b.gmom_stride, level_offset(b.nw, l - 1, 1, b.tree_levels), n_child,
-                           level_offset(b.nw, l, 1, b.tree_levels), n_parent, hierarchy_cells(b.nw, b.tree_levels));
-    }
-    if (b.near_block == 0)
-    {
-        int const ntab = (b.tile + 2*b.halo)/b.tile + 2;
-        hipLaunchKernelGGL(gas_optics_tree_lane_kernel<K>, dim3((unsigned)((b.nw + b.tile - 1)/b.tile), b.lay.num_layers, b.ncol),
-                           dim3(kBlock), tree_lds_bytes(b.tile, b.lay.num_slots, ntab), s, b, fsteps, shift, ntab);
-        return;
-    }
-    int const gtile = tree_gather_tile(), ntab = tree_gather_ntab(b.tile, b.halo);
-    hipLaunchKernelGGL(gas_optics_tree_kernel<K>, dim3((unsigned)((b.nw + gtile - 1)/gtile), b.lay.num_layers, b.ncol),
-                       dim3(kBlock), tree_lds_bytes(gtile, b.lay.num_slots, ntab), s, b, fsteps, shift, ntab, gtile);
-}
-
 // subtree_tile > 0: the tree form's first pass with moments straight to global memory, which ends by building the tile's
 // coarser cells in two LDS buffers (tile/2 + tile/4 cells of twelve moments) where the accumulator was
 size_t lean_lds_bytes(int num_slots)
@@ -3247,11 +2023,6 @@ size_t mp_lds_bytes(int nacc, int ncell, int fsteps, int num_slots, bool tree = 
     return main_loop > subtree ? main_loop : subtree;
 }
 
-size_t far_lds_bytes(int tile, int ncell, int fsteps, int num_slots, int cell_shift)
-{
-    return sizeof(double)*tile + sizeof(double)*num_slots*(4 + GRT_MAX_ISO) + sizeof(float)*((size_t)kMom*ncell + fsteps + 1)
-           + sizeof(int)*((size_t)(ncell >> cell_shift) + 3);
-}
 
 // GRT_LEAN=0 in the environment (read at every launch, so that a test can compare the two forms in one process): the
 // two-pass form's first pass keeps the general line loop everywhere
@@ -3305,8 +2076,8 @@ extern "C" int grt_gas_optics_mp_applicable(GrtGasOpticsArgs const *a)
                && level_offset(a->nw, a->tree_levels + 1, terms, a->tree_levels) < 0xffffffffull
                && a->tile + 2*a->halo <= 32767
                && mp_lds_bytes(a->tile + 2*a->halo, direct ? 0 : a->tile, 0, a->lay.num_slots, true, direct ? a->tile : 0) <= kLdsPerWorkgroup
-               && tree_lds_bytes(tree_gather_tile(), a->lay.num_slots, tree_gather_ntab(a->tile, a->halo)) <= kLdsPerWorkgroup
-               && tree_lds_bytes(a->tile, a->lay.num_slots, (a->tile + 2*a->halo)/a->tile + 2) <= kLdsPerWorkgroup;
+               && grt_tree_lds_bytes(grt_tree_gather_tile(), a->lay.num_slots, grt_tree_gather_ntab(a->tile, a->halo)) <= kLdsPerWorkgroup
+               && grt_tree_lds_bytes(a->tile, a->lay.num_slots, (a->tile + 2*a->halo)/a->tile + 2) <= kLdsPerWorkgroup;
     }
     if (fsteps > 4096)
     {
@@ -3321,7 +2092,7 @@ extern "C" int grt_gas_optics_mp_applicable(GrtGasOpticsArgs const *a)
         int const shift = log2_exact(a->tile);
         return shift >= 6 && a->gmom != NULL && a->gmom_stride >= (uint64_t)kMom*a->nw
                && mp_lds_bytes(a->tile + 2*(int)fsteps, a->tile, 0, a->lay.num_slots) <= kLdsPerWorkgroup
-               && far_lds_bytes(a->tile, a->tile + 2*(int)fsteps, (int)fsteps, a->lay.num_slots, shift) <= kLdsPerWorkgroup;
+               && grt_far_lds_bytes(a->tile, a->tile + 2*(int)fsteps, (int)fsteps, a->lay.num_slots, shift) <= kLdsPerWorkgroup;
     }
     return mp_lds_bytes(a->tile, a->tile + 2*(int)fsteps, (int)fsteps, a->lay.num_slots) <= kLdsPerWorkgroup;
 }
@@ -3391,7 +2162,7 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
         }
         b.halo = halo;
         b.direct_near = direct_near_wanted();
-        b.near_block = (tree && tree_gather_by_wave(fsteps)) ? 64 : 0;
+        b.near_block = (tree && grt_tree_gather_by_wave(fsteps)) ? 64 : 0;
         b.mom_terms = wide ? kMomWide : kMom;
         if (!tree)
         {
@@ -3479,45 +2250,11 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
         if (a->profile_tag) grt_profile_end(stream, slot);
         b.nslice = 1;
         slot = a->profile_tag ? grt_profile_begin(stream, a->profile_tag + 5) : -1;
-        if (tree)
-        {
-            // (the first pass has made the levels inside its tiles)
-            int first_level = 1;
-            while ((2 << (first_level - 1)) <= a->tile && first_level <= a->tree_levels) ++first_level;
-            if (wide)
-            {
-                launch_tree<kMomWide>(s, b, fsteps, shift, first_level);
-            }
-            else
-            {
-                launch_tree<kMom>(s, b, fsteps, shift, first_level);
-            }
-        }
-        else
-        {
-            // The gather's workgroups own wider tiles than the first pass's cell tiles (each thread takes two grid points in
-            // turn): a workgroup's fixed costs -- staging the column state and the moments of 2 fsteps extra cells, the
-            // near-field radii of the cell tiles it touches, two barriers -- are shared by twice the points.
-            static int far_want = -1;           // GRT_FAR_TILE in the environment: exploration only
-            if (far_want < 0)
-            {
-                char const *env = getenv("GRT_FAR_TILE");
-                far_want = env != NULL && atoi(env) >= 64 ? atoi(env) : 512;      // measured on G1: 256 -> 0.99 ms, 512 -> 0.90, 1 024 -> 1.42 (occupancy)
-            }
-            int far_tile = a->tile;
-            while (2*far_tile <= far_want && (uint64_t)far_tile < a->nw
-                   && far_lds_bytes(2*far_tile, 2*far_tile + 2*(int)fsteps, (int)fsteps, a->lay.num_slots, shift) <= kLdsPerWorkgroup)
-            {
-                far_tile *= 2;
-            }
-            b.tile = far_tile;
-            unsigned const far_tiles = (unsigned)((a->nw + far_tile - 1)/far_tile);
-            int const far_ncell = far_tile + 2*(int)fsteps;
-            hipLaunchKernelGGL(gas_optics_far_kernel, dim3(far_tiles, a->lay.num_layers, a->ncol), dim3(kBlock),
-                               far_lds_bytes(far_tile, far_ncell, (int)fsteps, a->lay.num_slots, shift), s, b, fsteps, shift, far_ncell);
-        }
+        // the second pass: k_gas_optics_far.hip (the coarse levels above the first pass's tiles and the hierarchy's gather, or
+        // the single-level gather)
+        int const rc_far = grt_launch_far_field(stream, &b, fsteps, shift);
         if (a->profile_tag) grt_profile_end(stream, slot);
-        return (int)hipGetLastError();
+        return rc_far;
     }
     int const ncell = a->tile + 2*(int)fsteps;
     size_t const lds = mp_lds_bytes(a->tile, ncell, (int)fsteps, a->lay.num_slots);
