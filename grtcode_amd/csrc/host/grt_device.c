@@ -270,6 +270,19 @@ int grt_dev_sync(Device_t device, void *stream)
     return GRTCODE_SUCCESS;
 }
 
+void grt_dev_forget_error(void)
+{
+    (void)hipGetLastError();
+}
+
+int grt_dev_alloc_size(Device_t device, void const *p, size_t *bytes)
+{
+    GRT_TRY(grt_dev_require(device));
+    hipDeviceptr_t base = NULL;
+    GRT_TRY(grt_dev_check((int)hipMemGetAddressRange(&base, bytes, (hipDeviceptr_t)p), "hipMemGetAddressRange"));
+    return GRTCODE_SUCCESS;
+}
+
 int grt_dev_mem_info(Device_t device, size_t *free_bytes, size_t *total_bytes)
 {
     GRT_TRY(grt_dev_require(device));

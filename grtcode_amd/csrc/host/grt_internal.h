@@ -53,6 +53,8 @@ int grt_dev_download(Device_t device, void *dst, void const *src, size_t bytes, 
 int grt_dev_copy(Device_t device, void *dst, void const *src, size_t bytes, void *stream);
 int grt_dev_sync(Device_t device, void *stream);
 int grt_dev_mem_info(Device_t device, size_t *free_bytes, size_t *total_bytes);     /* hipMemGetInfo */
+int grt_dev_alloc_size(Device_t device, void const *p, size_t *bytes);               /* size of the allocation p lies in */
+void grt_dev_forget_error(void);                                                     /* clear the runtime's sticky last error */
 int grt_dev_is_host_memory(void const *p);              /* 1: host memory the device writes in place */
 int grt_dev_sync_if_host_memory(Device_t device, void const *p, void *stream);
 void *grt_dev_upload_stream(Device_t device);           /* a stream of its own for the inputs of a one-column solver call */

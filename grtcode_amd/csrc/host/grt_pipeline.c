@@ -274,6 +274,14 @@ EXTERN int grt_pipeline_run(GrtPipeline_t *p, GrtColumns_t const *cols, fp_t *fl
     GRT_REQUIRE_PTR(cols->pressure);
     GRT_REQUIRE_PTR(cols->temperature);
     int const V = p->num_levels, L = V - 1, C = cols->ncol;
+    /* A pipeline belongs to the lane (HIP stream) that was selected when it was created: grt_pipeline_stream() hands THAT
+       stream to the caller (who orders a gather behind it), while the kernels below go to the lane selected now.  The two
+       must be the same: select the pipeline's lane before running it. */
+    if (grt_dev_lane(p->device) != p->lane)
+    {
+        GRT_FAIL(GRTCODE_VALUE_ERR, "this pipeline was created on lane %d, lane %d is selected: call grt_device_use_lane "
+                 "before grt_pipeline_run.", p->lane, grt_dev_lane(p->device));
+    }
     void *s = grt_dev_stream(p->device);
     /* the pinned staging buffer is reused every call: wait until the previous batch's copy of it has
        left -- not for its kernels, so that this batch is prepared on the host while that one runs */

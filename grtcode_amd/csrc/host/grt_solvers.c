@@ -97,6 +97,33 @@ static int download_fluxes(Device_t device, int V, uint64_t n, fp_t *up_h, fp_t 
 }
 
 /* ---- longwave ---- */
+/* A solver object is ONE device block: its inputs, flux_up, flux_down -- and, behind them, the scratch of the layer-parallel
+   first step (6 L or 5 L rows of n: 1.2 GB for a 0.1 cm-1 shortwave object, 12 GB at 0.01 cm-1).  The scratch is an
+   optimisation of one-column calls, not a necessity: where the device cannot give it the block is made without and the
+   solver runs its column chains (the same fluxes).  The reference's structs have no room for a flag (longwave.h:28-36,
+   shortwave.h:27-35), so the solver asks the runtime how large the block is. */
+static int alloc_with_optional_scratch(Device_t device, void **block, size_t base_bytes, size_t scratch_bytes)
+{
+    if (grt_dev_alloc(device, block, base_bytes + scratch_bytes) == GRTCODE_SUCCESS)
+    {
+        return GRTCODE_SUCCESS;
+    }
+    grt_dev_forget_error();          /* (the runtime remembers a failed hipMalloc until it is asked) */
+    GRT_TRY(grt_dev_alloc(device, block, base_bytes));
+    return GRTCODE_SUCCESS;
+}
+
+static int block_has_scratch(Device_t device, void const *block, void const *scratch, size_t scratch_bytes)
+{
+    size_t size = 0;
+    if (grt_dev_alloc_size(device, block, &size) != GRTCODE_SUCCESS)
+    {
+        grt_dev_forget_error();
+        return 0;
+    }
+    return (size_t)((char const *)scratch - (char const *)block) + scratch_bytes <= size;
+}
+
 EXTERN int create_longwave(Longwave_t * const lw, int const num_levels,
                            SpectralGrid_t const * const grid, Device_t const * const device)
 {
@@ -112,9 +139,9 @@ EXTERN int create_longwave(Longwave_t * const lw, int const num_levels,
     size_t const n = grid->n;
     /* one block: T_layers | T_levels | T_surf | emissivity | flux_up | flux_down */
     /* (+ 6 L rows behind flux_down: scratch of the solver's layer-parallel first step, k_longwave.hip) */
-    size_t const doubles = (size_t)(num_levels - 1) + num_levels + 1 + n + 2*n*num_levels + 6*n*(size_t)(num_levels - 1);
+    size_t const base = (size_t)(num_levels - 1) + num_levels + 1 + n + 2*n*num_levels;
     void *block = NULL;
-    GRT_TRY(grt_dev_alloc(*device, &block, sizeof(fp_t)*doubles));
+    GRT_TRY(alloc_with_optional_scratch(*device, &block, sizeof(fp_t)*base, sizeof(fp_t)*6*n*(size_t)(num_levels - 1)));
     lw->layer_temperature = block;
     lw->level_temperature = lw->layer_temperature + (num_levels - 1);
     lw->emissivity = lw->level_temperature + num_levels + 1;
@@ -179,7 +206,8 @@ EXTERN int calculate_lw_fluxes(Longwave_t * const lw, Optics_t const * const opt
     a.user_level = -1;
     /* GRT_LW_COLUMN_CHAINS=1: one thread per wavenumber through all the layers, as before round 4 (same fluxes) */
     char const *chains = getenv("GRT_LW_COLUMN_CHAINS");
-    a.layer_terms = (chains != NULL && chains[0] == '1') ? NULL : lw->flux_down + n*(size_t)V;
+    a.layer_terms = (chains != NULL && chains[0] == '1') || !block_has_scratch(lw->device, lw->layer_temperature, lw->flux_down + n*(size_t)V, sizeof(fp_t)*6*n*(size_t)(V - 1))
+                    ? NULL : lw->flux_down + n*(size_t)V;
     GRT_TRY(grt_dev_check(grt_launch_lw(s, &a), "longwave kernel"));
     GRT_TRY(download_fluxes(lw->device, V, n, flux_up, flux_down, lw->flux_up, lw->flux_down, s));
     GRT_TRY(grt_dev_sync(lw->device, s));
@@ -203,7 +231,7 @@ EXTERN int create_shortwave(Shortwave_t * const sw, int const num_levels,
     /* one block: solar | alb_dir | alb_dif | mu_dir,tsi | flux_up | flux_down | the layers' five properties
        (5 L rows behind flux_down: scratch of the solver's layer-parallel first step, k_shortwave.hip) */
     void *block = NULL;
-    GRT_TRY(grt_dev_alloc(*device, &block, sizeof(fp_t)*(3*n + 2 + 2*n*num_levels + 5*n*(size_t)(num_levels - 1))));
+    GRT_TRY(alloc_with_optional_scratch(*device, &block, sizeof(fp_t)*(3*n + 2 + 2*n*num_levels), sizeof(fp_t)*5*n*(size_t)(num_levels - 1)));
     sw->solar_flux = block;
     sw->sfc_alpha_dir = sw->solar_flux + n;
     sw->sfc_alpha_dif = sw->sfc_alpha_dir + n;
@@ -267,7 +295,8 @@ EXTERN int calculate_sw_fluxes(Shortwave_t * const sw, Optics_t const * const op
     a.user_level = -1;
     /* GRT_SW_COLUMN_CHAINS=1: one thread per wavenumber through all the layers, as before round 4 (same fluxes) */
     char const *chains = getenv("GRT_SW_COLUMN_CHAINS");
-    a.layer_props = (chains != NULL && chains[0] == '1') ? NULL : sw->flux_down + n*(size_t)V;
+    a.layer_props = (chains != NULL && chains[0] == '1') || !block_has_scratch(sw->device, sw->solar_flux, sw->flux_down + n*(size_t)V, sizeof(fp_t)*5*n*(size_t)(V - 1))
+                    ? NULL : sw->flux_down + n*(size_t)V;
     GRT_TRY(grt_dev_check(grt_launch_sw(s, &a), "shortwave kernel"));
     GRT_TRY(download_fluxes(sw->device, V, n, flux_up, flux_down, sw->flux_up, sw->flux_down, s));
     GRT_TRY(grt_dev_sync(sw->device, s));

@@ -157,7 +157,9 @@ static double q_vib(VibModes const *v, double T)
 
 typedef struct ModelFactors { double T; double power, ratio; VibModes const *v; int beta15; int valid; } ModelFactors;
 #define GRT_MODEL_MEMO 2048
-static ModelFactors g_memo[GRT_MODEL_MEMO];
+/* per thread: Q() is an exported function a caller may use from its own OpenMP threads; a shared table copied by value
+   could hand out an entry half of one temperature and half of another */
+static _Thread_local ModelFactors g_memo[GRT_MODEL_MEMO];
 
 static ModelFactors model_factors(VibModes const *v, double beta, double T)
 {

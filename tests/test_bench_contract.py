@@ -120,3 +120,93 @@ def test_round4_lines_of_the_other_configurations():
     assert strong["scaling"] == "strong" and strong["config"]["columns_per_step"] == 100
     drv = load("r4_reference_driver_timing.json")                # the unchanged driver binary; with its opt-in for three rows
     assert drv["fast3"]["columns_per_s"] > 150.0 and drv["fast3rows"]["columns_per_s"] > drv["fast3"]["columns_per_s"]
+
+
+# ---- round 5 (profiles/r5_*: scripts/evidence_round.sh -- one build, one session) -------------------------------------- #
+def _kernel_source_sha():
+    import hashlib
+    hip = os.path.join(ROOT, "grtcode_amd", "csrc", "hip")
+    return hashlib.sha256(b"".join(open(os.path.join(hip, f), "rb").read() for f in
+                                   ("k_gas_optics_mp.hip", "mp_general_block.inc", "mp_lean_block.inc", "k_gas_optics_far.hip",
+                                    "gas_optics_mp_dev.h", "gas_optics_dev.h"))).hexdigest()
+
+
+def test_round5_counters_belong_to_the_kernel_source_at_head():
+    """VERDICT r4 weak 1 / ADVICE r4: round 4 kept lines of two builds side by side.  The PMC counters bench.py carries into
+    its line (profiles/traffic_latest.json) name the kernel source they were taken on: it is the source of this tree."""
+    t = load("traffic_latest.json")
+    assert t["tag"] == "r5" and t["kernel_source_sha256"] == _kernel_source_sha()
+    assert t["cols"] == 64 and t["gas_optics_sw"]["sq"]["SQ_INSTS_VALU"] > 0
+
+
+def test_round5_headline_line():
+    line = load("r5_bench_line.json")
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert line["metric"].split(" at ")[0] in base["metric"] and line["unit"] == "columns/s" and line["scaling"] == "weak"
+    assert line["n_gpus"] == 1 and line["steps"] * line["ms_per_step"] >= 2500.0 and line["dtype"] == "f64" and line["vs_baseline"] is None
+    assert line["ms_per_step"] <= 112.0 and line["value"] >= 570.0                       # VERDICT r4, task 1's speed target
+    k = line["kernel_ms_per_step"]
+    assert k["gas_optics_lw"] <= 27.0                                                     # ... its longwave target
+    assert abs(sum(k.values()) - line["ms_per_step"]) / line["ms_per_step"] < 0.03      # the kernels' durations ARE the step
+    r = line["roofline"]
+    assert r["bound"] == "valu_issue" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.3 < r["frac"] < 1.0
+    assert "round tag r5" in r["instructions_source"] and r["traffic"] > 0
+    assert r["algorithmic_fp32_frac"] >= 0.28                                             # round 4: 0.25
+    v = line["roofline_valu"]
+    assert v["instructions_per_64_lines"] <= 520                                          # round 4: 613
+    h = line["roofline_hbm"]
+    assert h["bound"] == "hbm" and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-12
+    p = line["parity"]
+    assert p["kind"] == "reference" and p["ok"] is True and p["max_abs_flux_diff_w_m2"] <= 1e-3 and p["max_tau_err_of_layer_max"] <= 2e-6
+    q = p["physical_list"]
+    assert q["ok"] is True and q["max_abs_flux_diff_w_m2"] <= 1e-3 and 0.62 < q["rsds_over_rsdt"] < 0.75
+    c = line["cpu_baseline"]
+    assert c["kind"] == "reference" and c["cores"] >= 1 and c["value"] > 0 and c["one_thread"]["cores"] == 1
+    cols = line["config"]["columns_per_step"]
+    assert abs(line["value"] - cols / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-9
+
+
+def test_round5_rccl_at_world_size_one_is_a_pair_taken_back_to_back():
+    """VERDICT r4 task 2: forced and plain runs of ONE build, alternating, in one file."""
+    pairs = load("r5_rccl_world1_pairs.json")
+    assert len(pairs) >= 3
+    for x in pairs:
+        plain, forced = x["plain"], x["forced"]
+        assert plain["rccl_ranks"] == 0 and forced["rccl_ranks"] == 1 and forced["collective"]["backend"] == "nccl"
+        assert forced["collective"]["gathers_in_timed_region"] == 1
+        assert 0.98 * plain["value"] <= forced["value"] <= 1.005 * plain["value"]
+
+
+def test_round5_batch_shapes_of_an_eight_gpu_run():
+    """VERDICT r4 task 4: 13 columns per rank and step (100 columns over 8 GPUs) must run at >= 0.92 of the 64-column rate."""
+    rate = {x["cols"]: x["columns_per_s"] for x in load("r5_batch_sweep.json")}
+    assert set(rate) >= {1, 2, 4, 8, 9, 13, 16, 32, 64, 225}
+    assert rate[13] >= 0.92 * rate[64] and rate[9] >= 0.92 * rate[64] and rate[225] >= 0.98 * rate[64]
+
+
+def test_round5_fine_grid_lines_traffic_and_the_unchanged_caller():
+    g3 = load("r5_g3_pipeline_bench_line.json")
+    assert "0.001" in g3["config"]["workload"] and g3["value"] > 15.0
+    band = g3["roofline_hbm_lw_band"]                         # the north-star's "fraction of HBM roofline on the ~3M grid"
+    assert band["far_field_kernel"].startswith("gas_optics_tree_kernel") and 0.0 < band["frac_band"] < band["frac_far_field"] < 1.0
+    assert abs(band["algorithmic_bytes_per_column"] - 12.87e9) < 0.05e9
+    g3_32 = load("r5_g3_pipeline_32_columns_bench_line.json")         # task 5: 32 columns of 18.7 GB of moments each, in column groups
+    assert g3_32["config"]["columns_per_step"] == 32 and g3_32["value"] >= 0.95 * g3["value"]
+    t = load("traffic_latest.json")["g3"]
+    assert t["tag"] == "r5"
+    total = sum(k["hbm_bytes_per_launch"] for k in t["kernels"].values())
+    assert total <= 80e9                                      # the two-plane store: 75 GB per column (round 4: 100)
+    era = load("r5_era5_like_bench_line.json")
+    assert "@0.1 cm-1" in era["config"]["workload"] and era["config"]["columns_per_step"] == 64 and era["value"] > 450.0
+    strong = load("r5_strong_100_columns_bench_line.json")
+    assert strong["scaling"] == "strong" and strong["config"]["columns_per_step"] == 100 and strong["value"] >= 570.0
+    drv = load("r5_reference_driver_timing.json")
+    assert drv["fast3"]["columns_per_s"] >= 250.0 and drv["fast3rows"]["columns_per_s"] > drv["fast3"]["columns_per_s"]
+
+
+def test_round5_suite_logs_are_green():
+    for name, want in (("r5_pytest_gpu.log", "pytest -m gpu rc=0"), ("r5_pytest_gpu_deterministic.log", "deterministic rc=0")):
+        text = open(os.path.join(ROOT, "profiles", name)).read()
+        assert want in text and " passed" in text and "failed" not in text and "skipped" not in text
+    soak = open(os.path.join(ROOT, "profiles", "r5_soak.log")).read()
+    assert soak.count("600 passed") == 2 and "wide=1 rc=0" in soak and "wide=2 rc=0" in soak and "failed" not in soak

@@ -259,6 +259,10 @@ def test_two_pipelines_on_two_lanes_equal_one(bands, lib, device):
         api.use_lane(device, 0)
         made[1][0].sync()
         assert np.array_equal(out[0].to_host((ncol, api.GRT_FLUXES_PER_COLUMN)), two[1])
+        # ... and a pipeline is not RUN on another lane than its own (the stream it hands out for the gather would
+        # not be the one carrying its kernels): a clean error, nothing queued
+        with pytest.raises(Exception, match="lane"):
+            made[1][0].run(batches[1][0], out[0].ptr)
     finally:
         api.check(lib.grt_set_deterministic(-1))
         api.use_lane(device, 0)
