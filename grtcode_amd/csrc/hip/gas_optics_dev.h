@@ -239,7 +239,8 @@ __device__ __forceinline__ int voigt_class(float xi, float y)
 // ONLY = -1: any region; 0 / 1 / 2: the caller has sorted its points with voigt_class and only that
 // class's code is generated (no divergence inside a batch of 64 points); with voigt_class<., true>: 4 = class 0 without
 // region 3 (regions 1-2), 3 = region 3.
-template <bool FAST, int ONLY = -1>
+// PACKED4 (fused form, ONLY = 1 or 2): region 4's -T[J] and +T[J] branches side by side in packed fp32 registers.
+template <bool FAST, int ONLY = -1, bool PACKED4 = false>
 __device__ __forceinline__ double voigt_near(float xi, float y)
 {
     float const yq = y*y;
@@ -317,11 +318,53 @@ __device__ __forceinline__ double voigt_near(float xi, float y)
     // same sequence of roundings reproduces it; the divisions are hardware reciprocals refined to the
     // reference's rounding (quot_rounded) and exp(-x^2) the hardware exp2 after an fp64 range reduction)
     double k = 0.0;
-    // (round 4: the -T[J] and +T[J] branches of a term side by side in packed registers -- half the fp32 instructions of
-    // this region -- were measured SLOWER in the lean kernel, whose waves are at their register limit: longwave launch
-    // 32.3 -> 34.8 ms, shortwave 90.1 -> 91.8; so was one shared copy of the queues' evaluation code behind a call: 98.7.
-    // Round 5, with the kernel at 127 registers and no scratch, the packed form again: shortwave 75.5 -> 74.4 ms, longwave
-    // 22.9 -> 23.4 -- within the noise of the pair; left out)
+    // (round 4: one shared copy of the queues' evaluation code behind a call was measured at 98.7 ms against 90.1)
+    // The -T[J] and +T[J] branches of a term side by side in the halves of packed registers: the same operations in the same
+    // order per half, so the same fp32 numbers, in about half the instructions.  Round 4 measured it SLOWER in a kernel at
+    // its register limit; round 5 (127 registers, no scratch): the G1 shortwave launch 75.5 -> 74.4 ms three times out of
+    // three, the longwave launch 22.0 -> 22.6 -- so the instance of the shortwave band takes it and the longwave's does not.
+    if constexpr (FAST && PACKED4 && (ONLY == 1 || ONLY == 2))
+    {
+        v2f const xi2 = splat2(xi), yq0 = splat2(ypy0q);
+        if (ONLY == 1)
+        {
+#pragma unroll
+            for (int J = 0; J < 6; ++J)
+            {
+                v2f const d = xi2 + (v2f){-T[J], T[J]};                 // dm | dp
+                v2f const b = d*d + yq0;
+                v2f r = rcp2(b);
+                r = pk_fma(pk_fma(-b, r, splat2(1.0f)), r, r);
+                r = pk_fma(pk_fma(-b, r, splat2(1.0f)), r, r);          // mf | pf (recip_rounded)
+                v2f const xf = r*d, yf2 = r*ypy0;                       // xm | xp, ym | yp
+                k = k + (double)(C[J]*(yf2.x + yf2.y)) - (double)(S[J]*(xf.x - xf.y));
+            }
+            return k;
+        }
+        float const yf = y + y0py0;
+#pragma unroll
+        for (int J = 0; J < 6; ++J)
+        {
+            v2f const d = xi2 + (v2f){-T[J], T[J]};                     // dm | dp
+            v2f const sq = d*d;                                         // mq | pq
+            v2f const b = sq + yq0;
+            v2f r = rcp2(b);
+            r = pk_fma(pk_fma(-b, r, splat2(1.0f)), r, r);
+            r = pk_fma(pk_fma(-b, r, splat2(1.0f)), r, r);              // mf | pf
+            v2f const xf = r*d, yf2 = r*ypy0;                           // xm | xp, ym | yp
+            float const syf = S[J]*yf;
+            v2f const w = syf*xf;
+            v2f const num = C[J]*(sq*r - y0*yf2) + (v2f){w.x, -w.y};    // C (mq mf - y0 ym) + S yf xm | C (pq pf - y0 yp) - S yf xp
+            v2f const den = sq + y0q;
+            v2f q = rcp2(den);
+            q = pk_fma(pk_fma(-den, q, splat2(1.0f)), q, q);
+            v2f const qt = num*q;
+            v2f const res = pk_fma(pk_fma(-den, qt, num), q, qt);       // quot_rounded
+            k = k + (double)res.x + (double)res.y;
+        }
+        k = (double)y*k + exp_fast((double)(-xq));
+        return k;
+    }
     if (ONLY == 1 || (ONLY < 0 && abx <= xlim4))
     {
 #pragma unroll

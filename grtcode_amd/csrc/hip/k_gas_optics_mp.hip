@@ -40,7 +40,7 @@ extern "C" int grt_launch_far_field(void *stream, GrtGasOpticsArgs const *b, lon
 namespace {
 
 // CLASS: the queue; ONLY: the formula(s) voigt_near generates for it
-template <int CLASS, int ONLY, typename Queue>
+template <int CLASS, int ONLY, bool PACKED4, typename Queue>
 __device__ __forceinline__ void drain_class(double *acc, Queue const *q, int wave, int first, int count, int lane)
 {
 #ifdef GRT_ABL_NOEVAL
@@ -52,7 +52,7 @@ __device__ __forceinline__ void drain_class(double *acc, Queue const *q, int wav
         unsigned const idx = q->idx[CLASS][wave][i];
         // the Lorentzian in the same units (RFM_voigt.c:170: Y RSQRPI/(X^2 + Y^2) before the scaling of :278)
         float const far = (idx & 0x8000u) ? (y*kRsqrpi)*__builtin_amdgcn_rcpf(fmaf(xi, xi, y*y)) : 0.f;
-        double const k = voigt_near<true, ONLY>(xi, y) - (double)far;
+        double const k = voigt_near<true, ONLY, PACKED4>(xi, y) - (double)far;
         GRT_ACC_ADD(&acc[idx & 0x7fffu], (double)q->amp[CLASS][wave][i]*k);                   // kernels.c:459
     }
 }
@@ -302,10 +302,12 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         unsigned long long t0 = 0;
         if constexpr (PROBE) t0 = __builtin_readcyclecounter();
         {
-            if (cls == 0) drain_class<0, kSplit ? 4 : 0>(acc, nq, wave, first, count, lane);
-            else if (cls == 1) drain_class<1, 1>(acc, nq, wave, first, count, lane);
-            else if (cls == 2) drain_class<2, 2>(acc, nq, wave, first, count, lane);
-            else if constexpr (kSplit) drain_class<3, 3>(acc, nq, wave, first, count, lane);
+            // (region 4 in packed registers: the lean kernel's shortwave instance -- gas_optics_dev.h)
+            constexpr bool kPacked4 = LEANP > 0 && !LEAN;
+            if (cls == 0) drain_class<0, kSplit ? 4 : 0, false>(acc, nq, wave, first, count, lane);
+            else if (cls == 1) drain_class<1, 1, kPacked4>(acc, nq, wave, first, count, lane);
+            else if (cls == 2) drain_class<2, 2, kPacked4>(acc, nq, wave, first, count, lane);
+            else if constexpr (kSplit) drain_class<3, 3, false>(acc, nq, wave, first, count, lane);
         }
         if constexpr (PROBE)
         {
