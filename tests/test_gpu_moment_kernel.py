@@ -81,6 +81,22 @@ def test_dense_lines_many_per_cell(tmp_path, oracle, lib, device, tile, nslice):
     check(band, device, oracle, lib, syn.profile(2, 13), tile=tile, nslice=nslice)
 
 
+@pytest.mark.parametrize("w0,prof", [(30000.0, 3), (46000.0, 7), (18000.0, 11)])
+def test_region_two_points_of_the_lean_loop_against_the_exact_path(tmp_path, oracle, lib, device, w0, prof):
+    """Round 5: the lean loop evaluates Humlicek region 2 (XLIM2 = 6.8 - y <= |x| < XLIM1, RFM_voigt.c:113, :187-199) itself,
+    with its own fp32 x and y; the general loop sends the same points through the exact preparation and the class queues.
+    At these wavenumbers a grid step is 10-30 Doppler widths, so about half of all lines have their own grid point in
+    region 2 (and a quarter in regions 3-4): lean against general within LEAN_TOL, both within FAST_TOL of the oracle --
+    at line centres too, where a layer's largest optical depths are."""
+    band = Band(str(tmp_path), w0, w0 + 399.0, 1.0, 24000, sw=True, with_cfc=False)
+    col = syn.profile(prof, 13)
+    mp, want = check(band, device, oracle, lib, col)
+    peak = want.argmax(axis=1)
+    rows = np.arange(want.shape[0])
+    lean = run(band, device, col, 3)
+    assert np.max(np.abs(lean[rows, peak] - want[rows, peak]) / want[rows, peak]) < 2e-6
+
+
 def test_lone_column_of_a_crowded_band_is_cut_by_line_count(tmp_path, oracle, lib, device, monkeypatch):
     """A band whose lines crowd into one tile (real line lists: the infrared end of a shortwave band) as ONE column: the
     launch's work list (GrtGasOpticsArgs.tile_items) cuts that tile into pieces of ~10 000 lines and leaves the empty
