@@ -645,7 +645,7 @@ def main():
                 tj = json.load(open(tpath))
                 import hashlib
                 live_sha = hashlib.sha256(b"".join(open(os.path.join(ROOT, "grtcode_amd", "csrc", "hip", f), "rb").read()
-                                                   for f in ("k_gas_optics_mp.hip", "mp_general_block.h", "mp_lean_block.h", "k_gas_optics_far.hip", "gas_optics_mp_dev.h", "gas_optics_dev.h"))).hexdigest()
+                                                   for f in ("k_gas_optics_mp.hip", "mp_general_block.inc", "mp_lean_block.inc", "k_gas_optics_far.hip", "gas_optics_mp_dev.h", "gas_optics_dev.h"))).hexdigest()
                 if tj.get("kernel_source_sha256") != live_sha:
                     # (counters of another version of the kernel: not carried -- ADVICE r4)
                     traffic_src = (f"profiles/traffic_latest.json (round tag {tj.get('tag')}) was taken on another version of the "

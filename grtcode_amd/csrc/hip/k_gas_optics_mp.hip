@@ -72,247 +72,54 @@ __device__ __forceinline__ void drain_class(double *acc, Queue const *q, int wav
 // PROBE: the instrumented instance (GrtGasOpticsArgs.probe): per-workgroup clocks and event counts, for the cost
 // analysis of scripts/line_cost_by_wavenumber.py; the production instances carry none of it.
 constexpr int kProbeWords = 24;
-
-// The workgroup of a first-pass kernel as an object: what the prologue works out of the launch and the (tile, layer,
-// column) -- pointers into LDS, the tile's bounds, the layer's state, the near-field radius -- and the state of the walk over
-// the tile's lines (queue counts, the lean loop's prefetched records, probe counters) are its members; the line loops'
-// blocks are its member functions, each in a file of its own (round 5: they were lambdas of ONE 1 800-line function body):
-//   run()                               this file: prologue, the walk over the lines, epilogue
-//   general_block, general_near_field   mp_general_block.h: the GENERAL line loop (fp64 preparation, any near field)
-//   drain_raw, lean_fetch, lean_block   mp_lean_block.h: the LEAN line loop (packed fp32, seven-point near fields)
-//   queue_push, drain, mom_add ...      below
-// Everything is inlined into the kernel that instantiates it; the object never leaves registers.
-#define MP_TEMPLATE template <bool TWO_PASS, bool TREE, int K, bool LEAN, bool PROBE, int LEANP>
-#define MP_CLASS MpWorkgroup<TWO_PASS, TREE, K, LEAN, PROBE, LEANP>
 template <bool TWO_PASS, bool TREE, int K, bool LEAN = false, bool PROBE = false, int LEANP = 0>
-struct MpWorkgroup
-{
-    static_assert(LEANP == 0 || LEANP == 2, "the lean loop keeps the two lines of a lane in the halves of packed registers");
-    using Queue = std::conditional_t<TREE, MpQueueTree, MpQueueFlat>;
-    static constexpr bool kSplit = Queue::classes == kClassesSplit;
-    static constexpr int kLinesPerLane = LEANP > 0 ? LEANP : 1;
-    // what the near field of a lean (tile, layer) is made of (lean_block): bits of tflags
-    enum : unsigned { kTfStim = 1u, kTfFarir = 2u, kTfCorrected = 4u, kTfLreg = 8u, kTfV1 = 16u, kTfNcOne = 32u, kTfNcThree = 64u };
-
-    // ---- the launch ----
-    GrtGasOpticsArgs const &a;
-    long long fsteps_ll;
-    unsigned ngroups, perm_stride;
-    int ncell, nacc, halo;
-    // ---- LDS ----
-    double *acc;                    // [nacc]
-    Queue *nq;
-    long long *range;               // [2]
-    double *ms_l, *q_l, *ptab;      // [num_slots][4] | [num_slots][GRT_MAX_ISO] | [kPowTable]: (296/T)^(k/100)
-    float *mom, *invr;              // [kMom][ncell] | [fsteps + 1]
-    unsigned *occ_any, *occ_many;   // tree form, moments straight to global memory: [tile/32] each
-    LeanTables *lt = nullptr;
-    LeanRaw *raw = nullptr;
-    // ---- the thread, the work item, the tile ----
-    int fsteps, tid, lane, wave;
-    WorkItem wi;
-    int col, layer, tile_idx, slice;
-    long long nw, F0l, F1l;
-    int F0, F1, nw_i, cell0, A0;
-    double const *cs, *lay;
-    uint64_t jbeg, jend;
-    float wres_f, inv_wres_f;
-    double inv_wres;
-    bool use_moments, corrected, direct;
-    int R;
-    float *gcell;
-    CellStore<K> cells{nullptr, 0};
-    // ---- the walk over the lines ----
-    int qcount[Queue::classes] = {};        // wave-uniform: entries in the class queues
-    bool lean_ok = false;
-    int rawcount = 0;                       // wave-uniform: entries waiting in the raw queue
-    int xcount = 0;                         // wave-uniform: blocks with lines handed over to general_block
-    // (uniform per workgroup, but kept in VECTOR registers: an fp32 multiply or fma with a scalar operand runs at half rate)
-    float kh = 0.f, kl = 0.f, c2t = 0.f, pw = 0.f, pavg_f = 0.f, a_norm = 0.f, wres_v = 0.f, inv_wres_v = 0.f;
-    unsigned tflags = 0u;
-    uint64_t jal, walk_first;
-    unsigned walk_stride, nrel, lo_first;
-    float4 next_a0 = make_float4(0.f, 0.f, 0.f, 0.f), next_a1 = next_a0, next_b0 = next_a0, next_b1 = next_a0;
-    uint2 next_c = make_uint2(0u, 0u);
-    // ---- the instrumented instance (PROBE) ----
-    unsigned long long *probe_rec = nullptr;
-    unsigned pc_ring_inside = 0, pc_ring_lorentz = 0, pc_blocks = 0, pc_ring = 0, pc_near = 0, pc_momred = 0, pc_momlane = 0, pc_pre2 = 0, pc_walk = 0;    // wave-uniform
-    unsigned long long pt[8] = {}, pt_last = 0;     // clocks a wave spent in: preparation, moment reduction and adds, walk and
-                                                    // queue pushes, pre-pass 2, near field, the rest, queued points, moment terms
-
-    // what general_block hands its near field (general_near_field) of the lane's line
-    struct GeneralLine
-    {
-        bool valid, lorentz;
-        int c, lo, hi, near_lo, near_hi;
-        double amp;
-        float y, yq, xlim0, xq_near, x0q, a0, d0r, d2r, cl, wr, ndcr, delta_c, rwr;
-    };
-
-    __device__ __forceinline__ MpWorkgroup(GrtGasOpticsArgs const &a_, long long fsteps_ll_, unsigned ngroups_, unsigned perm_stride_,
-                                           int ncell_, int nacc_, int halo_)
-        : a(a_), fsteps_ll(fsteps_ll_), ngroups(ngroups_), perm_stride(perm_stride_), ncell(ncell_), nacc(nacc_), halo(halo_) {}
-    __device__ __forceinline__ void run();
-    __device__ __forceinline__ void phase_mark(int idx);
-    __device__ __forceinline__ void probe_finish(unsigned long long nlines, int R, bool corrected, bool use_moments);
-    __device__ __forceinline__ void mom_add(int k, int cell, float v);
-    __device__ __forceinline__ void drain(int cls, int first, int count);
-    __device__ __forceinline__ void queue_push(int const cls, float const amp_q, float const xr, float const y_q, unsigned short const idx_q);
-    __device__ __forceinline__ void general_block(uint64_t const j, bool const have);
-    __device__ __forceinline__ void general_near_field(GeneralLine const &gl);
-    __device__ __forceinline__ void drain_raw(int const first, int const count);
-    __device__ __forceinline__ void lean_fetch(unsigned const b);
-    __device__ __forceinline__ void lean_block(unsigned const base);
-};
-
-MP_TEMPLATE __device__ __forceinline__ void MP_CLASS::phase_mark(int idx)
-{
-    if constexpr (PROBE)
-    {
-        unsigned long long const now = __builtin_readcyclecounter();
-        pt[idx] += now - pt_last;
-        pt_last = now;
-    }
-}
-
-MP_TEMPLATE __device__ __forceinline__ void MP_CLASS::probe_finish(unsigned long long nlines, int R, bool corrected, bool use_moments)
-{
-    if constexpr (PROBE)
-    {
-        if (lane == 0)
-        {
-            atomicAdd(&probe_rec[4], (unsigned long long)pc_blocks);
-            atomicAdd(&probe_rec[5], (unsigned long long)pc_ring);
-            atomicAdd(&probe_rec[6], (unsigned long long)pc_near);
-            atomicAdd(&probe_rec[7], (unsigned long long)pc_momred);
-            atomicAdd(&probe_rec[8], (unsigned long long)pc_momlane);
-            atomicAdd(&probe_rec[9], (unsigned long long)pc_pre2);
-            atomicAdd(&probe_rec[10], (unsigned long long)pc_walk);
-            for (int i = 0; i < 8; ++i)
-            {
-                atomicAdd(&probe_rec[14 + i], pt[i]);
-            }
-            atomicAdd(&probe_rec[22], (unsigned long long)pc_ring_inside);
-            atomicAdd(&probe_rec[23], (unsigned long long)pc_ring_lorentz);
-        }
-        if (tid == 0)
-        {
-            probe_rec[2] = nlines;
-            probe_rec[3] = (unsigned long long)R | ((unsigned long long)corrected << 16) | ((unsigned long long)use_moments << 17);
-            probe_rec[1] = __builtin_readcyclecounter();
-        }
-    }
-}
-
-MP_TEMPLATE __device__ __forceinline__ void MP_CLASS::mom_add(int k, int cell, float v)
-{
-    if (direct)
-    {
-        unsafeAtomicAdd(cells.moment((uint64_t)cell, k), v);
-    }
-    else
-    {
-        unsafeAtomicAdd(&mom[k*ncell + (cell - cell0)], v);
-    }
-}
-
-MP_TEMPLATE __device__ __forceinline__ void MP_CLASS::drain(int cls, int first, int count)
-{
-    unsigned long long t0 = 0;
-    if constexpr (PROBE) t0 = __builtin_readcyclecounter();
-    {
-        // (region 4 in packed registers: the lean kernel's shortwave instance -- gas_optics_dev.h)
-        constexpr bool kPacked4 = LEANP > 0 && !LEAN;
-        if (cls == 0) drain_class<0, kSplit ? 4 : 0, false>(acc, nq, wave, first, count, lane);
-        else if (cls == 1) drain_class<1, 1, kPacked4>(acc, nq, wave, first, count, lane);
-        else if (cls == 2) drain_class<2, 2, kPacked4>(acc, nq, wave, first, count, lane);
-        else if constexpr (kSplit) drain_class<3, 3, false>(acc, nq, wave, first, count, lane);
-    }
-    if constexpr (PROBE)
-    {
-        // (evaluating the queued points: a phase of its own, taken out of the one that called)
-        unsigned long long const dt = __builtin_readcyclecounter() - t0;
-        pt[6] += dt;
-        pt_last += dt;
-    }
-}
-
-// A near-centre point per lane (cls: its class of formula, -1: none) goes to its class's queue, which is evaluated in
-// FULL batches of 64 -- one formula, all lanes busy.  A push that does not fit (the queues hold 64 ... 88 entries) is
-// split: as many points as fill the batch go in, the batch is evaluated, the rest follow.  (Until round 4 a queue that
-// could not take a push was emptied first, whatever it held: with 64-entry queues most batches were partial ones.)
-MP_TEMPLATE __device__ __forceinline__ void MP_CLASS::queue_push(int const cls, float const amp_q, float const xr, float const y_q, unsigned short const idx_q)
-{
-#pragma unroll
-    for (int q = 0; q < Queue::classes; ++q)
-    {
-        unsigned long long const mk = __ballot(cls == q);
-        if (mk == 0ull)
-        {
-            continue;
-        }
-        int const npush = __popcll(mk);
-        if constexpr (PROBE) pc_near += (unsigned)npush;
-        int const rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
-        int pos = qcount[q] + rank;                  // (qcount < 64 on entry: pos < 64 + 64)
-        bool mine = cls == q;
-        if (mine & (pos < 64))
-        {
-            nq->amp[q][wave][pos] = amp_q;
-            nq->xi[q][wave][pos] = xr;
-            nq->y[q][wave][pos] = y_q;
-            nq->idx[q][wave][pos] = idx_q;
-            mine = false;
-        }
-        qcount[q] += npush;
-        if (qcount[q] >= 64)
-        {
-            drain(q, 0, 64);                         // a full batch
-            qcount[q] -= 64;
-            pos -= 64;
-            if (mine)
-            {
-                nq->amp[q][wave][pos] = amp_q;
-                nq->xi[q][wave][pos] = xr;
-                nq->y[q][wave][pos] = y_q;
-                nq->idx[q][wave][pos] = idx_q;
-            }
-        }
-    }
-}
-
-// Prologue, the walk over the tile's lines, epilogue.
-MP_TEMPLATE __device__ __forceinline__ void MP_CLASS::run()
+__device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long long fsteps_ll, unsigned ngroups,
+                                               unsigned perm_stride, int ncell, int nacc, int halo)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    fsteps = (int)fsteps_ll;
-    acc = reinterpret_cast<double *>(smem);                               // [nacc]
-    nq = reinterpret_cast<Queue *>(smem + sizeof(double)*nacc);
-    range = reinterpret_cast<long long *>(nq + 1);                     // [2]
-    ms_l = reinterpret_cast<double *>(range + 2);                         // [num_slots][4]
-    q_l = ms_l + 4*a.lay.num_slots;                                       // [num_slots][GRT_MAX_ISO]
-    ptab = q_l + GRT_MAX_ISO*a.lay.num_slots;                             // [kPowTable]: (296/T)^(k/100)
-    mom = reinterpret_cast<float *>(ptab + kPowTable);                     // [kMom][ncell]
-    invr = mom + (size_t)kMom*ncell;                                       // [fsteps + 1]
+    int const fsteps = (int)fsteps_ll;
+    double *acc = reinterpret_cast<double *>(smem);                               // [nacc]
+    using Queue = std::conditional_t<TREE, MpQueueTree, MpQueueFlat>;
+    constexpr bool kSplit = Queue::classes == kClassesSplit;
+    Queue *nq = reinterpret_cast<Queue *>(smem + sizeof(double)*nacc);
+    long long *range = reinterpret_cast<long long *>(nq + 1);                     // [2]
+    double *ms_l = reinterpret_cast<double *>(range + 2);                         // [num_slots][4]
+    double *q_l = ms_l + 4*a.lay.num_slots;                                       // [num_slots][GRT_MAX_ISO]
+    double *ptab = q_l + GRT_MAX_ISO*a.lay.num_slots;                             // [kPowTable]: (296/T)^(k/100)
+    float *mom = reinterpret_cast<float *>(ptab + kPowTable);                     // [kMom][ncell]
+    float *invr = mom + (size_t)kMom*ncell;                                       // [fsteps + 1]
     // tree form, moments straight to global memory: which of the tile's cells hold a line at all / more than one
-    occ_any = reinterpret_cast<unsigned *>(invr + 1);                   // [tile/32]
-    occ_many = occ_any + (a.tile >> 5);                                 // [tile/32]
+    unsigned *occ_any = reinterpret_cast<unsigned *>(invr + 1);                   // [tile/32]
+    unsigned *occ_many = occ_any + (a.tile >> 5);                                 // [tile/32]
 
-    tid = threadIdx.x;
-    lane = tid & 63;
+    int const tid = threadIdx.x;
+    int const lane = tid & 63;
     // (the same in every lane of a wave, and said so: line indices, queue positions and the addresses built on them then
     // live in scalar registers)
-    wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    wi = decode_work(a, ngroups, perm_stride);
-    col = wi.col; layer = wi.layer; tile_idx = wi.tile_idx; slice = wi.slice;
+    int const wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    WorkItem const wi = decode_work(a, ngroups, perm_stride);
+    int const col = wi.col, layer = wi.layer, tile_idx = wi.tile_idx, slice = wi.slice;
     if (TWO_PASS && a.tile_nphase > 1 && tile_idx % a.tile_nphase != a.tile_phase)
     {
         return;         // deterministic mode: this launch takes every tile_nphase-th cell tile (see the launcher)
     }
-    nw = (long long)a.nw;
-    F0l = (long long)tile_idx*a.tile;
-    F1l = (F0l + a.tile < nw) ? F0l + a.tile : nw;                // [F0,F1)
-    F0 = (int)F0l; F1 = (int)F1l;
+    long long const nw = (long long)a.nw;
+    long long const F0l = (long long)tile_idx*a.tile;
+    long long const F1l = (F0l + a.tile < nw) ? F0l + a.tile : nw;                // [F0,F1)
+    int const F0 = (int)F0l, F1 = (int)F1l;
+    unsigned long long *probe_rec = nullptr;
+    unsigned pc_ring_inside = 0, pc_ring_lorentz = 0, pc_blocks = 0, pc_ring = 0, pc_near = 0, pc_momred = 0, pc_momlane = 0, pc_pre2 = 0, pc_walk = 0;    // wave-uniform
+    unsigned long long pt[8] = {}, pt_last = 0;         // clocks a wave spent in: preparation, moment reduction and adds, walk and
+                                                        // queue pushes, pre-pass 2, near field, the rest, queued points, moment terms
+    auto phase_mark = [&](int idx)
+    {
+        if constexpr (PROBE)
+        {
+            unsigned long long const now = __builtin_readcyclecounter();
+            pt[idx] += now - pt_last;
+            pt_last = now;
+        }
+    };
     if constexpr (PROBE)
     {
         unsigned long long const ntiles = ((unsigned long long)a.nw + a.tile - 1)/a.tile;
@@ -322,11 +129,39 @@ MP_TEMPLATE __device__ __forceinline__ void MP_CLASS::run()
             probe_rec[0] = __builtin_readcyclecounter();
         }
     }
-    cell0 = TWO_PASS ? F0 : F0 - fsteps;                                // cell of mom[.][0]
-    A0 = TWO_PASS ? F0 - halo : F0;                                     // grid index of acc[0]
+    auto probe_finish = [&](unsigned long long nlines, int R, bool corrected, bool use_moments)
+    {
+        if constexpr (PROBE)
+        {
+            if (lane == 0)
+            {
+                atomicAdd(&probe_rec[4], (unsigned long long)pc_blocks);
+                atomicAdd(&probe_rec[5], (unsigned long long)pc_ring);
+                atomicAdd(&probe_rec[6], (unsigned long long)pc_near);
+                atomicAdd(&probe_rec[7], (unsigned long long)pc_momred);
+                atomicAdd(&probe_rec[8], (unsigned long long)pc_momlane);
+                atomicAdd(&probe_rec[9], (unsigned long long)pc_pre2);
+                atomicAdd(&probe_rec[10], (unsigned long long)pc_walk);
+                for (int i = 0; i < 8; ++i)
+                {
+                    atomicAdd(&probe_rec[14 + i], pt[i]);
+                }
+                atomicAdd(&probe_rec[22], (unsigned long long)pc_ring_inside);
+                atomicAdd(&probe_rec[23], (unsigned long long)pc_ring_lorentz);
+            }
+            if (tid == 0)
+            {
+                probe_rec[2] = nlines;
+                probe_rec[3] = (unsigned long long)R | ((unsigned long long)corrected << 16) | ((unsigned long long)use_moments << 17);
+                probe_rec[1] = __builtin_readcyclecounter();
+            }
+        }
+    };
+    int const cell0 = TWO_PASS ? F0 : F0 - fsteps;                                // cell of mom[.][0]
+    int const A0 = TWO_PASS ? F0 - halo : F0;                                     // grid index of acc[0]
 
-    cs = a.colstate + (uint64_t)col*a.lay.stride;
-    lay = cs + a.lay.off_lay + (uint64_t)layer*4;
+    double const *cs = a.colstate + (uint64_t)col*a.lay.stride;
+    double const *lay = cs + a.lay.off_lay + (uint64_t)layer*4;
 
     for (int i = tid; i < nacc; i += kBlock)
     {
@@ -383,13 +218,13 @@ MP_TEMPLATE __device__ __forceinline__ void MP_CLASS::run()
     {
         if (tid == 0) probe_rec[11] = __builtin_readcyclecounter();      // prologue done
     }
-    jbeg = (uint64_t)range[0];
-    jend = (uint64_t)range[1];
+    uint64_t const jbeg = (uint64_t)range[0];
+    uint64_t const jend = (uint64_t)range[1];
 
-    wres_f = (float)a.wres;
-    inv_wres = 1./a.wres;
-    inv_wres_f = (float)inv_wres;
-    nw_i = (int)nw;
+    float const wres_f = (float)a.wres;
+    double const inv_wres = 1./a.wres;
+    float const inv_wres_f = (float)inv_wres;
+    int const nw_i = (int)nw;
 
     if constexpr (TREE && K == kMomWide)
     {
@@ -440,139 +275,96 @@ MP_TEMPLATE __device__ __forceinline__ void MP_CLASS::run()
         }
     }
 
-    R = near_radius(a, lay, ms_l, TWO_PASS ? F0l : F0l - fsteps_ll, F1l, fsteps, &use_moments, &corrected);
+    bool use_moments;
+    bool corrected;
+    int const R = near_radius(a, lay, ms_l, TWO_PASS ? F0l : F0l - fsteps_ll, F1l, fsteps, &use_moments, &corrected);
 
     // moments go to the tile's LDS block, or (tree form: ncell == 0, sparse lines, wide tiles) straight to the
     // zeroed level-0 block in global memory
-    direct = TREE && K == kMomWide && ncell == 0;     // (twelve moments <=> straight to global memory)
-    gcell = TWO_PASS ? a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*a.gmom_stride : nullptr;      // (CellStore)
-    cells = CellStore<K>(gcell, TREE ? hierarchy_cells(a.nw, a.tree_levels) : 0);
+    bool const direct = TREE && K == kMomWide && ncell == 0;     // (twelve moments <=> straight to global memory)
+    float *gcell = TWO_PASS ? a.gmom + ((uint64_t)col*a.lay.num_layers + layer)*a.gmom_stride : nullptr;      // (CellStore)
+    CellStore<K> const cells(gcell, TREE ? hierarchy_cells(a.nw, a.tree_levels) : 0);
+    auto mom_add = [&](int k, int cell, float v)
+    {
+        if (direct)
+        {
+            unsafeAtomicAdd(cells.moment((uint64_t)cell, k), v);
+        }
+        else
+        {
+            unsafeAtomicAdd(&mom[k*ncell + (cell - cell0)], v);
+        }
+    };
 
+    int qcount[Queue::classes] = {};     // wave-uniform
+    auto drain = [&](int cls, int first, int count)
+    {
+        unsigned long long t0 = 0;
+        if constexpr (PROBE) t0 = __builtin_readcyclecounter();
+        {
+            // (region 4 in packed registers: the lean kernel's shortwave instance -- gas_optics_dev.h)
+            constexpr bool kPacked4 = LEANP > 0 && !LEAN;
+            if (cls == 0) drain_class<0, kSplit ? 4 : 0, false>(acc, nq, wave, first, count, lane);
+            else if (cls == 1) drain_class<1, 1, kPacked4>(acc, nq, wave, first, count, lane);
+            else if (cls == 2) drain_class<2, 2, kPacked4>(acc, nq, wave, first, count, lane);
+            else if constexpr (kSplit) drain_class<3, 3, false>(acc, nq, wave, first, count, lane);
+        }
+        if constexpr (PROBE)
+        {
+            // (evaluating the queued points: a phase of its own, taken out of the one that called)
+            unsigned long long const dt = __builtin_readcyclecounter() - t0;
+            pt[6] += dt;
+            pt_last += dt;
+        }
+    };
 
+    // A near-centre point per lane (cls: its class of formula, -1: none) goes to its class's queue, which is evaluated in
+    // FULL batches of 64 -- one formula, all lanes busy.  A push that does not fit (the queues hold 64 ... 88 entries) is
+    // split: as many points as fill the batch go in, the batch is evaluated, the rest follow.  (Until round 4 a queue that
+    // could not take a push was emptied first, whatever it held: with 64-entry queues most batches were partial ones.)
+    auto queue_push = [&](int const cls, float const amp_q, float const xr, float const y_q, unsigned short const idx_q)
+    {
+#pragma unroll
+        for (int q = 0; q < Queue::classes; ++q)
+        {
+            unsigned long long const mk = __ballot(cls == q);
+            if (mk == 0ull)
+            {
+                continue;
+            }
+            int const npush = __popcll(mk);
+            if constexpr (PROBE) pc_near += (unsigned)npush;
+            int const rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0u));
+            int pos = qcount[q] + rank;                  // (qcount < 64 on entry: pos < 64 + 64)
+            bool mine = cls == q;
+            if (mine & (pos < 64))
+            {
+                nq->amp[q][wave][pos] = amp_q;
+                nq->xi[q][wave][pos] = xr;
+                nq->y[q][wave][pos] = y_q;
+                nq->idx[q][wave][pos] = idx_q;
+                mine = false;
+            }
+            qcount[q] += npush;
+            if (qcount[q] >= 64)
+            {
+                drain(q, 0, 64);                         // a full batch
+                qcount[q] -= 64;
+                pos -= 64;
+                if (mine)
+                {
+                    nq->amp[q][wave][pos] = amp_q;
+                    nq->xi[q][wave][pos] = xr;
+                    nq->y[q][wave][pos] = y_q;
+                    nq->idx[q][wave][pos] = idx_q;
+                }
+            }
+        }
+    };
 
     if constexpr (PROBE) pt_last = __builtin_readcyclecounter();
-
-    // ---------------------------------------------------------------------------------------------------------
-    // The LEAN form of the line loop (LEANP > 0: that many lines per lane; first pass of the two-pass form with the
-    // single-level gather).  Round 4's measurements (scripts/valu_mix*.hip, profiles/r4_*): the general loop above is not
-    // waiting on latencies, it fills the vector pipe -- with instructions that run at half rate on this chip (everything
-    // fp64, every conversion, compare, select, DPP move, min/max/floor; 4.5 cycles per wave against 2.4 for an fp32
-    // fma/mul/add) or at a quarter (rcp, exp, sqrt: 9.5), plus a scalar instruction stream that costs issue slots of its own.
-    // So this form does the per-line work in fp32 from packed records (GrtLineStore.lean_*), keeps compares and selects
-    // out of the per-point code, reduces TWO lines per lane with one pass of DPP exchanges, and leaves to the general
-    // code only what needs its fp64:
-    //   * centre index (kernels.c:431-432, bit-exact): nearest grid point and offset of the unshifted centre come with
-    //     the record; the pressure shift (kernels.c:44) is added to the offset in fp32, and a line whose sum comes within
-    //     1e-5 of the halfway mark goes through general_block, which forms the reference's fp64 expression;
-    //   * strength S(T) N (kernels.c:83-85, :459): exponent of e^(c2 E/T) split off exactly (two-float product), strength and
-    //     1/Q N as mantissa/exponent pairs -- relative error ~2e-7, the class of the fp32 line shape it multiplies;
-    //   * the Lorentzian of every point that sees one, A/((r - delta)^2 + eta^2), needs no Doppler width at all;
-    //   * near-centre points (|x| < XLIM1: Humlicek regions 2-4) need the reference's fp64 x and its y bit for bit (see
-    //     the file header): they wait in a raw per-wave queue (line, strength, grid point) and are prepared exactly, 64
-    //     at a time with all lanes busy, then sorted into the class queues as before;
-    //   * anything unusual (no Lorentz width, exponent not tabulated, strength outside the scaled range) is flagged and goes
-    //     through general_block whole.
-    // A workgroup takes this form if its near fields are seven points wide (R = 3: near_radius); otherwise every block of
-    // lines goes through general_block as before.
-    // ---------------------------------------------------------------------------------------------------------
-    // (per-slot and per-isotopologue tables, one array per quantity: a line's look-up then lands in its half of a register pair)
-    // (uniform per workgroup, but kept in VECTOR registers: an fp32 multiply or fma with a scalar operand runs at half rate)
-    // what the near field of this (tile, layer) is made of, from bounds on its lines' Doppler widths -- decided once per
-    // workgroup (each per-wave vote cost a compare, two scalar instructions and the expressions it tested), kept as bits of
-    // ONE scalar word (a flag as a lane mask of its own is two scalar registers, and the loop is short of those):
-    //   stim / farir the stimulated-emission factor is not 1 to fp32 / needs its series
-    //   corrected    region 1 beyond the near field is folded into the moments
-    //   lreg         only a line's own grid point can be anything but Lorentzian (half a grid step >= XLIM0 Doppler units)
-    //   v1           all seven points of every line lie in Humlicek region 1
-    //   nc_one       only a line's own grid point can be a near-centre point (|x| < XLIM1); nc_three: or its two neighbours
-    auto uniform_flag = [](bool b) { return __builtin_amdgcn_readfirstlane((int)b) != 0; };
-    if constexpr (LEANP > 0)
-    {
-        size_t const lean_off = ((size_t)(reinterpret_cast<unsigned char *>(invr + 1) - smem) + 15) & ~(size_t)15;
-        lt = reinterpret_cast<LeanTables *>(smem + lean_off);
-        raw = reinterpret_cast<LeanRaw *>(lt + 1);
-        // (round 5: the tiles at the grid's ends too.  The accumulator spans `halo` >= 8 points either side of the tile
-        // whatever the grid, points outside [0, nw) are dropped when it is flushed, a line whose centre index is off the
-        // grid belongs to no tile (kernels.c:433), and the far-field gather clips the windows as before -- the full-size
-        // parity tests pass with them; on the G1 longwave band, 51 tiles of 64 cells, the two end tiles on the general
-        // loop were 4 ms of a 30 ms launch, all of it on the two XCDs they are dealt to.)
-        lean_ok = uniform_flag(a.lean != 0 && use_moments && R == 3 && fsteps >= 8 && halo >= 8
-                               && a.lines.lean_a != nullptr);
-        if (lean_ok)
-        {
-            for (int i = tid; i < a.lay.num_slots; i += kBlock)
-            {
-                // (third entry: alpha of kernels.c:127 over the line centre, divided by RFM_voigt.c:94's sqrt(ln 2) -- 1/REPWID per cm-1)
-                lt->ps[i] = (float)ms_l[4*i];
-                lt->p_ps[i] = (float)ms_l[4*i + 1];
-                lt->dop[i] = (float)(((double)0.83255461115f/(double)kSqrln2)*ms_l[4*i + 3]);
-            }
-            for (int i = tid; i < a.lay.num_slots*GRT_MAX_ISO; i += kBlock)
-            {
-                double const v = q_l[i]*ms_l[(i/GRT_MAX_ISO)*4 + 2];                 // N_s/Q(T): kernels.c:85, :459
-                int e = 0;
-                double const m = frexp(v, &e);                                      // v = m 2^e, 1/2 <= m < 1
-                bool const ok = v > 0. && v < 1e300;
-                lt->qn_m[i] = ok ? (float)(2.*m) : 0.f;
-                lt->qn_e[i] = ok ? (float)(e - 1 - GRT_LEAN_S0_SHIFT) : 0.f;
-            }
-            for (int i = tid; i < kPowTable; i += kBlock)
-            {
-                lt->ptab[i] = (float)ptab[i];
-            }
-            __syncthreads();
-            double const kTd = ((double)(-1.4387686f)*1.4426950408889634)*lay[2];  // c2 log2(e)/T (kernels.c:75)
-            kh = (float)kTd;
-            kl = (float)(kTd - (double)kh);
-            c2t = (float)((double)(-1.4387686f)*lay[2]);
-            pw = (float)(lay[0]*inv_wres);
-            pavg_f = (float)lay[0];
-            a_norm = (float)(1./(3.14159265358979323846*a.wres));
-            wres_v = wres_f;
-            inv_wres_v = inv_wres_f;
-#ifndef GRT_LEAN_NOPIN
-            asm volatile("" : "+v"(kh), "+v"(kl), "+v"(c2t), "+v"(pw), "+v"(pavg_f), "+v"(a_norm), "+v"(wres_v), "+v"(inv_wres_v));
-#endif
-            // stimulated emission 1 - exp(c2 v0/T) (kernels.c:84): 1 to fp32 and beyond below exp(-20); the tile's lowest
-            // wavenumber decides for the whole workgroup (sorted store, shifts of a fraction of a grid step)
-            double const x2_tile = ((double)(-1.4387686f)*lay[2])*(a.w0 + ((double)F0 - 2.)*a.wres - 1.);
-            unsigned tf = (x2_tile > -21. ? kTfStim : 0u) | (x2_tile > -1.1 ? kTfFarir : 0u) | (corrected ? kTfCorrected : 0u);
-            {
-                double dop_hi = 0., dop_lo = 1e300;
-                for (int sl = 0; sl < a.lay.num_slots; ++sl)
-                {
-                    double const d = ((double)0.83255461115f/(double)kSqrln2)*ms_l[sl*4 + 3];
-                    dop_hi = fmax(dop_hi, d);
-                    dop_lo = d > 0. ? fmin(dop_lo, d) : dop_lo;
-                }
-                // grid step in Doppler units, wr = wres REPWID = wres/(centre x doppler factor), over the tile's lines (one cell
-                // and the largest shift of margin either side)
-                double const nu_lo = fmax(a.w0 + ((double)F0 - 1.5)*a.wres - a.lines.dmax*fabs(lay[0]), 1e-3);
-                double const nu_hi = a.w0 + ((double)F1 + 0.5)*a.wres + a.lines.dmax*fabs(lay[0]);
-                double const wr_min = dop_hi > 0. ? a.wres/(nu_hi*dop_hi) : 0.;
-                double const wr_max = dop_lo < 1e300 ? a.wres/(nu_lo*dop_lo) : 1e300;
-                // XLIM0^2 = 15100 + y (40 - 3.6 y) <= 15211.2 (y = 5.56), >= 15100 for y <= 4; XLIM1^2 <= 164 (RFM_voigt.c:109-118)
-                tf |= (0.25*wr_min*wr_min >= 1.003*15211.2 ? kTfLreg : 0u) | ((corrected && 12.25*wr_max*wr_max < 0.999*15100.) ? kTfV1 : 0u)
-                      | (0.25*wr_min*wr_min >= 164.1 ? kTfNcOne : 0u) | (2.25*wr_min*wr_min >= 164.1 ? kTfNcThree : 0u);
-            }
-            tflags = (unsigned)__builtin_amdgcn_readfirstlane((int)tf);
-        }
-    }
-
-    // (lean blocks start on even line indices -- a pair of the packed records; a line before jbeg in the first block is masked)
-    jal = lean_ok ? (jbeg & ~(uint64_t)1) : jbeg;
-    walk_first = a.deterministic ? (wave == 0 ? jal : jend) : jal + (uint64_t)wave*64*kLinesPerLane;
-    walk_stride = (a.deterministic ? 64u : (unsigned)kBlock)*kLinesPerLane;
-
-
-    // The packed records of the pair of lines b + 2 lane, b + 2 lane + 1 (b even; past the end of the workgroup's range:
-    // its last pair) -- requested one block ahead of their use.
-    // (the lean loop counts its lines from jal, in 32 bits -- the store has fewer than 2^32 lines where this loop runs: its
-    // range tests are scalar compares then; 64-bit ones are vector instructions on this chip)
-    nrel = (unsigned)(jend - jal);          // the range ends at jal + nrel
-    lo_first = (unsigned)(jbeg - jal);      // 0, or 1: the range begins on an odd index
-
-
+#include "mp_general_block.inc"
+#include "mp_lean_block.inc"
 
 
     // The workgroup's lines: lean blocks while that form applies and its list of handed-over lines has room; then the
@@ -817,17 +609,6 @@ MP_TEMPLATE __device__ __forceinline__ void MP_CLASS::run()
     }
     write_tile(a, acc, cs, col, layer, slice, F0l, F1l, tid);
     probe_finish(jend - jbeg, R, corrected, use_moments);
-}
-
-#include "mp_general_block.h"
-#include "mp_lean_block.h"
-
-template <bool TWO_PASS, bool TREE, int K, bool LEAN = false, bool PROBE = false, int LEANP = 0>
-__device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long long fsteps_ll, unsigned ngroups,
-                                               unsigned perm_stride, int ncell, int nacc, int halo)
-{
-    MpWorkgroup<TWO_PASS, TREE, K, LEAN, PROBE, LEANP> wg(a, fsteps_ll, ngroups, perm_stride, ncell, nacc, halo);
-    wg.run();
 }
 
 template <bool TWO_PASS, bool TREE = false, int K = kMom>

@@ -107,7 +107,7 @@ if gas:
     # (bench.py carries these counters into its line only while the kernels' source is the one they were taken on: ADVICE r4)
     import hashlib
     src_sha = hashlib.sha256(b"".join(open(os.path.join(ROOT, "grtcode_amd", "csrc", "hip", f), "rb").read()
-                                      for f in ("k_gas_optics_mp.hip", "mp_general_block.h", "mp_lean_block.h", "k_gas_optics_far.hip", "gas_optics_mp_dev.h", "gas_optics_dev.h"))).hexdigest()
+                                      for f in ("k_gas_optics_mp.hip", "mp_general_block.inc", "mp_lean_block.inc", "k_gas_optics_far.hip", "gas_optics_mp_dev.h", "gas_optics_dev.h"))).hexdigest()
     json.dump(dict({"tag": tag, "kernel_source_sha256": src_sha, "cols": cfg["chunk_columns"], "fast": cfg["fast"], "solvers": solv,
                     "gas_optics_sw": gas[sw_key], "gas_optics_lw": gas[lw_key]}, **keep),
               open(latest, "w"), indent=1)

@@ -127,7 +127,7 @@ def _kernel_source_sha():
     import hashlib
     hip = os.path.join(ROOT, "grtcode_amd", "csrc", "hip")
     return hashlib.sha256(b"".join(open(os.path.join(hip, f), "rb").read() for f in
-                                   ("k_gas_optics_mp.hip", "mp_general_block.h", "mp_lean_block.h", "k_gas_optics_far.hip",
+                                   ("k_gas_optics_mp.hip", "mp_general_block.inc", "mp_lean_block.inc", "k_gas_optics_far.hip",
                                     "gas_optics_mp_dev.h", "gas_optics_dev.h"))).hexdigest()
 
 
