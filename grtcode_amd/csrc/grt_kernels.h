@@ -82,6 +82,15 @@ typedef struct GrtColumnLayout
     uint64_t off_lay, off_ms, off_q, off_cont, off_h2o;
 } GrtColumnLayout;
 
+/* Where the spectral tables hold anything: [lo, hi) = from the first to one past the last grid point whose entry is not
+   +-0 (a CFC's band, a CIA pair's; the water-vapour pair: either 296 K coefficient).  Outside it the reference adds
+   cont*0 (kernels.c:585-630 run over the whole grid): a workgroup whose points lie outside skips the table's loads. */
+typedef struct GrtTableSpans
+{
+    int lo[GRT_MAX_TABLES], hi[GRT_MAX_TABLES];
+    int h2o_lo, h2o_hi;
+} GrtTableSpans;
+
 typedef struct GrtGasOpticsArgs
 {
     GrtLineStore lines;
@@ -144,6 +153,7 @@ typedef struct GrtGasOpticsArgs
                                  do, would otherwise be a few hundred long workgroups and thousands of short ones).  nslice is
                                  then 1 when no tile is cut and 2 when any is (moments and tau are added with atomics) */
     uint32_t n_items;
+    GrtTableSpans spans;
 } GrtGasOpticsArgs;
 
 int grt_launch_gas_optics(void *stream, GrtGasOpticsArgs const *a);

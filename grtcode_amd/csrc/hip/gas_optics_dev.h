@@ -645,7 +645,10 @@ __device__ __forceinline__ void candidate_range_wave(GrtGasOpticsArgs const &a, 
 // Epilogue: fold in continua / CFC / CIA and write the tile once.
 // Two consecutive grid points per lane: one 16-byte store per lane (1 KiB per wave instruction)
 // whenever the row start is 16-byte aligned, which also is the store shape WRITE_SIZE is
-// calibrated for on gfx950.
+// calibrated for on gfx950 -- and one 16-byte load per lane and table, of the tables that hold anything
+// at this tile's points (GrtTableSpans: the others would add cont*0).  The tables are read once per
+// (tile, layer, column) from L2: ten of them were 1.45 of the shortwave gather's 4.8 ms per 64 columns
+// with 8-byte loads and every table read everywhere.
 __device__ __forceinline__ void write_tile(GrtGasOpticsArgs const &a, double const *acc, double const *cs,
                                            int col, int layer, int slice, long long F0l, long long F1l, int tid)
 {
@@ -654,31 +657,39 @@ __device__ __forceinline__ void write_tile(GrtGasOpticsArgs const &a, double con
     double const *h2o = cs + a.lay.off_h2o + (uint64_t)layer*4;
     double *out = a.tau + (uint64_t)col*a.tau_col_stride + (uint64_t)layer*a.nw;
     bool const pair_ok = (a.nslice == 1) && ((reinterpret_cast<uintptr_t>(out + F0l) & 15u) == 0);
-    auto finish = [&](long long f) -> double
+    bool const h2o_here = add_tables && a.lay.has_h2o_ctm && a.spans.h2o_lo < F1l && a.spans.h2o_hi > F0l;
+    // the entries of one table at f and f + 1 (f - F0l is even)
+    auto two = [&](double const *row, long long f, bool has1) -> double2
     {
-        double v = acc[f - F0l];
-        if (add_tables)
+        if (has1 && (reinterpret_cast<uintptr_t>(row + F0l) & 15u) == 0)
         {
-            if (a.lay.has_h2o_ctm)
-            {
-                // kernels.c:484-487; h2o = {N*(296/T), Ps, P-Ps, 296-T};
-                // tables F296,S296,CKDF,CKDS (launch.c:165-170)
-                double const CF = a.h2o_tables[f], CS = a.h2o_tables[a.nw + f];
-                double const T0F = a.h2o_tables[2*a.nw + f], T0 = a.h2o_tables[3*a.nw + f];
-                v += h2o[0]*((CS*h2o[1]*exp(T0*h2o[3])) + (CF*h2o[2]*exp(T0F*h2o[3])));
-            }
-            for (int k = 0; k < a.lay.num_tables; ++k)
-            {
-                v += cont[k]*a.tables[(uint64_t)k*a.nw + f];
-            }
+            return *reinterpret_cast<double2 const *>(row + f);
         }
-        return v;
+        return make_double2(row[f], has1 ? row[f + 1] : 0.);
     };
     for (long long f = F0l + 2*tid; f < F1l; f += 2*kBlock)
     {
-        double const v0 = finish(f);
         bool const has1 = f + 1 < F1l;
-        double const v1 = has1 ? finish(f + 1) : 0.;
+        double v0 = acc[f - F0l];
+        double v1 = has1 ? acc[f + 1 - F0l] : 0.;
+        if (h2o_here)
+        {
+            // kernels.c:484-487; h2o = {N*(296/T), Ps, P-Ps, 296-T};
+            // tables F296,S296,CKDF,CKDS (launch.c:165-170)
+            double2 const CF = two(a.h2o_tables, f, has1), CS = two(a.h2o_tables + a.nw, f, has1);
+            double2 const T0F = two(a.h2o_tables + 2*a.nw, f, has1), T0 = two(a.h2o_tables + 3*a.nw, f, has1);
+            v0 += h2o[0]*((CS.x*h2o[1]*exp(T0.x*h2o[3])) + (CF.x*h2o[2]*exp(T0F.x*h2o[3])));
+            v1 += h2o[0]*((CS.y*h2o[1]*exp(T0.y*h2o[3])) + (CF.y*h2o[2]*exp(T0F.y*h2o[3])));
+        }
+        for (int k = 0; add_tables && k < a.lay.num_tables; ++k)
+        {
+            if (a.spans.lo[k] < F1l && a.spans.hi[k] > F0l)
+            {
+                double2 const t = two(a.tables + (uint64_t)k*a.nw, f, has1);
+                v0 += cont[k]*t.x;
+                v1 += cont[k]*t.y;
+            }
+        }
         if (pair_ok && has1)
         {
             *reinterpret_cast<double2 *>(out + f) = make_double2(v0, v1);

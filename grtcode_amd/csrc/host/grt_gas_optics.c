@@ -564,6 +564,16 @@ int grt_load_table_on_grid(char const *path, int expect_cols, SpectralGrid_t con
     return GRTCODE_SUCCESS;
 }
 
+/* [lo, hi): first .. one past the last entry that is not +-0 (NaN counts as an entry); lo = hi = 0 for an empty table */
+static void table_span(fp_t const *host, uint64_t n, int *lo, int *hi)
+{
+    uint64_t first = 0, last = n;
+    while (first < n && host[first] == 0.) ++first;
+    while (last > first && host[last - 1] == 0.) --last;
+    *lo = first < last ? (int)first : 0;
+    *hi = first < last ? (int)last : 0;
+}
+
 static int upload_table(GasOptics_t *go, fp_t const *host, double *dev_row)
 {
     void *s = grt_dev_stream(go->device);
@@ -585,6 +595,7 @@ static int add_linear_table(GasOptics_t *go, char const *path, int kind, int ref
     if (rc == GRTCODE_SUCCESS)
     {
         rc = upload_table(go, host, row);
+        table_span(host, go->grid.n, &im->spans.lo[im->num_lin], &im->spans.hi[im->num_lin]);
     }
     free(host);
     GRT_TRY(rc);
@@ -823,6 +834,22 @@ static int register_molecule(GasOptics_t *go, int molecule_id, GrtHostLines *lin
             {
                 rc = upload_table(go, host, im->h2o_tables + (size_t)k*go->grid.n);
                 go->h2o_cc.coefs[k] = im->h2o_tables + (size_t)k*go->grid.n;
+                if (k < 2)
+                {
+                    /* tau's term is N (CS Ps e^.. + CF (P - Ps) e^..): nothing where both 296 K coefficients are zero */
+                    int lo, hi;
+                    table_span(host, go->grid.n, &lo, &hi);
+                    if (k == 0 || (hi > 0 && im->spans.h2o_hi == 0))
+                    {
+                        im->spans.h2o_lo = lo;
+                        im->spans.h2o_hi = hi;
+                    }
+                    else if (hi > 0)
+                    {
+                        im->spans.h2o_lo = lo < im->spans.h2o_lo ? lo : im->spans.h2o_lo;
+                        im->spans.h2o_hi = hi > im->spans.h2o_hi ? hi : im->spans.h2o_hi;
+                    }
+                }
             }
         }
         free(host);
@@ -1808,6 +1835,7 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
     a->colstate = im->colstate_d;
     a->tables = im->lin_tables;
     a->h2o_tables = im->h2o_tables;
+    a->spans = im->spans;
     a->w0 = go->bins.w0;
     a->wres = go->bins.wres;
     a->nw = go->bins.num_wpoints;

@@ -115,6 +115,7 @@ typedef struct GrtGasOpticsImpl
     int num_lin;
     int lin_kind[GRT_MAX_TABLES];  /* 0: O3 continuum, 1: CFC, 2: CIA */
     int lin_ref[GRT_MAX_TABLES];   /* O3: slot; CFC: index into cfcs[]; CIA: index into cia[] */
+    GrtTableSpans spans;           /* where each table is not zero (grt_kernels.h) */
     /* column-state staging */
     GrtColumnLayout layout;
     int layout_cols;               /* capacity (columns) of the buffers below */

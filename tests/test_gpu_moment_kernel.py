@@ -142,6 +142,17 @@ def test_sparse_lines_many_cells_per_wave(tmp_path, oracle, lib, device):
     check(band, device, oracle, lib, syn.profile(4, 11))
 
 
+def test_tables_that_start_and_end_inside_tiles_on_a_grid_of_odd_length(tmp_path, oracle, lib, device):
+    """The epilogue (write_tile) reads a spectral table only where it holds anything (GrtTableSpans) and two entries per
+    load where the table's row is 16-byte aligned: 621 grid points put every other row off that alignment, the CFC tables
+    (700 - 1300 cm-1) begin and end inside tiles, the N2-N2 table (1 - 400) lies wholly outside the grid, the O2 pairs'
+    (from 1200) begin inside it."""
+    band = Band(str(tmp_path), 690.0, 1310.0, 1.0, 2500)
+    assert band.nw % 2 == 1
+    check(band, device, oracle, lib, syn.profile(6, 9))
+    check(band, device, oracle, lib, syn.profile(3, 9), tile=64, nslice=2)
+
+
 def test_lines_hugging_the_grid_edges(tmp_path, oracle, lib, device):
     """Windows clipped at index 0 and n-1, centres pushed off the grid by the pressure shift (kernels.c:433-437)."""
     band = Band(str(tmp_path), 100.0, 400.0, 1.0, 900, mols=[syn.H2O, syn.CO2], with_cfc=False, with_cia=False,
