@@ -85,7 +85,7 @@ def build(force=False, verbose=False):
     force = force or _flags_changed()
     headers = [os.path.join(ROOT, "include", h) for h in ("grtcode_hip_api.h", "grt_ext.h")]
     headers += [os.path.join(CSRC, "grt_kernels.h"), os.path.join(CSRC, "hip", "gas_optics_dev.h"), os.path.join(CSRC, "hip", "gas_optics_mp_dev.h"), os.path.join(CSRC, "hip", "mp_general_block.inc"), os.path.join(CSRC, "hip", "mp_lean_block.inc"),
-                os.path.join(CSRC, "hip", "optics_dev.h"), os.path.join(CSRC, "host", "grt_internal.h"), os.path.join(CSRC, "host", "grt_molecule_table.h")]
+                os.path.join(CSRC, "hip", "optics_dev.h"), os.path.join(CSRC, "hip", "exp_pair.h"), os.path.join(CSRC, "host", "grt_internal.h"), os.path.join(CSRC, "host", "grt_molecule_table.h")]
     objs, jobs = [], []
     for f in HOST_SRC:
         src, obj = os.path.join(CSRC, "host", f), os.path.join(OBJ, f[:-2] + ".o")

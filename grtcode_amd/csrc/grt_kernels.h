@@ -154,7 +154,27 @@ typedef struct GrtGasOpticsArgs
                                  then 1 when no tile is cut and 2 when any is (moments and tau are added with atomics) */
     uint32_t n_items;
     GrtTableSpans spans;
+    int skip_tables;          /* != 0: leave the spectral tables' part (continua, CFC, CIA) out of tau: the caller adds it where
+                                 it reads tau (the pipeline's fused solvers, GrtContinua) -- a table entry is then read once
+                                 per grid point and column instead of once per layer as well */
 } GrtGasOpticsArgs;
+
+/* What a kernel needs to add the spectral tables' part of the gas optical depth itself (write_tile's expressions in
+   write_tile's order, gas_optics_dev.h: tau + water-vapour continuum + the linear tables in ascending order). */
+typedef struct GrtContinua
+{
+    double const *colstate;   /* [ncol][stride]: GrtColumnLayout's cont [L][GRT_MAX_TABLES] and h2o [L][4] blocks */
+    uint64_t stride, off_cont, off_h2o;
+    double const *tables;     /* [num_tables][nw] */
+    double const *h2o_tables; /* [4][nw] or NULL */
+    int num_tables, has_h2o_ctm;
+    GrtTableSpans spans;
+} GrtContinua;
+/* tau_gas [ncol][L][nw] (column stride col_stride) += the tables' part: completes a tau the gas-optics launch wrote with
+   skip_tables set (same doubles as without it) */
+int grt_launch_add_continua(void *stream, GrtContinua const *c, int num_layers, int ncol, uint64_t nw,
+                            double *tau_gas, uint64_t col_stride);
+
 
 int grt_launch_gas_optics(void *stream, GrtGasOpticsArgs const *a);
 /* HIP-event brackets on the library stream (grt_device.c; grt_ext.h: grt_profile_*) */
@@ -235,6 +255,8 @@ typedef struct GrtLwArgs
        down surface, down user) at partials[(c*6 + k)*nblocks + block]; grt_launch_reduce_partials finishes. */
     double const *tau_gas, *n_layer;
     double *partials;
+    int add_continua;               /* fused form: tau_gas was written without the tables' part -- add it (continua) */
+    GrtContinua continua;
     /* spectral form, optional: scratch [ncol][6 L][nw].  When set, the four streams' extinctions and the two effective
        Planck terms of every layer are worked out first by one thread per (layer, wavenumber), and the two sweeps read
        them (the same doubles through the same expressions: identical fluxes) -- see GrtSwArgs.layer_props */
@@ -266,6 +288,8 @@ typedef struct GrtSwArgs
     double const *tau_gas, *n_layer;
     double w0;
     double *partials, *park;
+    int add_continua;               /* as in GrtLwArgs */
+    GrtContinua continua;
     /* fused form, no flux asked for between top and surface (user_level -1, 0 or num_levels - 1): ONE sweep from the top,
        nothing parked (k_shortwave.hip); 0: the two sweeps of the reference's order (GRT_SW_TWO_SWEEPS=1 in the environment) */
     int one_sweep;

@@ -652,7 +652,7 @@ __device__ __forceinline__ void candidate_range_wave(GrtGasOpticsArgs const &a, 
 __device__ __forceinline__ void write_tile(GrtGasOpticsArgs const &a, double const *acc, double const *cs,
                                            int col, int layer, int slice, long long F0l, long long F1l, int tid)
 {
-    bool const add_tables = (slice == 0);
+    bool const add_tables = (slice == 0) && !a.skip_tables;
     double const *cont = cs + a.lay.off_cont + (uint64_t)layer*GRT_MAX_TABLES;
     double const *h2o = cs + a.lay.off_h2o + (uint64_t)layer*4;
     double *out = a.tau + (uint64_t)col*a.tau_col_stride + (uint64_t)layer*a.nw;

@@ -91,6 +91,16 @@ __global__ __launch_bounds__(kBlock) void lw_kernel(GrtLwArgs a)
     int const user = a.user_level;
     double out[6] = {0., 0., 0., 0., 0., 0.};     // up TOA, up surface, up user, down TOA, down surface, down user
 
+    // (the gas-optics launch left the spectral tables' part of tau to this kernel: a table entry read once per point)
+    PointContinua pc;
+    long long const blk_lo = (long long)blockIdx.x*kBlock, blk_hi = blk_lo + kBlock < (long long)a.nw ? blk_lo + kBlock : (long long)a.nw;
+    bool const add_continua = FUSED && a.add_continua;
+    double const *cstate = a.continua.colstate + (uint64_t)col*a.continua.stride;
+    if (add_continua)
+    {
+        continua_load(a.continua, a.nw, ii, blk_lo, blk_hi, pc);
+    }
+
     // absorption optical depth of layer j: tau (1 - omega)  (longwave.c:252)
     auto layer_tau = [&](int j) -> double
     {
@@ -98,7 +108,12 @@ __global__ __launch_bounds__(kBlock) void lw_kernel(GrtLwArgs a)
         if (FUSED)
         {
             double t, om, gg;
-            clear_sky_combine(tau[o], rayleigh_tau(w, nl[j]), t, om, gg);
+            double tg = tau[o];
+            if (add_continua)
+            {
+                tg = continua_add(a.continua, pc, cstate, j, a.nw, ii, blk_lo, blk_hi, tg);
+            }
+            clear_sky_combine(tg, rayleigh_tau(w, nl[j]), t, om, gg);
             return t*(1. - om);
         }
         return omega ? tau[o]*(1. - omega[o]) : tau[o]*(1. - 0.);

@@ -127,6 +127,25 @@ __global__ __launch_bounds__(kBlock) void clear_sky_kernel(int L, int ncol, doub
     }
 }
 
+// tau_gas += the spectral tables' part, for a tau the gas-optics launch wrote without it (GrtGasOpticsArgs.skip_tables):
+// the pipeline's fused solvers add it themselves; this completes the array for a caller that wants to LOOK at tau_gas
+// (grt_pipeline_views).  One thread per grid point and column, walking the layers: continua_add's doubles.
+__global__ __launch_bounds__(kBlock) void add_continua_kernel(GrtContinua c, int L, uint64_t nw, double *tau_gas, uint64_t col_stride)
+{
+    uint64_t const i = (uint64_t)blockIdx.x*kBlock + threadIdx.x;
+    int const col = blockIdx.y;
+    long long const lo = (long long)blockIdx.x*kBlock, hi = lo + kBlock < (long long)nw ? lo + kBlock : (long long)nw;
+    uint64_t const ii = i < nw ? i : nw - 1;
+    PointContinua pc;
+    continua_load(c, nw, ii, lo, hi, pc);
+    double const *cstate = c.colstate + (uint64_t)col*c.stride;
+    double *tau = tau_gas + (uint64_t)col*col_stride + ii;
+    for (int j = 0; j < L && i < nw; ++j)
+    {
+        tau[(uint64_t)j*nw] = continua_add(c, pc, cstate, j, nw, ii, lo, hi, tau[(uint64_t)j*nw]);
+    }
+}
+
 // framework/src/driver.c:302-326: one workgroup per row; wavefront shuffle reduction,
 // then LDS across the 4 waves.  (Summation order differs from the serial loop.)
 __global__ __launch_bounds__(kBlock) void integrate_rows_kernel(double const *const *rows, uint64_t nw,
@@ -248,6 +267,14 @@ extern "C" int grt_launch_clear_sky_optics(void *stream, int num_layers, int nco
 {
     hipLaunchKernelGGL(clear_sky_kernel, dim3(grid_for((uint64_t)num_layers*nw*ncol)), dim3(kBlock), 0,
                        (hipStream_t)stream, num_layers, ncol, w0, dw, nw, n_layer, tau_gas, tau, omega, g);
+    return (int)hipGetLastError();
+}
+
+extern "C" int grt_launch_add_continua(void *stream, GrtContinua const *c, int num_layers, int ncol, uint64_t nw,
+                                       double *tau_gas, uint64_t col_stride)
+{
+    hipLaunchKernelGGL(add_continua_kernel, dim3((unsigned)((nw + kBlock - 1)/kBlock), (unsigned)ncol), dim3(kBlock), 0,
+                       (hipStream_t)stream, *c, num_layers, nw, tau_gas, col_stride);
     return (int)hipGetLastError();
 }
 

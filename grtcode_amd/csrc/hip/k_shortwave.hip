@@ -24,6 +24,7 @@
 #include <stdint.h>
 #include "../grt_kernels.h"
 #include "optics_dev.h"
+#include "exp_pair.h"
 
 #pragma clang fp contract(off)
 
@@ -61,7 +62,8 @@ __device__ __forceinline__ LayerRT eddington(double omega, double tau, double mu
         double const alpha2 = gamma1*gamma3 + gamma2*gamma4;
         double const k = sqrt(gamma1*gamma1 - gamma2*gamma2);
         double t = tau;
-        if (1./mu > k && tau/mu > kMaxExpArg)
+        double const tau_over_mu = tau/mu;
+        if (1./mu > k && tau_over_mu > kMaxExpArg)
         {
             t = kMaxExpArg*mu;
         }
@@ -69,7 +71,16 @@ __device__ __forceinline__ LayerRT eddington(double omega, double tau, double mu
         {
             t = kMaxExpArg/k;
         }
-        double const tp = exp(t/mu);
+        // (t is tau unless a clamp struck: the quotient above is then t/mu -- the same division of the same doubles)
+        double t_over_mu = tau_over_mu;
+        if (t != tau)
+        {
+            t_over_mu = t/mu;
+        }
+        // (the three exponential pairs of a layer -- exp(+-t/mu) here and in the other beam's call, exp(+-t k) -- each
+        // through one shared reduction and polynomial: exp_pair.h)
+        double tp, tm;
+        grt_exp_pair(t_over_mu, &tp, &tm);
         if (tp <= 1.0)
         {
             r.R = 0.;
@@ -78,7 +89,6 @@ __device__ __forceinline__ LayerRT eddington(double omega, double tau, double mu
         }
         else
         {
-            double const tm = exp(-t/mu);
             double tkm, tkp;
             if (shared.valid && shared.t == t)
             {
@@ -87,8 +97,7 @@ __device__ __forceinline__ LayerRT eddington(double omega, double tau, double mu
             }
             else
             {
-                tkm = exp(-t*k);
-                tkp = exp(t*k);
+                grt_exp_pair(t*k, &tkp, &tkm);
                 shared.t = t;
                 shared.tkm = tkm;
                 shared.tkp = tkp;
@@ -181,13 +190,28 @@ __global__ __launch_bounds__(kBlock) void sw_kernel(GrtSwArgs a)
     int const user = a.user_level;
     double out[6] = {0., 0., 0., 0., 0., 0.};     // up TOA, up surface, up user, down TOA, down surface, down user
 
+    // (the gas-optics launch left the spectral tables' part of tau to this kernel: a table entry read once per point)
+    PointContinua pc;
+    long long const blk_lo = (long long)blockIdx.x*kBlock, blk_hi = blk_lo + kBlock < (long long)nw ? blk_lo + kBlock : (long long)nw;
+    bool const add_continua = FUSED && a.add_continua;
+    double const *cstate = a.continua.colstate + (uint64_t)col*a.continua.stride;
+    if (add_continua)
+    {
+        continua_load(a.continua, nw, ii, blk_lo, blk_hi, pc);
+    }
+
     auto props_of = [&](int j) -> LayerProps
     {
         uint64_t const o = (uint64_t)j*nw;
         if (FUSED)
         {
             double t, om, gg;
-            clear_sky_combine(tau[o], rayleigh_tau(w, nl[j]), t, om, gg);
+            double tg = tau[o];
+            if (add_continua)
+            {
+                tg = continua_add(a.continua, pc, cstate, j, nw, ii, blk_lo, blk_hi, tg);
+            }
+            clear_sky_combine(tg, rayleigh_tau(w, nl[j]), t, om, gg);
             return layer_props(om, gg, t, mu_dir, mu_dif);
         }
         return layer_props(omega[o], g[o], tau[o], mu_dir, mu_dif);

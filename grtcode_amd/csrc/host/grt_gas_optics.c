@@ -1824,6 +1824,28 @@ EXTERN int grt_deterministic(void)
     return env != NULL && env[0] != '\0' && !(env[0] == '0' && env[1] == '\0');
 }
 
+int grt_gas_optics_defer_tables(GasOptics_t *go, int on)
+{
+    GrtGasOpticsImpl *im = impl_of(go);
+    im->defer_tables = on != 0 && go->optical_depth_method == line_sample;
+    return im->defer_tables;
+}
+
+void grt_gas_optics_continua(GasOptics_t *go, GrtContinua *c)
+{
+    GrtGasOpticsImpl *im = impl_of(go);
+    memset(c, 0, sizeof(*c));
+    c->colstate = im->colstate_d;
+    c->stride = im->layout.stride;
+    c->off_cont = im->layout.off_cont;
+    c->off_h2o = im->layout.off_h2o;
+    c->tables = im->lin_tables;
+    c->h2o_tables = im->h2o_tables;
+    c->num_tables = im->num_lin;
+    c->has_h2o_ctm = im->h2o_tables != NULL;
+    c->spans = im->spans;
+}
+
 int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_stride, GrtGasOpticsArgs *a)
 {
     GrtGasOpticsImpl *im = impl_of(go);
@@ -1836,6 +1858,7 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
     a->tables = im->lin_tables;
     a->h2o_tables = im->h2o_tables;
     a->spans = im->spans;
+    a->skip_tables = im->defer_tables && go->optical_depth_method == line_sample;
     a->w0 = go->bins.w0;
     a->wres = go->bins.wres;
     a->nw = go->bins.num_wpoints;

@@ -116,6 +116,7 @@ typedef struct GrtGasOpticsImpl
     int lin_kind[GRT_MAX_TABLES];  /* 0: O3 continuum, 1: CFC, 2: CIA */
     int lin_ref[GRT_MAX_TABLES];   /* O3: slot; CFC: index into cfcs[]; CIA: index into cia[] */
     GrtTableSpans spans;           /* where each table is not zero (grt_kernels.h) */
+    int defer_tables;              /* launches leave the tables' part of tau to the caller (grt_gas_optics_defer_tables) */
     /* column-state staging */
     GrtColumnLayout layout;
     int layout_cols;               /* capacity (columns) of the buffers below */
@@ -134,6 +135,12 @@ int grt_gas_optics_wait_staging(GasOptics_t *go);        /* until the last batch
 int grt_column_state(GasOptics_t const *go, fp_t const *p_mb, fp_t const *t,
                      fp_t const *x_mol /* [NUM_MOLS][V] by id-1 */, fp_t const *x_cfc /* [NUM_CFCS][V] */,
                      fp_t const *x_cia /* [NUM_CIAS][V] */, double *dst);
+/* The pipeline's fused solvers add the spectral tables' part of tau themselves (GrtContinua): on != 0 asks the object's
+   next launches to leave it out; returns whether they will (line-sample method only).  The caller switches it off again
+   after its launch -- the object's own entry points always deliver the whole tau.  grt_gas_optics_continua: what a
+   kernel needs to add that part for the columns of the object's last launch. */
+int grt_gas_optics_defer_tables(GasOptics_t *go, int on);
+void grt_gas_optics_continua(GasOptics_t *go, GrtContinua *c);
 int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_stride,
                       GrtGasOpticsArgs *args);
 

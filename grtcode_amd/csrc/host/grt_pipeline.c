@@ -25,6 +25,8 @@ typedef struct GrtBand
     GasOptics_t *gas;
     uint64_t n;            /* grid points */
     double *tau_gas;       /* [cols][L][n] */
+    int tau_gas_lacks_tables;      /* the last run left the spectral tables' part to the solver (grt_pipeline_views completes it) */
+    int last_cols;
     double *tau, *omega, *g;
     double *flux_up, *flux_down;   /* [cols][V][n] */
     double **rows_d;       /* [cols][6] device row pointers for the trapezoid */
@@ -255,6 +257,15 @@ EXTERN int grt_pipeline_views(GrtPipeline_t *pipeline, int band, fp_t **tau_gas,
         GRT_FAIL(GRTCODE_VALUE_ERR, "this pipeline keeps no spectra (only tau_gas): create it with "
                  "grt_pipeline_create_ex(..., keep_spectra = 1).%s", "");
     }
+    if (tau_gas != NULL && b->tau_gas_lacks_tables)
+    {
+        /* the last run's solver added the tables' part of tau itself: complete the array for the caller who looks at it */
+        GrtContinua c;
+        grt_gas_optics_continua(b->gas, &c);
+        GRT_TRY(grt_dev_check(grt_launch_add_continua(grt_dev_stream_of_lane(pipeline->device, pipeline->lane), &c, b->gas->num_layers, b->last_cols,
+                                                      b->n, b->tau_gas, (uint64_t)b->gas->num_layers*b->n), "continua kernel"));
+        b->tau_gas_lacks_tables = 0;
+    }
     if (tau_gas) *tau_gas = b->tau_gas;
     if (tau) *tau = b->tau;
     if (omega) *omega = b->omega;
@@ -344,8 +355,22 @@ EXTERN int grt_pipeline_run(GrtPipeline_t *p, GrtColumns_t const *cols, fp_t *fl
         }
         SpectralGrid_t const *grid = &b->gas->grid;
         uint64_t const per_opt = (uint64_t)L*b->n, per_flux = (uint64_t)V*b->n;
-        /* gas optics (launch.c:40-226) */
-        GRT_TRY(grt_optical_depth_batch(b->gas, cols, b->tau_gas));
+        /* gas optics (launch.c:40-226).  Fused form: the spectral tables' part of tau (continua, CFC, CIA) is left to the
+           solver kernel, which reads a table entry once per grid point and column instead of once per layer as well
+           (the same expressions in the same order: the same doubles; GRT_DEFER_CONTINUA=0 in the environment: comparison runs) */
+        GrtContinua continua;
+        int defer = 0;
+        if (!p->keep_spectra)
+        {
+            char const *env = getenv("GRT_DEFER_CONTINUA");
+            defer = grt_gas_optics_defer_tables(b->gas, !(env != NULL && env[0] == '0'));
+        }
+        int const rc_gas = grt_optical_depth_batch(b->gas, cols, b->tau_gas);
+        grt_gas_optics_defer_tables(b->gas, 0);                  /* (the object's own entry points deliver the whole tau) */
+        GRT_TRY(rc_gas);
+        grt_gas_optics_continua(b->gas, &continua);              /* (the column state's place is known after the batch call) */
+        b->tau_gas_lacks_tables = defer;
+        b->last_cols = C;
         if (!p->keep_spectra)
         {
             /* Rayleigh, add_optics({gas, rayleigh}), solver and -integrated output (driver.c:268, 382-424, 302-326)
@@ -362,6 +387,8 @@ EXTERN int grt_pipeline_run(GrtPipeline_t *p, GrtColumns_t const *cols, fp_t *fl
                 a.emis = p->emis_d; a.emis_stride = 0;
                 a.user_level = p->user_level;
                 a.partials = b->partials;
+                a.add_continua = defer;
+                if (defer) a.continua = continua;
                 slot = grt_profile_begin(s, 3);
                 krc = grt_launch_lw(s, &a);
                 grt_profile_end(s, slot);
@@ -391,6 +418,8 @@ EXTERN int grt_pipeline_run(GrtPipeline_t *p, GrtColumns_t const *cols, fp_t *fl
                     b->park = pk;
                 }
                 a.park = b->park;
+                a.add_continua = defer;
+                if (defer) a.continua = continua;
                 slot = grt_profile_begin(s, 4);
                 krc = grt_launch_sw(s, &a);
                 grt_profile_end(s, slot);

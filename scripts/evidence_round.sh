@@ -35,7 +35,7 @@ if has lines; then
     stamp "the other configurations' lines"
     python3 bench.py --columns 100 --no-extras --no-cpu-baseline > $OUT/strong_100_columns_bench_line.json 2>/dev/null || exit 1
     python3 bench.py --lw-dw 0.1 --sw-dw 10 --cols 64 --no-extras --no-cpu-baseline > $OUT/era5_like_bench_line.json 2>/dev/null || exit 1
-    python3 bench.py --lanes 2 --no-extras --no-cpu-baseline > $OUT/two_streams_bench_line.json 2>/dev/null || exit 1
+    python3 bench.py --lanes 2 --cols 128 --chunk 64 --no-extras --no-cpu-baseline > $OUT/two_streams_bench_line.json 2>/dev/null || exit 1
 fi
 if has g3; then
     stamp "G3 (0.001 cm-1 longwave) through the whole pipeline; 32 columns per step in column groups"

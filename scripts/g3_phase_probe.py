@@ -21,13 +21,14 @@ def main():
     ap.add_argument("--dw", type=float, default=0.001)
     ap.add_argument("--lines", type=int, default=W.LW_LINES)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--sw", action="store_true", help="the shortwave band (1 - 50 000 cm-1, 1.5e6 lines) instead of the longwave one")
     args = ap.parse_args()
     lib = api.load_library()
     device = api.create_device(0)
     root = tempfile.mkdtemp(prefix="grt_g3p_")
-    files, _ = W.write_tables(root, sw=False)
-    spec = (1.0, 3250.0, args.dw)
-    lines = W.band_lines(args.lines, spec, 20261003)
+    files, _ = W.write_tables(root, sw=args.sw)
+    spec = (1.0, 50000.0 if args.sw else 3250.0, args.dw)
+    lines = W.band_lines(W.SW_LINES if args.sw and args.lines == W.LW_LINES else args.lines, spec, 20261004 if args.sw else 20261003)
     go, grid = W.build_band(device, spec, lines, files, W.NUM_LEVELS)
     col = syn.profile(0, W.NUM_LEVELS)
     for m in W.MOL_ORDER:

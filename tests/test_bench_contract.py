@@ -202,6 +202,8 @@ def test_round5_fine_grid_lines_traffic_and_the_unchanged_caller():
     assert strong["scaling"] == "strong" and strong["config"]["columns_per_step"] == 100 and strong["value"] >= 570.0
     drv = load("r5_reference_driver_timing.json")
     assert drv["fast3"]["columns_per_s"] >= 250.0 and drv["fast3rows"]["columns_per_s"] > drv["fast3"]["columns_per_s"]
+    two = load("r5_two_streams_bench_line.json")               # the line named "two streams" must have run two
+    assert two["config"]["launches_in_flight"] == 2 and two["config"]["chunk_columns"] == 64 and two["value"] >= 570.0
 
 
 def test_round5_suite_logs_are_green():
