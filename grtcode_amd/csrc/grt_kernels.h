@@ -154,6 +154,9 @@ typedef struct GrtGasOpticsArgs
                                  then 1 when no tile is cut and 2 when any is (moments and tau are added with atomics) */
     uint32_t n_items;
     GrtTableSpans spans;
+    int *radius_table;        /* two-pass form, single-level gather, or NULL: [ncol][L][cell tiles] near-field radii of the first
+                                 pass's cell tiles (near_radius), filled by the launcher before the gather, whose workgroups
+                                 each look at the ten or so tiles they touch */
     int skip_tables;          /* != 0: leave the spectral tables' part (continua, CFC, CIA) out of tau: the caller adds it where
                                  it reads tau (the pipeline's fused solvers, GrtContinua) -- a table entry is then read once
                                  per grid point and column instead of once per layer as well */

@@ -6,6 +6,7 @@
 #include <math.h>
 #include <stdint.h>
 #include "../grt_kernels.h"
+#include "exp_pair.h"
 
 #pragma clang fp contract(off)
 
@@ -678,8 +679,10 @@ __device__ __forceinline__ void write_tile(GrtGasOpticsArgs const &a, double con
             // tables F296,S296,CKDF,CKDS (launch.c:165-170)
             double2 const CF = two(a.h2o_tables, f, has1), CS = two(a.h2o_tables + a.nw, f, has1);
             double2 const T0F = two(a.h2o_tables + 2*a.nw, f, has1), T0 = two(a.h2o_tables + 3*a.nw, f, has1);
-            v0 += h2o[0]*((CS.x*h2o[1]*exp(T0.x*h2o[3])) + (CF.x*h2o[2]*exp(T0F.x*h2o[3])));
-            v1 += h2o[0]*((CS.y*h2o[1]*exp(T0.y*h2o[3])) + (CF.y*h2o[2]*exp(T0F.y*h2o[3])));
+            // (grt_exp: exp_pair.h -- the fused solvers add this term themselves where the pipeline defers it, next to their
+            // own exponentials, and must arrive at the same doubles)
+            v0 += h2o[0]*((CS.x*h2o[1]*grt_exp(T0.x*h2o[3])) + (CF.x*h2o[2]*grt_exp(T0F.x*h2o[3])));
+            v1 += h2o[0]*((CS.y*h2o[1]*grt_exp(T0.y*h2o[3])) + (CF.y*h2o[2]*grt_exp(T0F.y*h2o[3])));
         }
         for (int k = 0; add_tables && k < a.lay.num_tables; ++k)
         {

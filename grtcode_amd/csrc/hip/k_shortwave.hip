@@ -52,7 +52,7 @@ __device__ __forceinline__ LayerRT eddington(double omega, double tau, double mu
     if (omega <= 0.0)
     {
         r.R = 0.;
-        r.T = exp(-tau/mu);
+        r.T = grt_exp(-tau/mu);         // (exp_pair.h: the constants this kernel holds anyway)
         r.Tpure = r.T;
     }
     else

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../grt_kernels.h"
+#include "exp_pair.h"
 
 #pragma clang fp contract(off)
 
@@ -91,7 +92,7 @@ __device__ __forceinline__ double continua_add(GrtContinua const &c, PointContin
     if (pc.h2o)
     {
         double const *h2o = col_state + c.off_h2o + (uint64_t)layer*4;
-        v += h2o[0]*((pc.cs*h2o[1]*exp(pc.t0*h2o[3])) + (pc.cf*h2o[2]*exp(pc.t0f*h2o[3])));
+        v += h2o[0]*((pc.cs*h2o[1]*grt_exp(pc.t0*h2o[3])) + (pc.cf*h2o[2]*grt_exp(pc.t0f*h2o[3])));
     }
 #pragma unroll
     for (int q = 0; q < kContinuaRegs; ++q)

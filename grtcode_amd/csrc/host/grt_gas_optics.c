@@ -774,6 +774,7 @@ EXTERN int destroy_gas_optics(GasOptics_t * const gas_optics)
         GRT_TRY(free_store(gas_optics));
         GRT_TRY(grt_dev_free(gas_optics->device, im->bins_block));
         GRT_TRY(grt_dev_free(gas_optics->device, im->gmom));
+        GRT_TRY(grt_dev_free(gas_optics->device, im->radius_table));
         GRT_TRY(grt_dev_free(gas_optics->device, im->h2o_tables));
         GRT_TRY(grt_dev_free(gas_optics->device, im->lin_tables));
         GRT_TRY(grt_dev_free(gas_optics->device, im->colstate_d));
@@ -1956,6 +1957,21 @@ int grt_fill_gas_args(GasOptics_t *go, int ncol, double *tau, uint64_t tau_col_s
                 if (!im->sizing_only)
                 {
                     a->gmom = im->gmom;
+                    if (a->tree_levels == 0)
+                    {
+                        /* the cell tiles' near-field radii, worked out once per launch for the gather's workgroups */
+                        size_t const tiles = (size_t)((a->nw + (uint64_t)a->tile - 1)/(uint64_t)a->tile);
+                        size_t const want = sizeof(int)*tiles*(size_t)go->num_layers*(size_t)ncol;
+                        if (want > im->radius_bytes)
+                        {
+                            GRT_TRY(grt_dev_free(go->device, im->radius_table));
+                            im->radius_table = NULL;
+                            im->radius_bytes = 0;
+                            GRT_TRY(grt_dev_alloc(go->device, (void **)&im->radius_table, want));
+                            im->radius_bytes = want;
+                        }
+                        a->radius_table = im->radius_table;
+                    }
                 }
             }
             else

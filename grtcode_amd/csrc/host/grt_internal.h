@@ -104,6 +104,8 @@ typedef struct GrtGasOpticsImpl
     void *bins_block;              /* device allocation backing bins.w / bins.l / bins.r / bins.tau */
     float *gmom;                   /* two-pass moment kernel: [ncol][L][8][n] cell moments */
     size_t gmom_bytes;
+    int *radius_table;             /* GrtGasOpticsArgs.radius_table */
+    size_t radius_bytes;
     size_t scratch_cap_bytes;      /* ... and what the object may hold of it (0: not asked yet; launch_columns) */
     size_t scratch_per_column;     /* ... what ONE column of the current form needs of it (set by grt_fill_gas_args) */
     int sizing_only;               /* grt_fill_gas_args: work the launch parameters out, allocate nothing */
