@@ -222,6 +222,52 @@ def test_one_sweep_shortwave_solver_equals_the_two_sweeps(bands, lib, device, us
     go_sw.destroy()
 
 
+@pytest.mark.parametrize("fast", [0, 3])
+def test_tables_part_of_tau_added_by_the_shortwave_solver_is_the_same_doubles(bands, lib, device, fast, monkeypatch):
+    """The production pipeline's shortwave gas-optics launch leaves the spectral tables' part of tau (continua, CFC, CIA) to
+    the solver kernel, which reads a table entry once per point (GrtGasOpticsArgs.skip_tables, GrtContinua) -- the same
+    expressions in the same order: fluxes AND the tau_gas a caller looks at afterwards (grt_pipeline_views completes it)
+    are bit for bit those of a run that adds the tables in the gas-optics kernel (GRT_DEFER_CONTINUA=0).  The gas-optics
+    object's own entry point still delivers the whole tau after it served a pipeline."""
+    lwb, swb = bands
+    V, ncol = 16, 3
+    cols = [syn.profile(60 + c, V) for c in range(ncol)]
+    go_lw, grid_lw = lwb.gas_optics(device, V)
+    go_sw, grid_sw = swb.gas_optics(device, V)
+    go_lw.tune(fast=fast)
+    go_sw.tune(fast=fast)
+    emis, alb = np.full(lwb.nw, 0.98), np.full(swb.nw, 0.2)
+    solar = api.create_solar_flux(grid_sw, swb.files["solar"])
+    gcols, keep = api.make_columns(cols, MOL_ORDER, cfc_order=(0, 1))
+    api.check(lib.grt_set_deterministic(1))
+    try:
+        flux, tau = {}, {}
+        for defer in ("1", "0"):
+            monkeypatch.setenv("GRT_DEFER_CONTINUA", defer)
+            pipe = api.Pipeline(go_lw, go_sw, ncol, -1, emis, alb, solar, spectral=False)
+            pipe.run(gcols)
+            flux[defer] = pipe.fluxes(ncol)
+            tau[defer] = api.device_to_host(device, pipe.views(1)["tau_gas"], (ncol, V - 1, swb.nw)).copy()
+            again = api.device_to_host(device, pipe.views(1)["tau_gas"], (ncol, V - 1, swb.nw))
+            assert np.array_equal(again, tau[defer])                # (looked at twice: completed once)
+            pipe.destroy()
+        assert np.array_equal(flux["1"], flux["0"])
+        assert np.array_equal(tau["1"], tau["0"])
+        with_tables = tau["0"][0]
+        swb.set_column(go_sw, cols[0])
+        opt = api.OpticsObject(V - 1, grid_sw, device)
+        go_sw.calculate_optical_depth(cols[0]["p"], cols[0]["t"], opt)
+        direct = opt.read()[0]
+        opt.destroy()
+        assert np.array_equal(direct, with_tables)
+        swb_plain = np.abs(with_tables).max()
+        assert swb_plain > 0.0
+    finally:
+        api.check(lib.grt_set_deterministic(-1))
+    go_lw.destroy()
+    go_sw.destroy()
+
+
 def test_two_pipelines_on_two_lanes_equal_one(bands, lib, device):
     """grt_device_use_lane (grt_ext.h): two pipelines with gas-optics objects of their own, each on a stream of its own,
     batches alternating between them without a wait in between -- the fluxes are those of one pipeline run batch by batch."""
