@@ -920,7 +920,7 @@ extern "C" int grt_launch_far_field(void *stream, GrtGasOpticsArgs const *bp, lo
     if (far_want < 0)
     {
         char const *env = getenv("GRT_FAR_TILE");
-        far_want = env != NULL && atoi(env) >= 64 ? atoi(env) : 512;      // measured on G1: 256 -> 0.99 ms, 512 -> 0.90, 1 024 -> 1.42 (occupancy)
+        far_want = env != NULL && atoi(env) >= 64 ? atoi(env) : 512;      // shortwave launch of 64 columns (round 5): 256 -> 3.97 ms, 512 -> 3.12, 1 024 -> 3.86
     }
     int far_tile = b.tile;
     while (2*far_tile <= far_want && (uint64_t)far_tile < b.nw
