@@ -7,9 +7,10 @@
 
 namespace {
 
-// The near-field radii of the first pass's cell tiles, [col][layer][tile]: one workgroup per (layer, column).  The gather's
-// workgroups each need the radii of the ten or so tiles within reach; worked out there -- by ten threads, behind a barrier
-// of their own, from a staged column state -- they were 0.25 of the shortwave gather's 4.2 ms per 64 columns.
+// The near-field radii of the first pass's cell tiles, [col][layer][tile]: one workgroup per (layer, column); an entry is
+// near_radius()'s R | use_moments << 16 | corrected << 17.  The gather's workgroups each need the radii of the ten or so
+// tiles within reach; worked out there -- by ten threads, behind a barrier of their own, from a staged column state -- they
+// were 0.5 of the shortwave gather's 3.5 ms per 64 columns.  The first pass's workgroups read their own tile's entry too.
 __global__ __launch_bounds__(kBlock) void near_radius_kernel(GrtGasOpticsArgs a, long long fsteps_ll, int cell_shift, int ntiles)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -26,8 +27,8 @@ __global__ __launch_bounds__(kBlock) void near_radius_kernel(GrtGasOpticsArgs a,
     {
         long long const c1 = ((long long)(t + 1) << cell_shift);
         bool um, cr;
-        a.radius_table[((uint64_t)col*a.lay.num_layers + layer)*ntiles + t] =
-            near_radius(a, lay, ms_l, (long long)t << cell_shift, c1 < nw ? c1 : nw, (int)fsteps_ll, &um, &cr);
+        int const R = near_radius(a, lay, ms_l, (long long)t << cell_shift, c1 < nw ? c1 : nw, (int)fsteps_ll, &um, &cr);
+        a.radius_table[((uint64_t)col*a.lay.num_layers + layer)*ntiles + t] = R | (um ? 0x10000 : 0) | (cr ? 0x20000 : 0);
     }
 }
 
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(kBlock) void gas_optics_far_kernel(GrtGasOpticsArgs
     if (!own_radii && tid <= t1 - t0)
     {
         int const ntiles = (int)((nw + ((long long)1 << cell_shift) - 1) >> cell_shift);
-        rtab[tid] = a.radius_table[((uint64_t)col*a.lay.num_layers + layer)*ntiles + t0 + tid];
+        rtab[tid] = a.radius_table[((uint64_t)col*a.lay.num_layers + layer)*ntiles + t0 + tid] & 0xffff;
     }
     __syncthreads();
     if (own_radii)
@@ -892,6 +893,15 @@ extern "C" int grt_tree_gather_by_wave(long long fsteps)
     return tree_gather_by_wave(fsteps) ? 1 : 0;
 }
 
+// Before the first pass (single-level form, b.radius_table set by the host): the cell tiles' near-field radii for both passes.
+extern "C" int grt_launch_near_radius(void *stream, GrtGasOpticsArgs const *bp, long long fsteps, int shift)
+{
+    int const ntiles = (int)((bp->nw + ((uint64_t)1 << shift) - 1) >> shift);
+    hipLaunchKernelGGL(near_radius_kernel, dim3(bp->lay.num_layers, bp->ncol), dim3(kBlock),
+                       sizeof(double)*bp->lay.num_slots*(4 + GRT_MAX_ISO), (hipStream_t)stream, *bp, fsteps, shift, ntiles);
+    return (int)hipGetLastError();
+}
+
 // The second pass of a launch whose first pass has been queued on `stream`: b as the first pass's launcher set it up (halo,
 // near_block, mom_terms, nslice = 1 ...), shift = log2 of the first pass's cell-tile size.
 extern "C" int grt_launch_far_field(void *stream, GrtGasOpticsArgs const *bp, long long fsteps, int shift)
@@ -927,12 +937,6 @@ extern "C" int grt_launch_far_field(void *stream, GrtGasOpticsArgs const *bp, lo
            && far_lds_bytes(2*far_tile, 2*far_tile + 2*(int)fsteps, (int)fsteps, b.lay.num_slots, shift) <= kLdsPerWorkgroup)
     {
         far_tile *= 2;
-    }
-    if (b.radius_table != nullptr)
-    {
-        int const ntiles = (int)((b.nw + ((uint64_t)1 << shift) - 1) >> shift);
-        hipLaunchKernelGGL(near_radius_kernel, dim3(b.lay.num_layers, b.ncol), dim3(kBlock),
-                           sizeof(double)*b.lay.num_slots*(4 + GRT_MAX_ISO), s, b, fsteps, shift, ntiles);
     }
     b.tile = far_tile;
     unsigned const far_tiles = (unsigned)((b.nw + far_tile - 1)/far_tile);

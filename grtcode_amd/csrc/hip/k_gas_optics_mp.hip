@@ -36,6 +36,7 @@ extern "C" int grt_tree_gather_tile(void);
 extern "C" int grt_tree_gather_ntab(int tile, int halo);
 extern "C" int grt_tree_gather_by_wave(long long fsteps);
 extern "C" int grt_launch_far_field(void *stream, GrtGasOpticsArgs const *b, long long fsteps, int shift);
+extern "C" int grt_launch_near_radius(void *stream, GrtGasOpticsArgs const *b, long long fsteps, int shift);
 
 namespace {
 
@@ -277,7 +278,20 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
 
     bool use_moments;
     bool corrected;
-    int const R = near_radius(a, lay, ms_l, TWO_PASS ? F0l : F0l - fsteps_ll, F1l, fsteps, &use_moments, &corrected);
+    int R;
+    if (TWO_PASS && !TREE && a.radius_table != nullptr)
+    {
+        // (single-level form: the launcher had the cell tiles' radii worked out once -- near_radius_kernel, the same call)
+        int const ntiles = (int)((nw + a.tile - 1)/a.tile);
+        int const packed = a.radius_table[((uint64_t)col*a.lay.num_layers + layer)*ntiles + F0/a.tile];
+        R = packed & 0xffff;
+        use_moments = (packed & 0x10000) != 0;
+        corrected = (packed & 0x20000) != 0;
+    }
+    else
+    {
+        R = near_radius(a, lay, ms_l, TWO_PASS ? F0l : F0l - fsteps_ll, F1l, fsteps, &use_moments, &corrected);
+    }
 
     // moments go to the tile's LDS block, or (tree form: ncell == 0, sparse lines, wide tiles) straight to the
     // zeroed level-0 block in global memory
@@ -828,6 +842,14 @@ extern "C" int grt_launch_gas_optics_mp(void *stream, GrtGasOpticsArgs const *a)
         if (!tree)
         {
             b.rcap = kRcap;
+        }
+        if (!tree && b.radius_table != nullptr)
+        {
+            int const rc_radius = grt_launch_near_radius(stream, &b, fsteps, shift);
+            if (rc_radius != 0)
+            {
+                return rc_radius;
+            }
         }
         int slot = a->profile_tag ? grt_profile_begin(stream, a->profile_tag) : -1;
         int const ncell = (tree && a->tile > kDirectTile) ? 0 : a->tile;
