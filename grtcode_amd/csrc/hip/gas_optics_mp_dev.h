@@ -354,6 +354,41 @@ __device__ int near_radius(GrtGasOpticsArgs const &a, double const *lay, double 
     return *use_moments ? R : fsteps;
 }
 
+// What the seven-point near fields of a (cell tile, layer) are made of, from bounds on its lines' Doppler widths -- bits of
+// one word, decided once per (tile, layer, column) (mp_lean_block.inc reads them; near_radius_kernel tabulates them):
+//   stim / farir the stimulated-emission factor is not 1 to fp32 / needs its series
+//   corrected    region 1 beyond the near field is folded into the moments
+//   lreg         only a line's own grid point can be anything but Lorentzian (half a grid step >= XLIM0 Doppler units)
+//   v1           all seven points of every line lie in Humlicek region 1
+//   nc_one       only a line's own grid point can be a near-centre point (|x| < XLIM1); nc_three: or its two neighbours
+enum : unsigned { kTfStim = 1u, kTfFarir = 2u, kTfCorrected = 4u, kTfLreg = 8u, kTfV1 = 16u, kTfNcOne = 32u, kTfNcThree = 64u };
+constexpr int kTileFlagsShift = 18;     // a radius-table entry: R | use_moments << 16 | corrected << 17 | flags << 18
+
+__device__ inline unsigned lean_tile_flags(GrtGasOpticsArgs const &a, double const *lay, double const *ms_l, int F0, int F1, bool corrected)
+{
+    // stimulated emission 1 - exp(c2 v0/T) (kernels.c:84): 1 to fp32 and beyond below exp(-20); the tile's lowest
+    // wavenumber decides for the whole workgroup (sorted store, shifts of a fraction of a grid step)
+    double const x2_tile = ((double)(-1.4387686f)*lay[2])*(a.w0 + ((double)F0 - 2.)*a.wres - 1.);
+    unsigned tf = (x2_tile > -21. ? kTfStim : 0u) | (x2_tile > -1.1 ? kTfFarir : 0u) | (corrected ? kTfCorrected : 0u);
+    double dop_hi = 0., dop_lo = 1e300;
+    for (int sl = 0; sl < a.lay.num_slots; ++sl)
+    {
+        double const d = ((double)0.83255461115f/(double)kSqrln2)*ms_l[sl*4 + 3];
+        dop_hi = fmax(dop_hi, d);
+        dop_lo = d > 0. ? fmin(dop_lo, d) : dop_lo;
+    }
+    // grid step in Doppler units, wr = wres REPWID = wres/(centre x doppler factor), over the tile's lines (one cell
+    // and the largest shift of margin either side)
+    double const nu_lo = fmax(a.w0 + ((double)F0 - 1.5)*a.wres - a.lines.dmax*fabs(lay[0]), 1e-3);
+    double const nu_hi = a.w0 + ((double)F1 + 0.5)*a.wres + a.lines.dmax*fabs(lay[0]);
+    double const wr_min = dop_hi > 0. ? a.wres/(nu_hi*dop_hi) : 0.;
+    double const wr_max = dop_lo < 1e300 ? a.wres/(nu_lo*dop_lo) : 1e300;
+    // XLIM0^2 = 15100 + y (40 - 3.6 y) <= 15211.2 (y = 5.56), >= 15100 for y <= 4; XLIM1^2 <= 164 (RFM_voigt.c:109-118)
+    tf |= (0.25*wr_min*wr_min >= 1.003*15211.2 ? kTfLreg : 0u) | ((corrected && 12.25*wr_max*wr_max < 0.999*15100.) ? kTfV1 : 0u)
+          | (0.25*wr_min*wr_min >= 164.1 ? kTfNcOne : 0u) | (2.25*wr_min*wr_min >= 164.1 ? kTfNcThree : 0u);
+    return tf;
+}
+
 // ---- the cell hierarchy of the tree form (described above gas_optics_tree_kernel): sizes, offsets, the shift of
 // a child's moments to its parent's centre ----
 constexpr int kMaxLevels = 20;

@@ -8,7 +8,7 @@
 namespace {
 
 // The near-field radii of the first pass's cell tiles, [col][layer][tile]: one workgroup per (layer, column); an entry is
-// near_radius()'s R | use_moments << 16 | corrected << 17.  The gather's workgroups each need the radii of the ten or so
+// near_radius()'s R | use_moments << 16 | corrected << 17 | lean_tile_flags() << 18.  The gather's workgroups each need the radii of the ten or so
 // tiles within reach; worked out there -- by ten threads, behind a barrier of their own, from a staged column state -- they
 // were 0.5 of the shortwave gather's 3.5 ms per 64 columns.  The first pass's workgroups read their own tile's entry too.
 __global__ __launch_bounds__(kBlock) void near_radius_kernel(GrtGasOpticsArgs a, long long fsteps_ll, int cell_shift, int ntiles)
@@ -28,7 +28,9 @@ __global__ __launch_bounds__(kBlock) void near_radius_kernel(GrtGasOpticsArgs a,
         long long const c1 = ((long long)(t + 1) << cell_shift);
         bool um, cr;
         int const R = near_radius(a, lay, ms_l, (long long)t << cell_shift, c1 < nw ? c1 : nw, (int)fsteps_ll, &um, &cr);
-        a.radius_table[((uint64_t)col*a.lay.num_layers + layer)*ntiles + t] = R | (um ? 0x10000 : 0) | (cr ? 0x20000 : 0);
+        long long const F1 = c1 < nw ? c1 : nw;
+        unsigned const tf = lean_tile_flags(a, lay, ms_l, (int)((long long)t << cell_shift), (int)F1, cr);
+        a.radius_table[((uint64_t)col*a.lay.num_layers + layer)*ntiles + t] = R | (um ? 0x10000 : 0) | (cr ? 0x20000 : 0) | (int)(tf << kTileFlagsShift);
     }
 }
 

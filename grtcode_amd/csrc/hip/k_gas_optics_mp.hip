@@ -279,6 +279,8 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
     bool use_moments;
     bool corrected;
     int R;
+    [[maybe_unused]] bool tile_flags_known = false;
+    [[maybe_unused]] unsigned tile_flags = 0u;
     if (TWO_PASS && !TREE && a.radius_table != nullptr)
     {
         // (single-level form: the launcher had the cell tiles' radii worked out once -- near_radius_kernel, the same call)
@@ -287,6 +289,8 @@ __device__ __forceinline__ void mp_kernel_body(GrtGasOpticsArgs const &a, long l
         R = packed & 0xffff;
         use_moments = (packed & 0x10000) != 0;
         corrected = (packed & 0x20000) != 0;
+        tile_flags = (unsigned)packed >> kTileFlagsShift;
+        tile_flags_known = true;
     }
     else
     {
