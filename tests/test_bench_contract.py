@@ -147,6 +147,8 @@ def test_round5_headline_line():
     assert line["ms_per_step"] <= 112.0 and line["value"] >= 570.0                       # VERDICT r4, task 1's speed target
     k = line["kernel_ms_per_step"]
     assert k["gas_optics_lw"] <= 27.0                                                     # ... its longwave target
+    assert k["gas_optics_sw"] <= 74.0                                                     # ... its shortwave target (no core-point kernel: fused)
+    assert k["far_field_sw"] + k["sw_solver"] <= 7.0                                      # task 6: the shortwave tail
     assert abs(sum(k.values()) - line["ms_per_step"]) / line["ms_per_step"] < 0.03      # the kernels' durations ARE the step
     r = line["roofline"]
     assert r["bound"] == "valu_issue" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.3 < r["frac"] < 1.0
