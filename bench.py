@@ -387,7 +387,7 @@ class PlaceholderEngine:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)       # (a timed region of >= 3 s at ~134 ms per step)
+    ap.add_argument("--steps", type=int, default=30)       # (a timed region of >= 3 s at ~103 ms per step)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cols", type=int, default=int(os.environ.get("GRT_BENCH_COLS", 64)), help="columns per GPU per step (weak scaling)")
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("GRT_BENCH_CHUNK", 64)), help="columns per launch of the pipeline "
