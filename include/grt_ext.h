@@ -142,7 +142,10 @@ EXTERN int grt_pipeline_sync(GrtPipeline_t *pipeline);
 /* The HIP stream every kernel of this device is enqueued on (for event timing). */
 EXTERN void *grt_pipeline_stream(GrtPipeline_t *pipeline);
 /* Device views of the last run's spectral arrays (for parity tests): band 0 = lw, 1 = sw.  tau_gas always; the rest
-   only on a pipeline created with keep_spectra = 1 (GRTCODE_VALUE_ERR otherwise). */
+   only on a pipeline created with keep_spectra = 1 (GRTCODE_VALUE_ERR otherwise).  (keep_spectra = 0: the shortwave
+   solver adds the spectral tables' part of tau -- continua, CFC, CIA -- itself, from tables it reads once per grid point;
+   asking for tau_gas queues, once per run, the small kernel that adds that part to the array: the same doubles a
+   gas-optics call delivers.  Asynchronous on the pipeline's stream like the run.) */
 EXTERN int grt_pipeline_views(GrtPipeline_t *pipeline, int band, fp_t **tau_gas, fp_t **tau,
                               fp_t **omega, fp_t **g, fp_t **flux_up, fp_t **flux_down);
 
