@@ -1,5 +1,6 @@
 #!/bin/bash
-# Timing experiments on the far-field gather: variants of k_gas_optics_far.hip under other flags.
+# Timing experiments on the far-field gather: variants of k_gas_optics_far.hip under other flags (-D macros put into the
+# source for the experiment and taken out again: profiles/r5_sw_tail_steps.txt lists the ones of round 5 and what they showed).
 #   local:   bash scripts/far_variants.sh build "name:flags" ...     GPU box: bash scripts/far_variants.sh run name ... [-- bench args]
 set -e
 cd "$(dirname "$0")/.."
