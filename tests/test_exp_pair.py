@@ -39,11 +39,16 @@ int main(void)
         double const a = ulps(p, expl((long double)x)), b = ulps(m, expl(-(long double)x));
         worst = a > worst ? a : worst;
         worst = b > worst ? b : worst;
+        double const one = ulps(grt_exp(x), expl((long double)x));         /* the single exponential: the same parts */
+        worst = one > worst ? one : worst;
+        if (grt_exp(x) != p) worst = 99.;                                   /* ... the pair's e^x, bit for bit */
     }
     double p, m, pn, mn;
     grt_exp_pair(0., &p, &m);
     grt_exp_pair(NAN, &pn, &mn);
-    printf("%%.4f %%d %%d\n", worst, p == 1. && m == 1., pn != pn && mn != mn);
+    int const limits = grt_exp(800.) == INFINITY && grt_exp(-800.) == 0. && grt_exp(INFINITY) == INFINITY && grt_exp(-INFINITY) == 0.
+                       && grt_exp(NAN) != grt_exp(NAN) && grt_exp(0.) == 1.;
+    printf("%%.4f %%d %%d %%d\n", worst, p == 1. && m == 1., pn != pn && mn != mn, limits);
     return 0;
 }
 """
@@ -54,7 +59,8 @@ def test_exp_pair_is_within_about_one_unit_in_the_last_place(tmp_path):
     src.write_text(PROGRAM % HEADER)
     exe = tmp_path / "t"
     subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", str(exe), str(src), "-lm"], check=True)
-    worst, one_at_zero, nan_in_nan_out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    worst, one_at_zero, nan_in_nan_out, limits = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     print("worst error of e^x / e^-x:", worst, "units in the last place")
     assert float(worst) < 1.06
     assert one_at_zero == "1" and nan_in_nan_out == "1"
+    assert limits == "1"            # grt_exp beyond its clamp: inf / 0 as exp gives, NaN for NaN
