@@ -491,6 +491,11 @@ def main():
         # alternate between them, so that the end of one launch's work (far-field gather, solvers) can overlap the next
         # launch's line kernel.  Same work per step; nothing is shared between the lanes.  Default 1 (two lanes: +2 %, but overlapping kernel durations).
         lanes = max(1, min(args.lanes, 4, -(-max(count, 1) // chunk)))
+        if lanes < args.lanes and rank == 0:
+            # (a step of `count` columns is ceil(count/chunk) launches: that many can be in flight.  Round 5's first
+            # "two streams" line had asked for two with one launch per step and timed one: say so)
+            print(f"bench.py: --lanes {args.lanes} asked for, {lanes} used: a step of {count} columns is {-(-max(count, 1) // chunk)} "
+                  f"launch(es) of {chunk}; give --cols {args.lanes * chunk} --chunk {chunk} for {args.lanes} launches in flight", file=sys.stderr)
         os.environ.setdefault("GRT_LINES_CACHE", os.path.join(os.environ.get("TMPDIR", "/tmp"), f"grt_lines_cache_{os.getuid()}"))
         wls = []
         for k in range(lanes):
